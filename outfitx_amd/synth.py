@@ -1,0 +1,233 @@
+"""Deterministic synthetic weights and inputs for the OutfitX scoring path.
+
+Nothing here is model code: it is the seeded generator that the golden-vector
+script (oracle/gen_golden.py), the parity tests and bench.py share, so that
+fixtures only need to store OUTPUTS (the 202 M parameters and the pixel tensors
+are regenerated from a seed on whichever box runs the test).
+
+Every tensor is drawn from its own PCG64 stream keyed by (seed, crc32(name)), so
+any subset of a state dict can be generated independently and in any order.
+
+Shapes and key names follow the reference's state_dict as enumerated in
+SURVEY.md §8(b) (reference: src/models/outfit_x.py:25-90 and the HF CLIP modules
+built by src/models/encoders/image_encoders/clip_image_encoder.py:20-22 and
+src/models/encoders/text_encoders/clip_text_encoder.py:19-21).
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Dict, Iterable, Tuple
+
+import numpy as np
+
+# ---- dimensions of the path -------------------------------
+D_MODEL = 1024
+N_HEAD = 16
+D_FFN = 2024
+N_LAYERS = 6
+D_HALF = 512
+
+VIT_WIDTH, VIT_LAYERS, VIT_HEADS, VIT_MLP, VIT_PATCH, VIT_IMG, VIT_POS = 768, 12, 12, 3072, 32, 224, 50
+TXT_WIDTH, TXT_LAYERS, TXT_HEADS, TXT_MLP, TXT_VOCAB, TXT_POS = 512, 12, 8, 2048, 49408, 77
+PROJ_DIM = 512
+BOS_ID, EOS_ID = 49406, 49407
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def _rng(seed: int, name: str) -> np.random.Generator:
+    return np.random.Generator(np.random.PCG64(np.random.SeedSequence([int(seed), zlib.crc32(name.encode())])))
+
+
+def outfit_transformer_shapes() -> Dict[str, Tuple[int, ...]]:
+    """Key → shape for the 51,155,313 trainable parameters (no item encoder)."""
+    s: Dict[str, Tuple[int, ...]] = {
+        "outfit_token": (D_MODEL,),
+        "target_item_image_emb": (D_HALF,),
+        "cp_ffn.1.weight": (1, D_MODEL),
+        "cp_ffn.1.bias": (1,),
+        "cir_ffn.0.weight": (D_MODEL, D_MODEL),
+    }
+    for i in range(N_LAYERS):
+        p = f"transformer_encoder.layers.{i}."
+        s[p + "self_attn.in_proj_weight"] = (3 * D_MODEL, D_MODEL)
+        s[p + "self_attn.in_proj_bias"] = (3 * D_MODEL,)
+        s[p + "self_attn.out_proj.weight"] = (D_MODEL, D_MODEL)
+        s[p + "self_attn.out_proj.bias"] = (D_MODEL,)
+        s[p + "linear1.weight"] = (D_FFN, D_MODEL)
+        s[p + "linear1.bias"] = (D_FFN,)
+        s[p + "linear2.weight"] = (D_MODEL, D_FFN)
+        s[p + "linear2.bias"] = (D_MODEL,)
+        for n in ("norm1", "norm2"):
+            s[p + n + ".weight"] = (D_MODEL,)
+            s[p + n + ".bias"] = (D_MODEL,)
+    return s
+
+
+def _clip_layer_shapes(prefix: str, width: int, mlp: int, n_layers: int) -> Dict[str, Tuple[int, ...]]:
+    s: Dict[str, Tuple[int, ...]] = {}
+    for i in range(n_layers):
+        p = f"{prefix}encoder.layers.{i}."
+        for proj in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            s[p + f"self_attn.{proj}.weight"] = (width, width)
+            s[p + f"self_attn.{proj}.bias"] = (width,)
+        s[p + "layer_norm1.weight"] = (width,)
+        s[p + "layer_norm1.bias"] = (width,)
+        s[p + "mlp.fc1.weight"] = (mlp, width)
+        s[p + "mlp.fc1.bias"] = (mlp,)
+        s[p + "mlp.fc2.weight"] = (width, mlp)
+        s[p + "mlp.fc2.bias"] = (width,)
+        s[p + "layer_norm2.weight"] = (width,)
+        s[p + "layer_norm2.bias"] = (width,)
+    return s
+
+
+def vision_shapes(n_layers: int = VIT_LAYERS) -> Dict[str, Tuple[int, ...]]:
+    """Key → shape of HF CLIPVisionModelWithProjection (ViT-B/32), keys relative to `….image_enc.model.`"""
+    v = "vision_model."
+    s: Dict[str, Tuple[int, ...]] = {
+        v + "embeddings.class_embedding": (VIT_WIDTH,),
+        v + "embeddings.patch_embedding.weight": (VIT_WIDTH, 3, VIT_PATCH, VIT_PATCH),
+        v + "embeddings.position_embedding.weight": (VIT_POS, VIT_WIDTH),
+        v + "pre_layrnorm.weight": (VIT_WIDTH,),
+        v + "pre_layrnorm.bias": (VIT_WIDTH,),
+    }
+    s.update(_clip_layer_shapes(v, VIT_WIDTH, VIT_MLP, n_layers))
+    s[v + "post_layernorm.weight"] = (VIT_WIDTH,)
+    s[v + "post_layernorm.bias"] = (VIT_WIDTH,)
+    s["visual_projection.weight"] = (PROJ_DIM, VIT_WIDTH)
+    return s
+
+
+def text_shapes(n_layers: int = TXT_LAYERS) -> Dict[str, Tuple[int, ...]]:
+    """Key → shape of HF CLIPTextModelWithProjection, keys relative to `….text_enc.model.`"""
+    t = "text_model."
+    s: Dict[str, Tuple[int, ...]] = {
+        t + "embeddings.token_embedding.weight": (TXT_VOCAB, TXT_WIDTH),
+        t + "embeddings.position_embedding.weight": (TXT_POS, TXT_WIDTH),
+    }
+    s.update(_clip_layer_shapes(t, TXT_WIDTH, TXT_MLP, n_layers))
+    s[t + "final_layer_norm.weight"] = (TXT_WIDTH,)
+    s[t + "final_layer_norm.bias"] = (TXT_WIDTH,)
+    s["text_projection.weight"] = (PROJ_DIM, TXT_WIDTH)
+    return s
+
+
+def _draw(seed: int, name: str, shape: Tuple[int, ...]) -> np.ndarray:
+    """One tensor. Scales are chosen so activations stay O(1) and softmax is not flat
+    (a parity test on near-uniform attention would not exercise the softmax)."""
+    g = _rng(seed, name)
+    z = g.standard_normal(shape, dtype=np.float32)
+    leaf = name.rsplit(".", 1)[-1]
+    if len(shape) == 1:
+        if "norm" in name and leaf == "weight":
+            return (1.0 + 0.1 * z).astype(np.float32)
+        if "norm" in name and leaf == "bias":
+            return (0.05 * z).astype(np.float32)
+        if name in ("outfit_token", "target_item_image_emb"):
+            return (0.02 * z).astype(np.float32)
+        if name.endswith("class_embedding"):
+            return (0.5 * z).astype(np.float32)
+        return (0.02 * z).astype(np.float32)  # biases
+    if name.endswith("token_embedding.weight"):
+        return (0.5 * z).astype(np.float32)
+    if name.endswith("position_embedding.weight"):
+        return (0.1 * z).astype(np.float32)
+    fan_in = int(np.prod(shape[1:]))
+    gain = 0.5 if any(k in name for k in ("out_proj", "fc2", "linear2")) else 1.0
+    return (z * np.float32(gain / np.sqrt(fan_in))).astype(np.float32)
+
+
+def make_weights(seed: int, shapes: Dict[str, Tuple[int, ...]], prefix: str = "") -> Dict[str, np.ndarray]:
+    """name → fp32 ndarray. `prefix` is prepended to the returned keys only; the random
+    stream is keyed by the un-prefixed name so the same tensor is drawn either way."""
+    return {prefix + k: _draw(seed, k, shp) for k, shp in shapes.items()}
+
+
+def outfit_transformer_weights(seed: int) -> Dict[str, np.ndarray]:
+    return make_weights(seed, outfit_transformer_shapes())
+
+
+def vision_weights(seed: int, prefix: str = "", n_layers: int = VIT_LAYERS) -> Dict[str, np.ndarray]:
+    return make_weights(seed, vision_shapes(n_layers), prefix)
+
+
+def text_weights(seed: int, prefix: str = "", n_layers: int = TXT_LAYERS) -> Dict[str, np.ndarray]:
+    return make_weights(seed, text_shapes(n_layers), prefix)
+
+
+IMG_PREFIX = "item_encoder.image_enc.model."
+TXT_PREFIX = "item_encoder.text_enc.model."
+
+
+def full_state_dict(seed: int) -> Dict[str, np.ndarray]:
+    """All 474 tensors / 202,432,625 parameters under the reference's key names."""
+    sd = outfit_transformer_weights(seed)
+    sd.update(vision_weights(seed, IMG_PREFIX))
+    sd.update(text_weights(seed, TXT_PREFIX))
+    return sd
+
+
+# ---- inputs ---------------------------------------------------------------
+def item_embeddings(seed: int, name: str, *lead: int) -> np.ndarray:
+    """[*lead, 1024] fp32 rows shaped like ItemEncoder output: each 512-half L2-normalised
+    (reference: base_image_encoder.py:46-47, base_text_encoder.py:37-38, model_utils.py:40-41)."""
+    g = _rng(seed, name)
+    z = g.standard_normal((*lead, 2, D_HALF), dtype=np.float32)
+    z /= np.maximum(np.linalg.norm(z, axis=-1, keepdims=True), 1e-12)
+    return z.reshape(*lead, D_MODEL).astype(np.float32)
+
+
+def unit_rows(seed: int, name: str, *shape: int) -> np.ndarray:
+    g = _rng(seed, name)
+    z = g.standard_normal(shape, dtype=np.float32)
+    z /= np.maximum(np.linalg.norm(z, axis=-1, keepdims=True), 1e-12)
+    return z.astype(np.float32)
+
+
+def outfit_batch(seed: int, B: int, L: int = 16, n_items=8, name: str = "outfits"):
+    """(outfit_embedding [B,L,1024] fp32, outfit_mask [B,L] bool) exactly as the reference's
+    collate emits them (outfit_x_base_processor.py:20-43): real rows first, zero pad rows after,
+    mask True on the pad rows. `n_items` is an int or a length-B sequence."""
+    n = np.full(B, n_items, dtype=np.int64) if np.isscalar(n_items) else np.asarray(n_items, dtype=np.int64)
+    assert n.shape == (B,) and n.min() >= 0 and n.max() <= L
+    emb = item_embeddings(seed, name, B, L)
+    mask = np.arange(L)[None, :] >= n[:, None]
+    emb[mask] = 0.0
+    return emb, mask
+
+
+def ragged_lengths(seed: int, B: int, lo: int, hi: int, name: str = "lengths") -> np.ndarray:
+    return _rng(seed, name).integers(lo, hi + 1, size=B).astype(np.int64)
+
+
+def pixel_values(seed: int, N: int, name: str = "pixels") -> np.ndarray:
+    """[N,3,224,224] fp32: uniform uint8 images after the CLIP rescale+normalise that the
+    reference's host-side CLIPImageProcessor applies (clip_image_encoder.py:29-31,69-71)."""
+    g = _rng(seed, name)
+    u8 = g.integers(0, 256, size=(N, 3, VIT_IMG, VIT_IMG), dtype=np.uint8)
+    mean = np.asarray(CLIP_MEAN, np.float32).reshape(1, 3, 1, 1)
+    std = np.asarray(CLIP_STD, np.float32).reshape(1, 3, 1, 1)
+    return ((u8.astype(np.float32) * np.float32(1 / 255.0) - mean) / std).astype(np.float32)
+
+
+def token_batch(seed: int, N: int, T: int = 64, n_real=8, name: str = "tokens"):
+    """(input_ids [N,T] int64, attention_mask [N,T] int64) shaped like
+    CLIPTokenizer(max_length=64, padding='max_length') output (clip_text_encoder.py:42-50):
+    BOS, words, EOS, then EOS-id padding with attention_mask 0."""
+    g = _rng(seed, name)
+    n = np.full(N, n_real, dtype=np.int64) if np.isscalar(n_real) else np.asarray(n_real, dtype=np.int64)
+    assert n.min() >= 2 and n.max() <= T
+    ids = np.full((N, T), EOS_ID, dtype=np.int64)
+    ids[:, 0] = BOS_ID
+    words = g.integers(1000, 40000, size=(N, T), dtype=np.int64)
+    pos = np.arange(T)[None, :]
+    inner = (pos >= 1) & (pos < (n[:, None] - 1))
+    ids[inner] = words[inner]
+    att = (pos < n[:, None]).astype(np.int64)
+    return ids, att
+
+
+def checksum(a: np.ndarray) -> str:
+    return f"{zlib.crc32(np.ascontiguousarray(a).tobytes()):08x}"

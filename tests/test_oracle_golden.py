@@ -1,0 +1,102 @@
+"""Pin the numpy oracle (oracle/np_oracle.py) to outputs of the reference itself
+(tests/golden/*.npz, written by oracle/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import golden, rel_err
+from oracle import np_oracle as O
+from outfitx_amd import synth
+
+TOL = 2e-5  # fp32 numpy vs fp32 torch: different summation orders only
+
+
+@pytest.mark.parametrize("tag", ["ot_cfg1", "ot_ragged"])
+def test_outfit_transformer_cp_and_cir(tag, ot_weights):
+    g = golden(tag)
+    B, seed = int(g["B"]), int(g["seed"])
+    n = g["n_items"] if g["n_items"].ndim else int(g["n_items"])
+    emb, mask = synth.outfit_batch(seed, B, 16, n)
+    assert synth.checksum(emb) == str(g["emb_crc"])
+    taps = []
+    cp = O.cp_forward(emb, mask, ot_weights, taps=taps)
+    assert cp.shape == (B, 1)
+    assert rel_err(cp, g["cp_logits"]) < TOL
+    assert rel_err(np.stack(taps), g["cp_row0"]) < TOL
+    txt = synth.unit_rows(seed, "target_text", B, 512)
+    cir = O.cir_forward(emb, mask, txt, ot_weights)
+    assert rel_err(cir, g["cir_emb"]) < TOL
+
+
+def test_padding_is_inert(ot_weights):
+    """Padded rows never influence row 0: S=17 padded == S=1+n unpadded."""
+    emb, mask = synth.outfit_batch(5, 4, 16, 8)
+    a = O.cp_forward(emb, mask, ot_weights)
+    b = O.cp_forward(emb[:, :8], mask[:, :8], ot_weights)
+    assert rel_err(a, b) < TOL
+    emb2 = emb.copy(); emb2[:, 8:] = 123.0          # pad VALUES must not matter either
+    assert rel_err(O.cp_forward(emb2, mask, ot_weights), a) < TOL
+
+
+def test_vit_tower(vit_weights):
+    g = golden("vit_n4")
+    px = synth.pixel_values(int(g["seed"]), 4)
+    assert synth.checksum(px) == str(g["px_crc"])
+    out = O.vit_forward(px, vit_weights)
+    assert rel_err(out, g["image_embeds"]) < TOL
+
+
+def test_text_tower(txt_weights):
+    g = golden("text_n8")
+    ids, att = synth.token_batch(int(g["seed"]), 8, 64, g["n_real"])
+    assert synth.checksum(ids) == str(g["ids_crc"])
+    out = O.text_forward(ids, att, txt_weights)
+    assert rel_err(out, g["text_embeds"]) < TOL
+    # causal ⇒ tokens after the first EOS cannot change the pooled output
+    T = int(g["n_real"].max())
+    for i in (0, 2, 4):
+        n = int(g["n_real"][i])
+        o = O.text_forward(ids[i:i + 1, :n], att[i:i + 1, :n], txt_weights)
+        assert rel_err(o, g["text_embeds"][i:i + 1]) < TOL
+
+
+def test_item_encoder_and_cp_with_encoder(ot_weights, vit_weights, txt_weights):
+    g = golden("item_encoder")
+    B, L = 2, 3
+    px = synth.pixel_values(1239, B * L).reshape(B, L, 3, 224, 224)
+    ids, att = synth.token_batch(1239, B * L, 64, np.array([4, 8, 6, 3, 9, 12]))
+    ids, att = ids.reshape(B, L, 64), att.reshape(B, L, 64)
+    items = O.item_encoder(px, ids, att, vit_weights, txt_weights)
+    assert items.shape == (B, L, 1024)
+    assert rel_err(items, g["item_emb"]) < TOL
+    cp = O.cp_forward(items, g["mask"], ot_weights)
+    assert rel_err(cp, g["cp_logits"]) < 5e-5
+    assert rel_err(items[:, 0], g["precomputed"]) < TOL
+    mean = O.item_encoder(px, ids, att, vit_weights, txt_weights, method="mean")
+    assert mean.shape == g["items_mean"].shape == (2, B, 512)      # the reference's literal (buggy) shape
+    assert rel_err(mean, g["items_mean"]) < TOL
+    with pytest.raises(ValueError):
+        O.aggregate_embeddings(items, items, "sum")
+
+
+def test_scoring():
+    g = golden("scoring")
+    y = (synth.item_embeddings(1240, "y_hat", 64) * 3.0).astype(np.float32)
+    cand = synth.item_embeddings(1240, "cand", 64, 4)
+    idx, d = O.fitb_argmin(y, cand)
+    assert np.array_equal(idx, g["fitb_idx"])
+    assert rel_err(d, g["fitb_dist"]) < 1e-6
+    Q = (synth.item_embeddings(1241, "queries", 100) * 3.0).astype(np.float32)
+    P = synth.item_embeddings(1241, "pool", 5000)
+    ti, td = O.l2_topk(Q, P, 50)
+    assert rel_err(td, g["topk_dist"]) < 1e-6
+    assert np.array_equal(ti, g["topk_idx"])                      # bit-exact indices
+
+
+def test_aux_focal_and_collate():
+    g = golden("aux")
+    assert abs(O.focal_loss(g["focal_logits"], g["focal_labels"]) - float(g["focal_value"])) < 1e-6
+    lens = g["proc_lens"]
+    rows = [synth.item_embeddings(1243, f"o{i}", int(n)) for i, n in enumerate(lens)]
+    emb, mask = O.pad_outfits(rows)
+    assert synth.checksum(emb) == str(g["proc_emb_crc"])
+    assert np.array_equal(mask, g["proc_mask"])
