@@ -1,0 +1,141 @@
+/* libofx_hip.so — C ABI of the MI355X-native OutfitX compatibility-scoring forward path.
+ *
+ * The reference (Krual-T/OutfitX) is 100 % Python and has NO FFI / plugin interface; its boundary
+ * for this path is the Python nn.Module API `src.models.OutfitX` (reference src/models/outfit_x.py).
+ * This header is the boundary that sits directly UNDER that API: every entry point names the
+ * reference symbol whose arithmetic it replaces.  The Python host (outfitx_amd/) binds it with
+ * ctypes; see INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions: plain pointers and sizes only (no torch types); every pointer is a DEVICE pointer
+ * unless marked host; every launch goes to the hipStream_t passed as `stream` (void*); no
+ * function synchronises the host or allocates caller-visible memory; return 0 on success or a
+ * negative OFX_E* code with text in ofx_last_error() (thread-local).  gfx950 only.
+ */
+#ifndef OFX_H
+#define OFX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFX_ABI_VERSION 1
+
+enum { OFX_OK = 0, OFX_EINVAL = -1, OFX_ESHAPE = -2, OFX_EHIP = -3, OFX_EWORKSPACE = -4, OFX_ESTATE = -5 };
+enum ofx_dtype { OFX_F32 = 0, OFX_BF16 = 1, OFX_F16 = 2 };
+enum ofx_act { OFX_ACT_NONE = 0, OFX_ACT_QUICK_GELU = 1, OFX_ACT_GELU = 2, OFX_ACT_MISH = 3 };
+/* MFMA operand precision of a sub-model.  BF16X3 = three bf16 products per term
+ * (hi*hi + lo*hi + hi*lo, realised as one K-concatenated GEMM) ~ fp32-grade results. */
+enum ofx_precision { OFX_PREC_BF16 = 0, OFX_PREC_F16 = 1, OFX_PREC_BF16X3 = 2 };
+enum ofx_out_kind { OFX_OUT_F32 = 0, OFX_OUT_OP = 1, OFX_OUT_SPLIT3 = 2 };
+
+typedef struct ofx_handle ofx_handle;
+typedef void* ofx_stream; /* hipStream_t */
+
+const char* ofx_last_error(void);
+int ofx_abi_version(void);
+
+/* ------------------------------------------------------------------ model description ------ */
+typedef struct ofx_model_desc {
+    /* global outfit Transformer — reference src/models/configs/transformer_config.py:8-24 */
+    int d_model, n_head, d_ffn, n_layers, max_items; /* 1024, 16, 2024, 6, 16 */
+    int outfit_act;                                   /* OFX_ACT_MISH */
+    int outfit_precision;                             /* ofx_precision */
+    /* CLIP ViT-B/32 vision tower — HF CLIPVisionConfig as loaded by clip_image_encoder.py:20-22 */
+    int vit_width, vit_layers, vit_heads, vit_mlp, vit_patch, vit_image, vit_act; /* 768,12,12,3072,32,224 */
+    /* CLIP text tower — HF CLIPTextConfig as loaded by clip_text_encoder.py:19-21 */
+    int txt_width, txt_layers, txt_heads, txt_mlp, txt_vocab, txt_max_pos, txt_act, txt_eos_id; /* 512,12,8,2048,49408,77 */
+    int proj_dim;                                     /* 512 */
+    int tower_precision;                              /* OFX_PREC_BF16 | OFX_PREC_F16 */
+    float ln_eps;                                     /* 1e-5 */
+} ofx_model_desc;
+
+/* Fills *d with the configuration of the reference's type='clip' model. */
+void ofx_default_desc(ofx_model_desc* d);
+
+ofx_handle* ofx_create(int device, const ofx_model_desc* desc);
+void ofx_destroy(ofx_handle* h);
+
+/* ------------------------------------------------------------------ weight packing --------- *
+ * fp32 torch parameters (device pointers, contiguous) -> MFMA operand layout in the handle's own
+ * HBM arena.  Re-run after the parameters change (optimizer.step / load_state_dict).
+ * Pointer order = state_dict order of the reference module:
+ *   outfit: [outfit_token, target_item_image_emb, cp_ffn.1.weight, cp_ffn.1.bias, cir_ffn.0.weight]
+ *           then per layer: in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias,
+ *           linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm1.w, norm1.b, norm2.w, norm2.b
+ *   vision: [class_embedding, patch_embedding.weight, position_embedding.weight, pre_layrnorm.w, .b]
+ *           then per layer: k_proj.w,.b, v_proj.w,.b, q_proj.w,.b, out_proj.w,.b, layer_norm1.w,.b,
+ *           mlp.fc1.w,.b, mlp.fc2.w,.b, layer_norm2.w,.b ; then post_layernorm.w,.b, visual_projection.weight
+ *   text:   [token_embedding.weight, position_embedding.weight] then per layer (as vision) ;
+ *           then final_layer_norm.w,.b, text_projection.weight                                  */
+int ofx_pack_outfit_weights(ofx_handle* h, const void* const* fp32_params, int n_params, ofx_stream stream);
+int ofx_pack_vision_weights(ofx_handle* h, const void* const* fp32_params, int n_params, ofx_stream stream);
+int ofx_pack_text_weights(ofx_handle* h, const void* const* fp32_params, int n_params, ofx_stream stream);
+
+/* ------------------------------------------------------------------ workspace -------------- */
+enum ofx_op { OFX_OP_SET_ENCODER = 0, OFX_OP_VIT = 1, OFX_OP_TEXT = 2, OFX_OP_TOPK = 3 };
+/* bytes of scratch the op needs for `n` units (outfits / images / texts / queries) of `len`
+ * (max items incl. none / unused / tokens per text / pool rows). */
+size_t ofx_workspace_bytes(ofx_handle* h, int op, int n, int len);
+
+/* ------------------------------------------------------------------ hot path --------------- */
+/* Rows B/C/D of SURVEY §8a: prefix-token concat + key-padding mask + the 6-layer pre-norm
+ * Transformer encoder + "take row 0" — replaces src/models/outfit_x.py:129-142 (CP) and
+ * :154-168 (CIR) incl. the nn.TransformerEncoder call.  Padded items are skipped (pad-free).
+ *   x         [B, L, d_model] fp32 item embeddings (row-major)
+ *   pad_mask  [B, L] uint8/bool, non-zero = padded item (reference: True = pad)
+ *   prefix    [d_model] (prefix_stride 0: CP outfit_token) or [B, d_model] (stride d_model: CIR)
+ *             fp32; NULL = use the packed outfit_token
+ *   out_row0  [B, d_model] fp32: encoder output at the prefix position                         */
+int ofx_set_encoder_fwd(ofx_handle* h, const float* x, const uint8_t* pad_mask, const float* prefix,
+                        int prefix_stride, int B, int L, float* out_row0, void* ws, size_t ws_bytes,
+                        ofx_stream stream);
+/* cp_ffn = Dropout -> Linear(d_model,1): raw logit per outfit (outfit_x.py:57-61,143). */
+int ofx_cp_head(ofx_handle* h, const float* row0, int B, float* logits, ofx_stream stream);
+/* cir_ffn = Linear(d_model,d_model,bias=False) (outfit_x.py:65-67,171). */
+int ofx_cir_head(ofx_handle* h, const float* row0, int B, float* emb, void* ws, size_t ws_bytes, ofx_stream stream);
+/* CIR prefix token [target_item_image_emb ‖ target text emb] (outfit_x.py:154-158): out [B,d_model]. */
+int ofx_cir_prefix(ofx_handle* h, const float* target_text_emb, int B, float* prefix_out, ofx_stream stream);
+
+/* Row F: HF CLIPVisionModelWithProjection(pixel_values).image_embeds (clip_image_encoder.py:74-76)
+ * + optional F.normalize (base_image_encoder.py:46-47).  pixels [N,3,224,224] fp32 (already
+ * resized/normalised by the host processor); emb [N, emb_ld] fp32, written at column emb_col.   */
+int ofx_vit_b32_fwd(ofx_handle* h, const float* pixels, int N, float* emb, int emb_ld, int emb_col,
+                    int normalize, void* ws, size_t ws_bytes, ofx_stream stream);
+/* Row G: HF CLIPTextModelWithProjection(input_ids, attention_mask).text_embeds
+ * (clip_text_encoder.py:56-58) + optional F.normalize.  ids/mask [N,T] int64.  `lengths` is a HOST
+ * array [N] of tokens to compute per text (= EOS position + 1; causal attention makes later tokens
+ * irrelevant), or NULL to compute all T.                                                        */
+int ofx_clip_text_fwd(ofx_handle* h, const int64_t* ids, const int64_t* attn_mask, const int* lengths_host,
+                      int N, int T, float* emb, int emb_ld, int emb_col, int normalize, void* ws,
+                      size_t ws_bytes, ofx_stream stream);
+
+/* Row H: torch.cdist(y[B,1,D], cand[B,C,D]).squeeze(1).argmin(-1) (fill_in_the_blank_trainer.py:50-56).
+ * idx int64 [B]; dist fp32 [B,C] optional.                                                      */
+int ofx_fitb_argmin(const float* y_hat, const float* cand, int B, int C, int D, int64_t* idx, float* dist,
+                    ofx_stream stream);
+/* Row I: torch.cdist(Q,P) -> topk(k, largest=False) (complementary_item_retrieval_trainer.py:240-249).
+ * fp32-exact distances; ascending; ties -> smaller pool index.  idx int64 [nq,k] = row + index_base.  */
+int ofx_l2_topk(ofx_handle* h, const float* Q, const float* P, int nq, int np, int D, int k, int64_t index_base,
+                int64_t* idx, float* dist, void* ws, size_t ws_bytes, ofx_stream stream);
+/* Merge `parts` candidate lists (after the RCCL all-gather of per-shard top-k): in [parts,nq,k]. */
+int ofx_topk_merge(const int64_t* idx_in, const float* dist_in, int parts, int nq, int k, int64_t* idx, float* dist,
+                   ofx_stream stream);
+
+/* ------------------------------------------------------------------ op level (tests) ------- */
+int ofx_gemm(const void* A, const void* W, void* C, const float* bias, const float* resid, int M, int N, int K,
+             int lda, int ldc, int ldr, int act, int out_kind, int op_dtype, ofx_stream stream);
+int ofx_layernorm(const float* x, const int* row_idx, const float* gamma, const float* beta, void* y, int rows,
+                  int D, int ldy, int out_kind, int op_dtype, float eps, ofx_stream stream);
+int ofx_attention(const void* qkv, void* out, const int64_t* key_mask, int nseq, int seq_len, int n_head, int ld,
+                  int ldo, int k_off, int v_off, int mask_ld, int causal, float scale, int op_dtype, ofx_stream stream);
+int ofx_set_attention(const float* qkv, void* out, const int* cu_seqlens, int nseq, int n_head, int D, int ldo,
+                      int out_kind, int max_len, int only_row0, float scale, int op_dtype, ofx_stream stream);
+/* fp32 [rows, cols] -> operand type; mode 0 plain, 1 [hi|lo|hi] (activation split), 2 [hi|hi|lo] (weight split) */
+int ofx_convert(const float* src, void* dst, int rows, int cols, int mode, int op_dtype, ofx_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

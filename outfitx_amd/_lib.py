@@ -1,0 +1,95 @@
+"""ctypes binding of libofx_hip.so (the C ABI declared in include/ofx.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, an exception is
+raised.  The library is built in-tree by `make` / `__graft_entry__.build()`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libofx_hip.so")
+
+OFX_OK = 0
+F32, BF16, F16 = 0, 1, 2
+ACT_NONE, ACT_QUICK_GELU, ACT_GELU, ACT_MISH = 0, 1, 2, 3
+PREC_BF16, PREC_F16, PREC_BF16X3 = 0, 1, 2
+OUT_F32, OUT_OP, OUT_SPLIT3 = 0, 1, 2
+OP_SET_ENCODER, OP_VIT, OP_TEXT, OP_TOPK = 0, 1, 2, 3
+PRECISIONS = {"bf16": PREC_BF16, "f16": PREC_F16, "fp16": PREC_F16, "bf16x3": PREC_BF16X3}
+ACTS = {"none": ACT_NONE, "quick_gelu": ACT_QUICK_GELU, "gelu": ACT_GELU, "mish": ACT_MISH}
+
+
+class OfxError(RuntimeError):
+    pass
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "d_model", "n_head", "d_ffn", "n_layers", "max_items", "outfit_act", "outfit_precision",
+        "vit_width", "vit_layers", "vit_heads", "vit_mlp", "vit_patch", "vit_image", "vit_act",
+        "txt_width", "txt_layers", "txt_heads", "txt_mlp", "txt_vocab", "txt_max_pos", "txt_act", "txt_eos_id",
+        "proj_dim", "tower_precision")] + [("ln_eps", C.c_float)]
+
+
+_vp, _i, _f, _sz, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
+
+# name -> (restype, argtypes); every symbol include/ofx.h declares
+SIGNATURES = {
+    "ofx_last_error": (C.c_char_p, []),
+    "ofx_abi_version": (_i, []),
+    "ofx_default_desc": (None, [C.POINTER(ModelDesc)]),
+    "ofx_create": (_vp, [_i, C.POINTER(ModelDesc)]),
+    "ofx_destroy": (None, [_vp]),
+    "ofx_pack_outfit_weights": (_i, [_vp, C.POINTER(_vp), _i, _vp]),
+    "ofx_pack_vision_weights": (_i, [_vp, C.POINTER(_vp), _i, _vp]),
+    "ofx_pack_text_weights": (_i, [_vp, C.POINTER(_vp), _i, _vp]),
+    "ofx_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "ofx_set_encoder_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "ofx_cp_head": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "ofx_cir_head": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "ofx_cir_prefix": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "ofx_vit_b32_fwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "ofx_clip_text_fwd": (_i, [_vp, _vp, _vp, C.POINTER(_i), _i, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "ofx_fitb_argmin": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ofx_l2_topk": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "ofx_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ofx_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ofx_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "ofx_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "ofx_set_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "ofx_convert": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the library once; raise (never fall back) when it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OfxError(f"{LIB_PATH} not found: build it with `make` (or __graft_entry__.build()); "
+                       "outfitx_amd has no CPU/PyTorch fallback for the scoring path")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)        # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.ofx_abi_version() != 1:
+        raise OfxError("libofx_hip.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != OFX_OK:
+        msg = load().ofx_last_error()
+        raise OfxError(f"{what or 'ofx call'} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def default_desc() -> ModelDesc:
+    d = ModelDesc()
+    load().ofx_default_desc(C.byref(d))
+    return d

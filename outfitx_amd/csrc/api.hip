@@ -1,0 +1,494 @@
+// C ABI of libofx_hip.so: handle, weight packing and the launch sequences of the scoring path.
+// Everything here is host code; it only enqueues work on the caller's stream (no syncs, no
+// allocation on the launch path — the weight arenas are allocated by the pack calls).
+#include <stdarg.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "ofx_common.h"
+
+static thread_local char g_err[512] = "";
+void ofx_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* ofx_last_error(void) { return g_err; }
+extern "C" int ofx_abi_version(void) { return OFX_ABI_VERSION; }
+
+int ofx_launch_fitb(const float* y, const float* cand, int B, int C, int D, int64_t* idx, float* dist, hipStream_t s);
+int ofx_launch_l2_topk(const float* Q, const float* P, int nq, int np, int D, int k, int64_t index_base, int64_t* idx,
+                       float* dist, void* ws, size_t ws_bytes, hipStream_t s);
+size_t ofx_l2_topk_ws(int nq, int np);
+int ofx_launch_topk_merge(const int64_t* idx_in, const float* dist_in, int parts, int nq, int k, int64_t* idx, float* dist,
+                          hipStream_t s);
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int pad128(int v) { return (v + 127) / 128 * 128; }
+
+struct Bump {                                       // carve a caller-provided workspace
+    char* base; size_t cap, off = 0; bool ok = true;
+    Bump(void* p, size_t c) : base((char*)p), cap(c) {}
+    template <typename T> T* take(size_t n) {
+        off = align_up(off, 256);
+        T* r = (T*)(base + off);
+        off += n * sizeof(T);
+        if (off > cap) ok = false;
+        return r;
+    }
+};
+
+struct Arena {                                      // library-owned HBM for packed weights
+    char* base = nullptr; size_t cap = 0, off = 0;
+    int reserve(size_t bytes) {
+        if (base && cap >= bytes) { off = 0; return OFX_OK; }
+        if (base) (void)hipFree(base);
+        base = nullptr; cap = 0; off = 0;
+        OFX_HIP(hipMalloc((void**)&base, bytes));
+        cap = bytes;
+        return OFX_OK;
+    }
+    template <typename T> T* take(size_t n) {
+        off = align_up(off, 256);
+        T* r = (T*)(base + off);
+        off += n * sizeof(T);
+        return r;
+    }
+    void release() { if (base) (void)hipFree(base); base = nullptr; cap = off = 0; }
+};
+
+struct OutfitLayer { void *w_in, *w_out, *w_1, *w_2; float *b_in, *b_out, *b_1, *b_2, *g1, *be1, *g2, *be2; };
+struct ClipLayer { void *w_qkv, *w_o, *w_fc1, *w_fc2; float *b_qkv, *b_o, *b_fc1, *b_fc2, *g1, *be1, *g2, *be2; };
+
+}  // namespace
+
+struct ofx_handle {
+    int device;
+    ofx_model_desc d;
+    // outfit transformer
+    Arena a_out; bool out_ready = false;
+    int ot_dtype, ot_kmul, ot_ffn_pad;
+    std::vector<OutfitLayer> ol;
+    float *outfit_token, *tgt_img_emb, *cp_w, *cp_b; void* cir_w;
+    // towers
+    int tw_dtype;
+    Arena a_vis; bool vis_ready = false;
+    std::vector<ClipLayer> vl;
+    void *v_patch_w, *v_proj_w; float *v_cls, *v_pos, *v_pre_g, *v_pre_b, *v_post_g, *v_post_b;
+    Arena a_txt; bool txt_ready = false;
+    std::vector<ClipLayer> tl;
+    float *t_tok, *t_pos, *t_fin_g, *t_fin_b; void* t_proj_w;
+};
+
+extern "C" void ofx_default_desc(ofx_model_desc* d) {
+    memset(d, 0, sizeof(*d));
+    d->d_model = 1024; d->n_head = 16; d->d_ffn = 2024; d->n_layers = 6; d->max_items = 16;
+    d->outfit_act = OFX_ACT_MISH; d->outfit_precision = OFX_PREC_BF16X3;
+    d->vit_width = 768; d->vit_layers = 12; d->vit_heads = 12; d->vit_mlp = 3072; d->vit_patch = 32; d->vit_image = 224;
+    d->vit_act = OFX_ACT_QUICK_GELU;
+    d->txt_width = 512; d->txt_layers = 12; d->txt_heads = 8; d->txt_mlp = 2048; d->txt_vocab = 49408; d->txt_max_pos = 77;
+    d->txt_act = OFX_ACT_QUICK_GELU; d->txt_eos_id = 49407;
+    d->proj_dim = 512; d->tower_precision = OFX_PREC_BF16; d->ln_eps = 1e-5f;
+}
+
+extern "C" ofx_handle* ofx_create(int device, const ofx_model_desc* desc) {
+    if (!desc) { ofx_set_error("ofx_create: desc is NULL"); return nullptr; }
+    const ofx_model_desc& d = *desc;
+    auto bad = [&](const char* why) { ofx_set_error("ofx_create: %s", why); return (ofx_handle*)nullptr; };
+    if (d.d_model != d.n_head * 64 || (d.d_model != 512 && d.d_model != 768 && d.d_model != 1024)) return bad("d_model must be n_head*64 and one of 512/768/1024");
+    if (d.vit_width != d.vit_heads * 64 || d.txt_width != d.txt_heads * 64) return bad("tower head_dim must be 64");
+    if (d.vit_width % 256 || d.txt_width % 256 || d.proj_dim % 128 || d.vit_mlp % 128 || d.txt_mlp % 128) return bad("tower dims must be multiples of 128/256");
+    if (d.vit_image % d.vit_patch || (d.vit_image / d.vit_patch) * (d.vit_image / d.vit_patch) + 1 > 64) return bad("ViT sequence (patches+1) must be <= 64");
+    if (d.max_items < 0 || d.max_items > 31) return bad("max_items must be in [0,31]");
+    if (d.tower_precision != OFX_PREC_BF16 && d.tower_precision != OFX_PREC_F16) return bad("tower_precision must be BF16 or F16");
+    if (d.outfit_precision < 0 || d.outfit_precision > 2) return bad("bad outfit_precision");
+    if (d.n_layers < 1 || d.vit_layers < 1 || d.txt_layers < 1 || d.d_ffn < 1) return bad("layer counts / d_ffn must be positive");
+    if (hipSetDevice(device) != hipSuccess) return bad("hipSetDevice failed");
+    ofx_handle* h = new ofx_handle();
+    h->device = device; h->d = d;
+    h->ot_dtype = d.outfit_precision == OFX_PREC_F16 ? OFX_F16 : OFX_BF16;
+    h->ot_kmul = d.outfit_precision == OFX_PREC_BF16X3 ? 3 : 1;
+    h->ot_ffn_pad = pad128(d.d_ffn);
+    h->tw_dtype = d.tower_precision == OFX_PREC_F16 ? OFX_F16 : OFX_BF16;
+    return h;
+}
+
+extern "C" void ofx_destroy(ofx_handle* h) {
+    if (!h) return;
+    h->a_out.release(); h->a_vis.release(); h->a_txt.release();
+    delete h;
+}
+
+// ------------------------------------------------------------------------------------------ pack
+static int copy_f32(float* dst, const void* src, size_t n, hipStream_t s) {
+    OFX_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return OFX_OK;
+}
+#define TRY(x) do { int rc_ = (x); if (rc_ != OFX_OK) return rc_; } while (0)
+
+extern "C" int ofx_pack_outfit_weights(ofx_handle* h, const void* const* P, int n, ofx_stream stream) {
+    OFX_REQUIRE(h, OFX_EINVAL, "pack_outfit: NULL handle");
+    const ofx_model_desc& d = h->d;
+    OFX_REQUIRE(n == 5 + 12 * d.n_layers, OFX_EINVAL, "pack_outfit: expected %d tensors, got %d", 5 + 12 * d.n_layers, n);
+    for (int i = 0; i < n; ++i) OFX_REQUIRE(P[i], OFX_EINVAL, "pack_outfit: tensor %d is NULL", i);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t D = d.d_model, F = d.d_ffn, Fp = h->ot_ffn_pad, km = h->ot_kmul;
+    const size_t per_layer = 2 * km * (3 * D * D + D * D + Fp * D + D * Fp) + 4 * (3 * D + D + Fp + D + 4 * D) + 16 * 256;
+    TRY(h->a_out.reserve(per_layer * d.n_layers + 2 * km * D * D + 4 * (3 * D + 8) + 16 * 256));
+    Arena& A = h->a_out;
+    const int dt = h->ot_dtype, mode = km == 3 ? 2 : 0;
+    h->outfit_token = A.take<float>(D); TRY(copy_f32(h->outfit_token, P[0], D, s));
+    h->tgt_img_emb = A.take<float>(D / 2); TRY(copy_f32(h->tgt_img_emb, P[1], D / 2, s));
+    h->cp_w = A.take<float>(D); TRY(copy_f32(h->cp_w, P[2], D, s));
+    h->cp_b = A.take<float>(1); TRY(copy_f32(h->cp_b, P[3], 1, s));
+    h->cir_w = A.take<char>(2 * km * D * D); TRY(ofx_launch_pack_rows((const float*)P[4], h->cir_w, D, D, D, D, D, mode, dt, s));
+    h->ol.resize(d.n_layers);
+    for (int l = 0; l < d.n_layers; ++l) {
+        const void* const* q = P + 5 + 12 * l;
+        OutfitLayer& L = h->ol[l];
+        L.w_in = A.take<char>(2 * km * 3 * D * D); TRY(ofx_launch_pack_rows((const float*)q[0], L.w_in, 3 * D, 3 * D, D, D, D, mode, dt, s));
+        L.b_in = A.take<float>(3 * D); TRY(copy_f32(L.b_in, q[1], 3 * D, s));
+        L.w_out = A.take<char>(2 * km * D * D); TRY(ofx_launch_pack_rows((const float*)q[2], L.w_out, D, D, D, D, D, mode, dt, s));
+        L.b_out = A.take<float>(D); TRY(copy_f32(L.b_out, q[3], D, s));
+        L.w_1 = A.take<char>(2 * km * Fp * D); TRY(ofx_launch_pack_rows((const float*)q[4], L.w_1, F, Fp, D, D, D, mode, dt, s));
+        L.b_1 = A.take<float>(Fp); OFX_HIP(hipMemsetAsync(L.b_1, 0, Fp * 4, s)); TRY(copy_f32(L.b_1, q[5], F, s));
+        L.w_2 = A.take<char>(2 * km * D * Fp); TRY(ofx_launch_pack_rows((const float*)q[6], L.w_2, D, D, F, Fp, F, mode, dt, s));
+        L.b_2 = A.take<float>(D); TRY(copy_f32(L.b_2, q[7], D, s));
+        L.g1 = A.take<float>(D); TRY(copy_f32(L.g1, q[8], D, s));
+        L.be1 = A.take<float>(D); TRY(copy_f32(L.be1, q[9], D, s));
+        L.g2 = A.take<float>(D); TRY(copy_f32(L.g2, q[10], D, s));
+        L.be2 = A.take<float>(D); TRY(copy_f32(L.be2, q[11], D, s));
+    }
+    OFX_REQUIRE(A.off <= A.cap, OFX_ESTATE, "pack_outfit: arena overflow");
+    h->out_ready = true;
+    return OFX_OK;
+}
+
+// q/k/v Linear weights -> one [3W, W] operand matrix in q|k|v order (+ fused bias).  `q` points at
+// the 16 per-layer tensors in HF order: k.w,k.b,v.w,v.b,q.w,q.b,out.w,out.b,ln1.w,ln1.b,fc1.w,fc1.b,fc2.w,fc2.b,ln2.w,ln2.b
+static int pack_clip_layer(Arena& A, ClipLayer& L, const void* const* q, size_t W, size_t MLP, int dt, hipStream_t s) {
+    char* wq = A.take<char>(2 * 3 * W * W);
+    L.w_qkv = wq;
+    TRY(ofx_launch_pack_rows((const float*)q[4], wq, W, W, W, W, W, 0, dt, s));
+    TRY(ofx_launch_pack_rows((const float*)q[0], wq + 2 * W * W, W, W, W, W, W, 0, dt, s));
+    TRY(ofx_launch_pack_rows((const float*)q[2], wq + 4 * W * W, W, W, W, W, W, 0, dt, s));
+    L.b_qkv = A.take<float>(3 * W);
+    TRY(copy_f32(L.b_qkv, q[5], W, s)); TRY(copy_f32(L.b_qkv + W, q[1], W, s)); TRY(copy_f32(L.b_qkv + 2 * W, q[3], W, s));
+    L.w_o = A.take<char>(2 * W * W); TRY(ofx_launch_pack_rows((const float*)q[6], L.w_o, W, W, W, W, W, 0, dt, s));
+    L.b_o = A.take<float>(W); TRY(copy_f32(L.b_o, q[7], W, s));
+    L.g1 = A.take<float>(W); TRY(copy_f32(L.g1, q[8], W, s));
+    L.be1 = A.take<float>(W); TRY(copy_f32(L.be1, q[9], W, s));
+    L.w_fc1 = A.take<char>(2 * MLP * W); TRY(ofx_launch_pack_rows((const float*)q[10], L.w_fc1, MLP, MLP, W, W, W, 0, dt, s));
+    L.b_fc1 = A.take<float>(MLP); TRY(copy_f32(L.b_fc1, q[11], MLP, s));
+    L.w_fc2 = A.take<char>(2 * W * MLP); TRY(ofx_launch_pack_rows((const float*)q[12], L.w_fc2, W, W, MLP, MLP, MLP, 0, dt, s));
+    L.b_fc2 = A.take<float>(W); TRY(copy_f32(L.b_fc2, q[13], W, s));
+    L.g2 = A.take<float>(W); TRY(copy_f32(L.g2, q[14], W, s));
+    L.be2 = A.take<float>(W); TRY(copy_f32(L.be2, q[15], W, s));
+    return OFX_OK;
+}
+static size_t clip_layer_bytes(size_t W, size_t MLP) { return 2 * (4 * W * W + 2 * W * MLP) + 4 * (9 * W + MLP) + 16 * 256; }
+
+extern "C" int ofx_pack_vision_weights(ofx_handle* h, const void* const* P, int n, ofx_stream stream) {
+    OFX_REQUIRE(h, OFX_EINVAL, "pack_vision: NULL handle");
+    const ofx_model_desc& d = h->d;
+    OFX_REQUIRE(n == 5 + 16 * d.vit_layers + 3, OFX_EINVAL, "pack_vision: expected %d tensors, got %d", 8 + 16 * d.vit_layers, n);
+    for (int i = 0; i < n; ++i) OFX_REQUIRE(P[i], OFX_EINVAL, "pack_vision: tensor %d is NULL", i);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t W = d.vit_width, MLP = d.vit_mlp, KP = 3 * (size_t)d.vit_patch * d.vit_patch, g = d.vit_image / d.vit_patch, S = g * g + 1, PD = d.proj_dim;
+    TRY(h->a_vis.reserve(clip_layer_bytes(W, MLP) * d.vit_layers + 2 * W * KP + 2 * PD * W + 4 * (W + S * W + 4 * W) + 16 * 256));
+    Arena& A = h->a_vis;
+    const int dt = h->tw_dtype;
+    h->v_cls = A.take<float>(W); TRY(copy_f32(h->v_cls, P[0], W, s));
+    h->v_patch_w = A.take<char>(2 * W * KP); TRY(ofx_launch_pack_rows((const float*)P[1], h->v_patch_w, W, W, KP, KP, KP, 0, dt, s));
+    h->v_pos = A.take<float>(S * W); TRY(copy_f32(h->v_pos, P[2], S * W, s));
+    h->v_pre_g = A.take<float>(W); TRY(copy_f32(h->v_pre_g, P[3], W, s));
+    h->v_pre_b = A.take<float>(W); TRY(copy_f32(h->v_pre_b, P[4], W, s));
+    h->vl.resize(d.vit_layers);
+    for (int l = 0; l < d.vit_layers; ++l) TRY(pack_clip_layer(A, h->vl[l], P + 5 + 16 * l, W, MLP, dt, s));
+    const void* const* t = P + 5 + 16 * d.vit_layers;
+    h->v_post_g = A.take<float>(W); TRY(copy_f32(h->v_post_g, t[0], W, s));
+    h->v_post_b = A.take<float>(W); TRY(copy_f32(h->v_post_b, t[1], W, s));
+    h->v_proj_w = A.take<char>(2 * PD * W); TRY(ofx_launch_pack_rows((const float*)t[2], h->v_proj_w, PD, PD, W, W, W, 0, dt, s));
+    OFX_REQUIRE(A.off <= A.cap, OFX_ESTATE, "pack_vision: arena overflow");
+    h->vis_ready = true;
+    return OFX_OK;
+}
+
+extern "C" int ofx_pack_text_weights(ofx_handle* h, const void* const* P, int n, ofx_stream stream) {
+    OFX_REQUIRE(h, OFX_EINVAL, "pack_text: NULL handle");
+    const ofx_model_desc& d = h->d;
+    OFX_REQUIRE(n == 2 + 16 * d.txt_layers + 3, OFX_EINVAL, "pack_text: expected %d tensors, got %d", 5 + 16 * d.txt_layers, n);
+    for (int i = 0; i < n; ++i) OFX_REQUIRE(P[i], OFX_EINVAL, "pack_text: tensor %d is NULL", i);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t W = d.txt_width, MLP = d.txt_mlp, V = d.txt_vocab, NP = d.txt_max_pos, PD = d.proj_dim;
+    TRY(h->a_txt.reserve(clip_layer_bytes(W, MLP) * d.txt_layers + 4 * (V * W + NP * W + 2 * W) + 2 * PD * W + 16 * 256));
+    Arena& A = h->a_txt;
+    const int dt = h->tw_dtype;
+    h->t_tok = A.take<float>(V * W); TRY(copy_f32(h->t_tok, P[0], V * W, s));
+    h->t_pos = A.take<float>(NP * W); TRY(copy_f32(h->t_pos, P[1], NP * W, s));
+    h->tl.resize(d.txt_layers);
+    for (int l = 0; l < d.txt_layers; ++l) TRY(pack_clip_layer(A, h->tl[l], P + 2 + 16 * l, W, MLP, dt, s));
+    const void* const* t = P + 2 + 16 * d.txt_layers;
+    h->t_fin_g = A.take<float>(W); TRY(copy_f32(h->t_fin_g, t[0], W, s));
+    h->t_fin_b = A.take<float>(W); TRY(copy_f32(h->t_fin_b, t[1], W, s));
+    h->t_proj_w = A.take<char>(2 * PD * W); TRY(ofx_launch_pack_rows((const float*)t[2], h->t_proj_w, PD, PD, W, W, W, 0, dt, s));
+    OFX_REQUIRE(A.off <= A.cap, OFX_ESTATE, "pack_text: arena overflow");
+    h->txt_ready = true;
+    return OFX_OK;
+}
+
+// ------------------------------------------------------------------------------------- workspace
+namespace {
+struct SetWs { int* cu; float* X; char* H; float* QKV; char* U; };
+size_t carve_set(const ofx_handle* h, Bump& b, int B, int L, SetWs* w) {
+    const size_t M = (size_t)B * (L + 1), D = h->d.d_model, km = h->ot_kmul, Fp = h->ot_ffn_pad;
+    SetWs t;
+    t.cu = b.take<int>(B + 1);
+    t.X = b.take<float>(M * D);
+    t.H = b.take<char>(M * km * D * 2);
+    t.QKV = b.take<float>(M * 3 * D);
+    t.U = b.take<char>(M * km * Fp * 2);
+    if (w) *w = t;
+    return b.off;
+}
+struct ClipWs { float* X; char* H; char* QKV; char* U; int* idx; char* PL; float* E; };
+size_t carve_clip(Bump& b, size_t rows, size_t n, size_t W, size_t MLP, size_t PD, size_t u_min_bytes, size_t qkv_min_bytes, ClipWs* w) {
+    ClipWs t;
+    t.X = b.take<float>(rows * W);
+    t.H = b.take<char>(rows * W * 2);
+    t.QKV = b.take<char>(std::max(rows * 3 * W * 2, qkv_min_bytes));
+    t.U = b.take<char>(std::max(rows * MLP * 2, u_min_bytes));
+    t.idx = b.take<int>(n);
+    t.PL = b.take<char>(n * W * 2);
+    t.E = b.take<float>(n * PD);
+    if (w) *w = t;
+    return b.off;
+}
+size_t vit_bytes(const ofx_handle* h, int n, ClipWs* w, void* ws, size_t cap) {
+    const ofx_model_desc& d = h->d;
+    const size_t g = d.vit_image / d.vit_patch, S = g * g + 1, KP = 3 * (size_t)d.vit_patch * d.vit_patch;
+    Bump b(ws, cap);
+    // the patch matrix aliases U and the fp32 patch-GEMM output aliases QKV (both dead before the layers start)
+    size_t r = carve_clip(b, (size_t)n * S, n, d.vit_width, d.vit_mlp, d.proj_dim, (size_t)n * g * g * KP * 2, (size_t)n * g * g * d.vit_width * 4, w);
+    return align_up(r, 256);
+}
+size_t txt_bytes(const ofx_handle* h, int n, int Tc, ClipWs* w, void* ws, size_t cap) {
+    const ofx_model_desc& d = h->d;
+    Bump b(ws, cap);
+    size_t r = carve_clip(b, (size_t)n * Tc, n, d.txt_width, d.txt_mlp, d.proj_dim, 0, 0, w);
+    return align_up(r, 256);
+}
+constexpr int VIT_CHUNK_MAX = 2048;
+}  // namespace
+
+extern "C" size_t ofx_workspace_bytes(ofx_handle* h, int op, int n, int len) {
+    if (!h || n <= 0) return 0;
+    switch (op) {
+        case OFX_OP_SET_ENCODER: { Bump b(nullptr, ~(size_t)0); return align_up(carve_set(h, b, n, len, nullptr), 256); }
+        case OFX_OP_VIT: return vit_bytes(h, std::min(n, VIT_CHUNK_MAX), nullptr, nullptr, ~(size_t)0);
+        case OFX_OP_TEXT: return txt_bytes(h, n, len, nullptr, nullptr, ~(size_t)0);
+        case OFX_OP_TOPK: return ofx_l2_topk_ws(n, len);
+        default: return 0;
+    }
+}
+
+// --------------------------------------------------------------------------- outfit transformer
+extern "C" int ofx_set_encoder_fwd(ofx_handle* h, const float* x, const uint8_t* pad_mask, const float* prefix,
+                                   int prefix_stride, int B, int L, float* out_row0, void* ws, size_t ws_bytes,
+                                   ofx_stream stream) {
+    OFX_REQUIRE(h && h->out_ready, OFX_ESTATE, "set_encoder_fwd: outfit weights not packed");
+    OFX_REQUIRE(B > 0 && L >= 0 && L <= 31, OFX_ESHAPE, "set_encoder_fwd: B=%d L=%d (L must be in [0,31])", B, L);
+    OFX_REQUIRE((x || L == 0) && (pad_mask || L == 0) && out_row0 && ws, OFX_EINVAL, "set_encoder_fwd: NULL argument");
+    const ofx_model_desc& d = h->d;
+    hipStream_t s = (hipStream_t)stream;
+    Bump bump(ws, ws_bytes);
+    SetWs w;
+    carve_set(h, bump, B, L, &w);
+    OFX_REQUIRE(bump.ok, OFX_EWORKSPACE, "set_encoder_fwd: workspace %zu < %zu bytes", ws_bytes, bump.off);
+    const int D = d.d_model, km = h->ot_kmul, Fp = h->ot_ffn_pad, dt = h->ot_dtype, M = B * (L + 1);
+    const int okind = km == 3 ? OFX_OUT_SPLIT3 : OFX_OUT_OP;
+    if (!prefix) { prefix = h->outfit_token; prefix_stride = 0; }
+    TRY(ofx_launch_set_build(x, pad_mask, prefix, prefix_stride, w.cu, w.X, B, L, D, s));
+    const int* m_dev = w.cu + B;
+    for (int l = 0; l < d.n_layers; ++l) {
+        const OutfitLayer& Ly = h->ol[l];
+        LnArgs ln{w.X, nullptr, Ly.g1, Ly.be1, w.H, M, D, km * D, okind, d.ln_eps};
+        TRY(ofx_launch_layernorm_dev(ln, m_dev, dt, s));
+        GemmArgs g1{}; g1.A = w.H; g1.W = Ly.w_in; g1.C = w.QKV; g1.bias = Ly.b_in; g1.resid = nullptr; g1.m_dev = m_dev;
+        g1.M = M; g1.N = 3 * D; g1.K = km * D; g1.lda = km * D; g1.ldc = 3 * D; g1.ldr = 0; g1.act = OFX_ACT_NONE; g1.out_kind = OFX_OUT_F32;
+        TRY(ofx_launch_gemm(g1, dt, s));
+        SetAttnArgs sa{w.QKV, w.H, w.cu, B, d.n_head, D, km * D, okind, L + 1, 0, 0.125f};
+        TRY(ofx_launch_set_attention(sa, dt, s));
+        GemmArgs g2{}; g2.A = w.H; g2.W = Ly.w_out; g2.C = w.X; g2.bias = Ly.b_out; g2.resid = w.X; g2.m_dev = m_dev;
+        g2.M = M; g2.N = D; g2.K = km * D; g2.lda = km * D; g2.ldc = D; g2.ldr = D; g2.act = OFX_ACT_NONE; g2.out_kind = OFX_OUT_F32;
+        TRY(ofx_launch_gemm(g2, dt, s));
+        LnArgs ln2{w.X, nullptr, Ly.g2, Ly.be2, w.H, M, D, km * D, okind, d.ln_eps};
+        TRY(ofx_launch_layernorm_dev(ln2, m_dev, dt, s));
+        GemmArgs g3{}; g3.A = w.H; g3.W = Ly.w_1; g3.C = w.U; g3.bias = Ly.b_1; g3.resid = nullptr; g3.m_dev = m_dev;
+        g3.M = M; g3.N = Fp; g3.K = km * D; g3.lda = km * D; g3.ldc = km * Fp; g3.ldr = 0; g3.act = d.outfit_act; g3.out_kind = okind;
+        TRY(ofx_launch_gemm(g3, dt, s));
+        GemmArgs g4{}; g4.A = w.U; g4.W = Ly.w_2; g4.C = w.X; g4.bias = Ly.b_2; g4.resid = w.X; g4.m_dev = m_dev;
+        g4.M = M; g4.N = D; g4.K = km * Fp; g4.lda = km * Fp; g4.ldc = D; g4.ldr = D; g4.act = OFX_ACT_NONE; g4.out_kind = OFX_OUT_F32;
+        TRY(ofx_launch_gemm(g4, dt, s));
+    }
+    return ofx_launch_gather_row0(w.X, w.cu, out_row0, B, D, s);
+}
+
+extern "C" int ofx_cp_head(ofx_handle* h, const float* row0, int B, float* logits, ofx_stream stream) {
+    OFX_REQUIRE(h && h->out_ready, OFX_ESTATE, "cp_head: outfit weights not packed");
+    OFX_REQUIRE(row0 && logits && B > 0, OFX_EINVAL, "cp_head: bad argument");
+    return ofx_launch_cp_head(row0, h->cp_w, h->cp_b, logits, B, h->d.d_model, (hipStream_t)stream);
+}
+
+extern "C" int ofx_cir_head(ofx_handle* h, const float* row0, int B, float* emb, void* ws, size_t ws_bytes, ofx_stream stream) {
+    OFX_REQUIRE(h && h->out_ready, OFX_ESTATE, "cir_head: outfit weights not packed");
+    OFX_REQUIRE(row0 && emb && B > 0 && ws, OFX_EINVAL, "cir_head: bad argument");
+    const int D = h->d.d_model, km = h->ot_kmul;
+    OFX_REQUIRE(ws_bytes >= (size_t)B * km * D * 2, OFX_EWORKSPACE, "cir_head: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    TRY(ofx_launch_pack_rows(row0, ws, B, B, D, D, D, km == 3 ? 1 : 0, h->ot_dtype, s));
+    GemmArgs g{}; g.A = ws; g.W = h->cir_w; g.C = emb; g.bias = nullptr; g.resid = nullptr;
+    g.M = B; g.N = D; g.K = km * D; g.lda = km * D; g.ldc = D; g.ldr = 0; g.act = OFX_ACT_NONE; g.out_kind = OFX_OUT_F32;
+    return ofx_launch_gemm(g, h->ot_dtype, s);
+}
+
+extern "C" int ofx_cir_prefix(ofx_handle* h, const float* txt, int B, float* out, ofx_stream stream) {
+    OFX_REQUIRE(h && h->out_ready, OFX_ESTATE, "cir_prefix: outfit weights not packed");
+    OFX_REQUIRE(txt && out && B > 0, OFX_EINVAL, "cir_prefix: bad argument");
+    return ofx_launch_cir_prefix(h->tgt_img_emb, txt, out, B, h->d.d_model, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------ CLIP towers
+static int clip_layers(const std::vector<ClipLayer>& Ls, const ClipWs& w, int rows, int nseq, int S, int W, int MLP,
+                       int heads, int act, float eps, int causal, const int64_t* key_mask, int mask_ld, int dt, hipStream_t s) {
+    for (const ClipLayer& L : Ls) {
+        LnArgs ln{w.X, nullptr, L.g1, L.be1, w.H, rows, W, W, OFX_OUT_OP, eps};
+        TRY(ofx_launch_layernorm(ln, dt, s));
+        GemmArgs g1{}; g1.A = w.H; g1.W = L.w_qkv; g1.C = w.QKV; g1.bias = L.b_qkv; g1.M = rows; g1.N = 3 * W; g1.K = W; g1.lda = W;
+        g1.ldc = 3 * W; g1.act = OFX_ACT_NONE; g1.out_kind = OFX_OUT_OP;
+        TRY(ofx_launch_gemm(g1, dt, s));
+        AttnArgs at{w.QKV, w.H, key_mask, nseq, S, heads, 3 * W, W, W, 2 * W, mask_ld, causal, 0.125f};
+        TRY(ofx_launch_attention_mfma(at, dt, s));
+        GemmArgs g2{}; g2.A = w.H; g2.W = L.w_o; g2.C = w.X; g2.bias = L.b_o; g2.resid = w.X; g2.M = rows; g2.N = W; g2.K = W; g2.lda = W;
+        g2.ldc = W; g2.ldr = W; g2.act = OFX_ACT_NONE; g2.out_kind = OFX_OUT_F32;
+        TRY(ofx_launch_gemm(g2, dt, s));
+        LnArgs ln2{w.X, nullptr, L.g2, L.be2, w.H, rows, W, W, OFX_OUT_OP, eps};
+        TRY(ofx_launch_layernorm(ln2, dt, s));
+        GemmArgs g3{}; g3.A = w.H; g3.W = L.w_fc1; g3.C = w.U; g3.bias = L.b_fc1; g3.M = rows; g3.N = MLP; g3.K = W; g3.lda = W;
+        g3.ldc = MLP; g3.act = act; g3.out_kind = OFX_OUT_OP;
+        TRY(ofx_launch_gemm(g3, dt, s));
+        GemmArgs g4{}; g4.A = w.U; g4.W = L.w_fc2; g4.C = w.X; g4.bias = L.b_fc2; g4.resid = w.X; g4.M = rows; g4.N = W; g4.K = MLP;
+        g4.lda = MLP; g4.ldc = W; g4.ldr = W; g4.act = OFX_ACT_NONE; g4.out_kind = OFX_OUT_F32;
+        TRY(ofx_launch_gemm(g4, dt, s));
+    }
+    return OFX_OK;
+}
+
+extern "C" int ofx_vit_b32_fwd(ofx_handle* h, const float* pixels, int N, float* emb, int emb_ld, int emb_col,
+                               int normalize, void* ws, size_t ws_bytes, ofx_stream stream) {
+    OFX_REQUIRE(h && h->vis_ready, OFX_ESTATE, "vit_b32_fwd: vision weights not packed");
+    OFX_REQUIRE(pixels && emb && ws && N > 0, OFX_EINVAL, "vit_b32_fwd: bad argument");
+    const ofx_model_desc& d = h->d;
+    OFX_REQUIRE(emb_ld >= emb_col + d.proj_dim && emb_ld % 4 == 0 && emb_col % 4 == 0, OFX_ESHAPE, "vit_b32_fwd: bad emb_ld/emb_col");
+    hipStream_t s = (hipStream_t)stream;
+    const int g = d.vit_image / d.vit_patch, S = g * g + 1, W = d.vit_width, KP = 3 * d.vit_patch * d.vit_patch, dt = h->tw_dtype;
+    // largest chunk of images the workspace holds
+    int chunk = std::min(N, VIT_CHUNK_MAX);
+    while (chunk > 1 && vit_bytes(h, chunk, nullptr, nullptr, ~(size_t)0) > ws_bytes) chunk = (chunk + 1) / 2;
+    OFX_REQUIRE(vit_bytes(h, chunk, nullptr, nullptr, ~(size_t)0) <= ws_bytes, OFX_EWORKSPACE, "vit_b32_fwd: workspace %zu bytes cannot hold one image", ws_bytes);
+    const size_t px_per_img = (size_t)3 * d.vit_image * d.vit_image;
+    for (int n0 = 0; n0 < N; n0 += chunk) {
+        const int n = std::min(chunk, N - n0);
+        ClipWs w;
+        vit_bytes(h, n, &w, ws, ws_bytes);
+        const int rows = n * S;
+        TRY(ofx_launch_patchify(pixels + (size_t)n0 * px_per_img, w.U, n, d.vit_image, d.vit_patch, dt, s));
+        GemmArgs gp{}; gp.A = w.U; gp.W = h->v_patch_w; gp.C = w.QKV; gp.M = n * g * g; gp.N = W; gp.K = KP; gp.lda = KP; gp.ldc = W;
+        gp.act = OFX_ACT_NONE; gp.out_kind = OFX_OUT_F32;
+        TRY(ofx_launch_gemm(gp, dt, s));
+        TRY(ofx_launch_vit_embed_ln((const float*)w.QKV, h->v_cls, h->v_pos, h->v_pre_g, h->v_pre_b, w.X, n, S, W, d.ln_eps, s));
+        TRY(clip_layers(h->vl, w, rows, n, S, W, d.vit_mlp, d.vit_heads, d.vit_act, d.ln_eps, 0, nullptr, 0, dt, s));
+        TRY(ofx_launch_iota_rows(w.idx, n, S, s));
+        LnArgs ln{w.X, w.idx, h->v_post_g, h->v_post_b, w.PL, n, W, W, OFX_OUT_OP, d.ln_eps};
+        TRY(ofx_launch_layernorm(ln, dt, s));
+        GemmArgs gj{}; gj.A = w.PL; gj.W = h->v_proj_w; gj.C = w.E; gj.M = n; gj.N = d.proj_dim; gj.K = W; gj.lda = W; gj.ldc = d.proj_dim;
+        gj.act = OFX_ACT_NONE; gj.out_kind = OFX_OUT_F32;
+        TRY(ofx_launch_gemm(gj, dt, s));
+        TRY(ofx_launch_l2norm_store(w.E, emb + (size_t)n0 * emb_ld, n, d.proj_dim, emb_ld, emb_col, normalize, s));
+    }
+    return OFX_OK;
+}
+
+extern "C" int ofx_clip_text_fwd(ofx_handle* h, const int64_t* ids, const int64_t* attn_mask, const int* lengths_host,
+                                 int N, int T, float* emb, int emb_ld, int emb_col, int normalize, void* ws,
+                                 size_t ws_bytes, ofx_stream stream) {
+    OFX_REQUIRE(h && h->txt_ready, OFX_ESTATE, "clip_text_fwd: text weights not packed");
+    OFX_REQUIRE(ids && emb && ws && N > 0 && T > 0, OFX_EINVAL, "clip_text_fwd: bad argument");
+    const ofx_model_desc& d = h->d;
+    OFX_REQUIRE(T <= d.txt_max_pos, OFX_ESHAPE, "clip_text_fwd: T=%d exceeds max_position_embeddings=%d", T, d.txt_max_pos);
+    OFX_REQUIRE(emb_ld >= emb_col + d.proj_dim && emb_ld % 4 == 0 && emb_col % 4 == 0, OFX_ESHAPE, "clip_text_fwd: bad emb_ld/emb_col");
+    int Tc = T;
+    if (lengths_host) {
+        Tc = 1;
+        for (int i = 0; i < N; ++i) Tc = std::max(Tc, std::min(lengths_host[i], T));
+    }
+    OFX_REQUIRE(Tc <= 64, OFX_ESHAPE, "clip_text_fwd: %d tokens per text exceed the 64-token attention tile", Tc);
+    hipStream_t s = (hipStream_t)stream;
+    ClipWs w;
+    const size_t need = txt_bytes(h, N, Tc, &w, ws, ws_bytes);
+    OFX_REQUIRE(need <= ws_bytes, OFX_EWORKSPACE, "clip_text_fwd: workspace %zu < %zu bytes", ws_bytes, need);
+    const int W = d.txt_width, dt = h->tw_dtype, rows = N * Tc;
+    TRY(ofx_launch_text_embed(ids, h->t_tok, h->t_pos, w.X, N, T, Tc, W, d.txt_vocab, s));
+    TRY(clip_layers(h->tl, w, rows, N, Tc, W, d.txt_mlp, d.txt_heads, d.txt_act, d.ln_eps, 1, attn_mask, T, dt, s));
+    TRY(ofx_launch_text_eos_index(ids, w.idx, N, T, Tc, d.txt_eos_id, s));
+    LnArgs ln{w.X, w.idx, h->t_fin_g, h->t_fin_b, w.PL, N, W, W, OFX_OUT_OP, d.ln_eps};
+    TRY(ofx_launch_layernorm(ln, dt, s));
+    GemmArgs gj{}; gj.A = w.PL; gj.W = h->t_proj_w; gj.C = w.E; gj.M = N; gj.N = d.proj_dim; gj.K = W; gj.lda = W; gj.ldc = d.proj_dim;
+    gj.act = OFX_ACT_NONE; gj.out_kind = OFX_OUT_F32;
+    TRY(ofx_launch_gemm(gj, dt, s));
+    return ofx_launch_l2norm_store(w.E, emb, N, d.proj_dim, emb_ld, emb_col, normalize, s);
+}
+
+// ------------------------------------------------------------------------------------- scoring
+extern "C" int ofx_fitb_argmin(const float* y, const float* cand, int B, int C, int D, int64_t* idx, float* dist, ofx_stream stream) {
+    OFX_REQUIRE(y && cand && idx && B > 0 && C > 0 && D > 0 && D % 4 == 0, OFX_EINVAL, "fitb_argmin: bad argument");
+    return ofx_launch_fitb(y, cand, B, C, D, idx, dist, (hipStream_t)stream);
+}
+extern "C" int ofx_l2_topk(ofx_handle*, const float* Q, const float* P, int nq, int np, int D, int k, int64_t index_base,
+                           int64_t* idx, float* dist, void* ws, size_t ws_bytes, ofx_stream stream) {
+    return ofx_launch_l2_topk(Q, P, nq, np, D, k, index_base, idx, dist, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int ofx_topk_merge(const int64_t* idx_in, const float* dist_in, int parts, int nq, int k, int64_t* idx, float* dist, ofx_stream stream) {
+    return ofx_launch_topk_merge(idx_in, dist_in, parts, nq, k, idx, dist, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------- op level
+extern "C" int ofx_gemm(const void* A, const void* W, void* C, const float* bias, const float* resid, int M, int N, int K,
+                        int lda, int ldc, int ldr, int act, int out_kind, int op_dtype, ofx_stream stream) {
+    GemmArgs g{}; g.A = A; g.W = W; g.C = C; g.bias = bias; g.resid = resid; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc;
+    g.ldr = ldr; g.act = act; g.out_kind = out_kind;
+    return ofx_launch_gemm(g, op_dtype, (hipStream_t)stream);
+}
+extern "C" int ofx_layernorm(const float* x, const int* row_idx, const float* gamma, const float* beta, void* y, int rows,
+                             int D, int ldy, int out_kind, int op_dtype, float eps, ofx_stream stream) {
+    LnArgs a{x, row_idx, gamma, beta, y, rows, D, ldy, out_kind, eps};
+    return ofx_launch_layernorm(a, op_dtype, (hipStream_t)stream);
+}
+extern "C" int ofx_attention(const void* qkv, void* out, const int64_t* key_mask, int nseq, int seq_len, int n_head, int ld,
+                             int ldo, int k_off, int v_off, int mask_ld, int causal, float scale, int op_dtype, ofx_stream stream) {
+    AttnArgs a{qkv, out, key_mask, nseq, seq_len, n_head, ld, ldo, k_off, v_off, mask_ld, causal, scale};
+    return ofx_launch_attention_mfma(a, op_dtype, (hipStream_t)stream);
+}
+extern "C" int ofx_set_attention(const float* qkv, void* out, const int* cu_seqlens, int nseq, int n_head, int D, int ldo,
+                                 int out_kind, int max_len, int only_row0, float scale, int op_dtype, ofx_stream stream) {
+    SetAttnArgs a{qkv, out, cu_seqlens, nseq, n_head, D, ldo, out_kind, max_len, only_row0, scale};
+    return ofx_launch_set_attention(a, op_dtype, (hipStream_t)stream);
+}
+extern "C" int ofx_convert(const float* src, void* dst, int rows, int cols, int mode, int op_dtype, ofx_stream stream) {
+    return ofx_launch_pack_rows(src, dst, rows, rows, cols, cols, cols, mode, op_dtype, (hipStream_t)stream);
+}

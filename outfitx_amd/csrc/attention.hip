@@ -1,0 +1,281 @@
+// Attention kernels of the scoring path (head_dim 64 everywhere).
+//
+// (1) attention_mfma: one wavefront per (sequence, head), whole sequence (S <= 64) in one tile —
+//     CLIP ViT-B/32 (S = 50, 12 heads) and CLIP text (S <= 64, causal ∧ key-padding, 8 heads);
+//     replaces HF CLIPAttention's softmax(QK^T/8 + mask)V (reached from clip_image_encoder.py:74-76,
+//     clip_text_encoder.py:56-58).  S^T = K·Q^T on v_mfma_f32_16x16x32 so a query's scores sit in
+//     one lane quad (wavefront softmax: in-lane + 2 shuffles); the S^T accumulators are re-used
+//     in place as the P operand of O^T = V^T·P^T (k-slot permutation, guide §3), V goes through
+//     LDS once and is read back transposed with ds_read_b64_tr_b16 (160-B rows: conflict-free).
+// (2) set_attention: fp32 VALU attention over an outfit's 1 + n items (S <= 32, 16 heads);
+//     replaces nn.MultiheadAttention's SDPA inside nn.TransformerEncoderLayer
+//     (src/models/outfit_x.py:137-140,165-168) with -inf on padded keys realised by pad-free
+//     compaction.  < 0.3 % of the path's FLOPs, kept exact.
+#include "ofx_common.h"
+
+namespace {
+
+struct AttnK {
+    const char* qkv;
+    char* out;
+    const int64_t* key_mask;
+    int nseq, S, n_head, ld, ldo, k_off, v_off, mask_ld, causal;
+    float scale;
+};
+
+constexpr int V_ROW = 160;                 // bytes per V row in LDS (64 x 2 B + 32 pad): tr-read conflict-free
+constexpr int V_TILE = 64 * V_ROW;
+
+template <typename T>
+__global__ __launch_bounds__(256) void attention_mfma_kernel(AttnK a) {
+    typedef typename OpT<T>::v8 v8;
+    typedef typename OpT<T>::v4 v4;
+    __shared__ __attribute__((aligned(16))) char smem[4 * V_TILE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int npairs = a.nseq * a.n_head;
+    const int pair_raw = blockIdx.x * 4 + wave;
+    const bool live = pair_raw < npairs;           // wave-uniform; dead waves recompute the last pair and store nothing
+    const int pair = live ? pair_raw : npairs - 1;
+    const int seq = pair / a.n_head, head = pair % a.n_head;
+    const int S = a.S;
+    const T* base = (const T*)a.qkv + (size_t)seq * S * a.ld + head * 64;
+    const int r16 = lane & 15, q4 = lane >> 4;
+
+    // ---- V -> LDS, zero rows beyond S (0 * garbage must stay 0)
+    OFX_LDS char* vl = (OFX_LDS char*)smem + wave * V_TILE;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int key = it * 8 + (lane >> 3);
+        v8 val;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) val[e] = (T)0.0f;
+        if (key < S) val = *(const v8*)(base + (size_t)key * a.ld + a.v_off + (lane & 7) * 8);
+        *(OFX_LDS v8*)(vl + key * V_ROW + (lane & 7) * 16) = val;
+    }
+
+    // ---- K (A operand) and Q (B operand) fragments straight from global, rows clamped
+    v8 kf[4][2], qf[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int row = 16 * t + r16;
+        row = row < S ? row : S - 1;
+        const T* rp = base + (size_t)row * a.ld + q4 * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            kf[t][ks] = *(const v8*)(rp + a.k_off + ks * 32);
+            qf[t][ks] = *(const v8*)(rp + ks * 32);
+        }
+    }
+
+    // ---- dead-key bits for this lane's 16 keys (key = 16t + 4q4 + r), independent of the query
+    unsigned dead_bits = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 16 * t + 4 * q4 + r;
+            bool dead = key >= S;
+            if (!dead && a.key_mask) dead = a.key_mask[(size_t)seq * a.mask_ld + key] == 0;
+            dead_bits |= (dead ? 1u : 0u) << (t * 4 + r);
+        }
+
+    // ---- S^T[key][query]: st[t][u][r] = score(query 16u + r16, key 16t + 4q4 + r)
+    f32x4 st[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            c = OpT<T>::mfma16(kf[t][0], qf[u][0], c);
+            st[t][u] = OpT<T>::mfma16(kf[t][1], qf[u][1], c);
+        }
+
+    // ---- wavefront softmax per query column; P written back normalised
+    const float sc = a.scale * 1.4426950408889634f;        // exp(x) = exp2(x * log2 e)
+    v8 pf[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int query = 16 * u + r16;
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * t + 4 * q4 + r;
+                const bool dead = ((dead_bits >> (t * 4 + r)) & 1u) || (a.causal && key > query);
+                const float s = dead ? -INFINITY : st[t][u][r] * sc;
+                st[t][u][r] = s;
+                m = fmaxf(m, s);
+            }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        if (m == -INFINITY) m = 0.f;
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = exp2f(st[t][u][r] - m);
+                st[t][u][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        // P fragment of k-step ks: element j <-> key 16(2ks + (j>>2)) + 4q4 + (j&3)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[u][ks][j] = (T)(st[2 * ks + (j >> 2)][u][j & 3] * inv);
+    }
+
+    // ---- O^T[d][query] = V^T · P^T; V fragments by transposed LDS reads (EXEC is all ones here)
+    f32x4 ot[4][4];
+#pragma unroll
+    for (int nd = 0; nd < 4; ++nd) {
+        v8 vf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int key0 = 32 * ks + 16 * h2 + 4 * q4;
+                OFX_LDS s16x4* ap = (OFX_LDS s16x4*)(vl + (key0 + (r16 >> 2)) * V_ROW + (16 * nd + 4 * (r16 & 3)) * 2);
+                const s16x4 tr = __builtin_amdgcn_ds_read_tr16_b64_v4i16(ap);
+                const v4 trv = __builtin_bit_cast(v4, tr);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vf[ks][4 * h2 + e] = trv[e];
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            c = OpT<T>::mfma16(vf[0], pf[u][0], c);
+            ot[nd][u] = OpT<T>::mfma16(vf[1], pf[u][1], c);
+        }
+    }
+
+    // ---- store: ot[nd][u][r] = O[query 16u + r16][d 16nd + 4q4 + r]
+    if (live) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int query = 16 * u + r16;
+            if (query < S) {
+                T* op = (T*)a.out + (size_t)(seq * S + query) * a.ldo + head * 64 + 4 * q4;
+#pragma unroll
+                for (int nd = 0; nd < 4; ++nd) {
+                    v4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (T)ot[nd][u][r];
+                    *(v4*)(op + 16 * nd) = o;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct SetK {
+    const float* qkv;
+    char* out;
+    const int* cu;
+    int nseq, n_head, D, ldo, out_kind, only_row0;
+    float scale;
+};
+
+template <typename T, int SMAX>
+__global__ __launch_bounds__(64) void set_attention_kernel(SetK a) {
+    constexpr int STR = 68;                         // floats per staged row: 16-B slots of consecutive rows differ
+    __shared__ __attribute__((aligned(16))) float qs[SMAX * STR];
+    __shared__ __attribute__((aligned(16))) float ks[SMAX * STR];
+    __shared__ __attribute__((aligned(16))) float sc[SMAX * (SMAX + 4)];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x / a.n_head, h = blockIdx.x % a.n_head;
+    const int r0 = a.cu[b];
+    int S = a.cu[b + 1] - r0;
+    S = S < SMAX ? S : SMAX;
+    const int nq = a.only_row0 ? 1 : S;
+    const int D = a.D;
+    float vreg[SMAX];
+#pragma unroll
+    for (int j = 0; j < SMAX; ++j) {
+        vreg[j] = 0.f;
+        if (j < S) {
+            const float* rp = a.qkv + (size_t)(r0 + j) * 3 * D + h * 64 + lane;
+            if (j < nq) qs[j * STR + lane] = rp[0];
+            ks[j * STR + lane] = rp[D];
+            vreg[j] = rp[2 * D];
+        }
+    }
+    __syncthreads();
+    for (int p = lane; p < nq * S; p += 64) {
+        const int i = p / S, j = p % S;
+        const f32x4* qp = (const f32x4*)(qs + i * STR);
+        const f32x4* kp = (const f32x4*)(ks + j * STR);
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const f32x4 x = qp[c], y = kp[c];
+            d += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+        }
+        sc[i * (SMAX + 4) + j] = d * a.scale;
+    }
+    __syncthreads();
+    if (lane < nq) {
+        float* row = sc + lane * (SMAX + 4);
+        float m = -INFINITY;
+        for (int j = 0; j < S; ++j) m = fmaxf(m, row[j]);
+        float sum = 0.f;
+        for (int j = 0; j < S; ++j) { const float e = expf(row[j] - m); row[j] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < S; ++j) row[j] *= inv;
+    }
+    __syncthreads();
+    for (int i = 0; i < nq; ++i) {
+        const float* row = sc + i * (SMAX + 4);
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < SMAX; ++j) acc += (j < S ? row[j] : 0.f) * vreg[j];
+        const size_t off = (size_t)(r0 + i) * a.ldo + h * 64 + lane;
+        if (a.out_kind == 0) {
+            ((float*)a.out)[off] = acc;
+        } else {
+            const T hi = (T)acc;
+            T* p = (T*)a.out + off;
+            p[0] = hi;
+            if (a.out_kind == 2) { p[D] = (T)(acc - (float)hi); p[2 * D] = hi; }
+        }
+    }
+}
+
+}  // namespace
+
+int ofx_launch_attention_mfma(const AttnArgs& g, int op_dtype, hipStream_t s) {
+    OFX_REQUIRE(g.seq_len >= 1 && g.seq_len <= 64, OFX_ESHAPE, "attention: seq_len=%d must be in [1,64]", g.seq_len);
+    OFX_REQUIRE(g.nseq > 0 && g.n_head > 0, OFX_ESHAPE, "attention: nseq=%d n_head=%d", g.nseq, g.n_head);
+    OFX_REQUIRE(g.ld % 8 == 0 && g.ldo % 4 == 0 && g.k_off % 8 == 0 && g.v_off % 8 == 0, OFX_ESHAPE, "attention: strides must keep 16-byte alignment");
+    OFX_REQUIRE((uintptr_t)g.qkv % 16 == 0 && (uintptr_t)g.out % 8 == 0, OFX_EINVAL, "attention: misaligned pointers");
+    AttnK k;
+    k.qkv = (const char*)g.qkv; k.out = (char*)g.out; k.key_mask = g.key_mask; k.nseq = g.nseq; k.S = g.seq_len;
+    k.n_head = g.n_head; k.ld = g.ld; k.ldo = g.ldo; k.k_off = g.k_off; k.v_off = g.v_off; k.mask_ld = g.mask_ld;
+    k.causal = g.causal; k.scale = g.scale;
+    const int grid = (g.nseq * g.n_head + 3) / 4;
+    if (op_dtype == OFX_F16) hipLaunchKernelGGL(attention_mfma_kernel<f16_t>, dim3(grid), dim3(256), 0, s, k);
+    else hipLaunchKernelGGL(attention_mfma_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, k);
+    OFX_LAUNCH_CHECK();
+    return OFX_OK;
+}
+
+int ofx_launch_set_attention(const SetAttnArgs& g, int op_dtype, hipStream_t s) {
+    OFX_REQUIRE(g.D == g.n_head * 64, OFX_ESHAPE, "set_attention: head_dim must be 64 (D=%d heads=%d)", g.D, g.n_head);
+    OFX_REQUIRE(g.max_len >= 1 && g.max_len <= 32, OFX_ESHAPE, "set_attention: 1+items=%d exceeds 32", g.max_len);
+    OFX_REQUIRE(g.ldo >= (g.out_kind == 2 ? 3 * g.D : g.D), OFX_ESHAPE, "set_attention: bad ldo=%d", g.ldo);
+    SetK k;
+    k.qkv = g.qkv; k.out = (char*)g.out; k.cu = g.cu_seqlens; k.nseq = g.nseq; k.n_head = g.n_head; k.D = g.D; k.ldo = g.ldo;
+    k.out_kind = g.out_kind; k.only_row0 = g.only_row0; k.scale = g.scale;
+    const int grid = g.nseq * g.n_head;
+#define SA(T, N) hipLaunchKernelGGL((set_attention_kernel<T, N>), dim3(grid), dim3(64), 0, s, k)
+    if (op_dtype == OFX_F16) { if (g.max_len <= 20) SA(f16_t, 20); else SA(f16_t, 32); }
+    else { if (g.max_len <= 20) SA(bf16_t, 20); else SA(bf16_t, 32); }
+#undef SA
+    OFX_LAUNCH_CHECK();
+    return OFX_OK;
+}

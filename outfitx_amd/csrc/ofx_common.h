@@ -1,0 +1,160 @@
+// Internal helpers shared by the HIP translation units of libofx_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ofx.h"
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+#define OFX_LDS __attribute__((address_space(3)))
+#define OFX_GLB __attribute__((address_space(1)))
+
+// thread-local last-error text (ofx_last_error)
+void ofx_set_error(const char* fmt, ...);
+
+#define OFX_REQUIRE(cond, code, ...)            \
+    do {                                        \
+        if (!(cond)) {                          \
+            ofx_set_error(__VA_ARGS__);         \
+            return (code);                      \
+        }                                       \
+    } while (0)
+
+#define OFX_HIP(call)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            ofx_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return OFX_EHIP;                                                           \
+        }                                                                              \
+    } while (0)
+
+#define OFX_LAUNCH_CHECK()                                                             \
+    do {                                                                               \
+        hipError_t e_ = hipGetLastError();                                             \
+        if (e_ != hipSuccess) {                                                        \
+            ofx_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return OFX_EHIP;                                                           \
+        }                                                                              \
+    } while (0)
+
+// ---- operand-type traits (bf16 / f16 share every fragment shape and MFMA rate) ----
+template <typename T> struct OpT;
+template <> struct OpT<bf16_t> {
+    typedef bf16x8 v8;
+    typedef bf16x4 v4;
+    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct OpT<f16_t> {
+    typedef f16x8 v8;
+    typedef f16x4 v4;
+    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+// ---- activations (fp32) ----
+__device__ __forceinline__ float act_quick_gelu(float u) { return u / (1.0f + __expf(-1.702f * u)); }
+__device__ __forceinline__ float act_gelu(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f)); }
+__device__ __forceinline__ float act_mish(float u) {
+    // u * tanh(softplus(u)); softplus threshold 20 as torch.  tanh(log(1+e^u)) = ((1+e^u)^2-1)/((1+e^u)^2+1)
+    if (u > 20.0f) return u;
+    float e = __expf(u);
+    float n = e * (e + 2.0f);
+    return u * (n / (n + 2.0f));
+}
+__device__ __forceinline__ float apply_act(float u, int act) {
+    switch (act) {
+        case OFX_ACT_QUICK_GELU: return act_quick_gelu(u);
+        case OFX_ACT_GELU: return act_gelu(u);
+        case OFX_ACT_MISH: return act_mish(u);
+        default: return u;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- internal launchers (defined in the .hip files, used by api.hip) ----
+struct GemmArgs {
+    const void* A;      // [M, lda] operand type, K-contiguous
+    const void* W;      // [N, K] operand type, K-contiguous (torch Linear layout)
+    void* C;            // output, see out_kind
+    const float* bias;  // [N] or null
+    const float* resid; // fp32 [M, ldr] or null; may alias C when out_kind == F32
+    const int* m_dev = nullptr; // optional device-side live row count (<= M)
+    int M, N, K, lda, ldc, ldr;
+    int act;            // ofx_act
+    int out_kind;       // 0 fp32 | 1 operand type | 2 split3 (hi|lo|hi at column blocks of width N, ldc >= 3N; bf16 only)
+};
+int ofx_launch_gemm(const GemmArgs& g, int op_dtype /*OFX_BF16|OFX_F16*/, hipStream_t s);
+
+struct LnArgs {
+    const float* x;        // [rows_in, D] fp32
+    const int* row_idx;    // optional gather: output row r reads x[row_idx[r]]
+    const float* gamma;    // [D]
+    const float* beta;     // [D]
+    void* y;               // [rows, ldy]
+    int rows, D, ldy;
+    int out_kind;          // 0 fp32 | 1 operand type | 2 split3
+    float eps;
+};
+int ofx_launch_layernorm(const LnArgs& a, int op_dtype, hipStream_t s);
+int ofx_launch_layernorm_dev(const LnArgs& a, const int* rows_dev, int op_dtype, hipStream_t s);
+int ofx_launch_pack_rows(const float* src, void* dst, int rows_src, int rows_dst, int K_src, int K_dst, int ld_src,
+                         int mode, int op_dtype, hipStream_t s);
+int ofx_launch_patchify(const float* px, void* out, int N, int img, int patch, int op_dtype, hipStream_t s);
+int ofx_launch_vit_embed_ln(const float* patch_out, const float* cls, const float* pos, const float* g, const float* b,
+                            float* x, int N, int S, int D, float eps, hipStream_t s);
+int ofx_launch_text_embed(const int64_t* ids, const float* tok, const float* pos, float* x, int N, int T, int Tc, int D,
+                          int vocab, hipStream_t s);
+int ofx_launch_text_eos_index(const int64_t* ids, int* row_idx, int N, int T, int Tc, int eos_id, hipStream_t s);
+int ofx_launch_iota_rows(int* idx, int n, int stride, hipStream_t s);
+int ofx_launch_l2norm_store(const float* src, float* dst, int rows, int D, int ld, int col, int normalize, hipStream_t s);
+int ofx_launch_set_build(const float* x, const uint8_t* mask, const float* prefix, int prefix_stride, int* cu, float* X,
+                         int B, int L, int D, hipStream_t s);
+int ofx_launch_gather_row0(const float* X, const int* cu, float* out, int B, int D, hipStream_t s);
+int ofx_launch_cir_prefix(const float* img_emb, const float* txt, float* out, int B, int D, hipStream_t s);
+int ofx_launch_cp_head(const float* row0, const float* w, const float* bias, float* logits, int B, int D, hipStream_t s);
+
+struct AttnArgs {
+    const void* qkv;          // [nseq*seq_len, ld] operand type: q at col 0, k at col k_off, v at col v_off; head h at +h*64
+    void* out;                // [nseq*seq_len, ldo] operand type
+    const int64_t* key_mask;  // optional [nseq, mask_ld]: 0 = key ignored (HF attention_mask)
+    int nseq, seq_len, n_head, ld, ldo, k_off, v_off, mask_ld;
+    int causal;
+    float scale;
+};
+int ofx_launch_attention_mfma(const AttnArgs& a, int op_dtype, hipStream_t s);
+
+struct SetAttnArgs {
+    const float* qkv;      // [rows, 3D] fp32 (q|k|v)
+    void* out;             // [rows, ldo]: out_kind 0 fp32 | 1 op | 2 split3
+    const int* cu_seqlens; // [nseq+1] device row offsets
+    int nseq, n_head, D, ldo, out_kind;
+    int max_len;           // upper bound of 1 + items (<= 32)
+    int only_row0;         // compute query row 0 of every set only (last layer)
+    float scale;
+};
+int ofx_launch_set_attention(const SetAttnArgs& a, int op_dtype, hipStream_t s);

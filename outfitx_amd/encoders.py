@@ -1,0 +1,415 @@
+"""Item encoder of the scoring path: CLIP ViT-B/32 image tower + CLIP text tower + fuser, with the
+reference's module tree (so `state_dict()` keys and strict `load_state_dict` match SURVEY.md §8b)
+but with every forward running in libofx_hip.so.
+
+Reference: src/models/encoders/item_encoder.py:8-61, base_encoders/base_image_encoder.py:17-49,
+base_encoders/base_text_encoder.py:14-40, image_encoders/clip_image_encoder.py:10-79,
+text_encoders/clip_text_encoder.py:11-60, src/utils/model_utils.py:26-48.
+
+The nn.Linear / nn.LayerNorm / nn.Embedding / nn.Conv2d objects below are PARAMETER CONTAINERS
+(names, shapes, default init); their torch forward is never called.
+"""
+from __future__ import annotations
+
+import itertools
+import warnings
+from types import SimpleNamespace
+from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+from PIL import Image
+from torch import nn
+
+from . import _lib as L
+from .configs import ItemEncoderConfig
+from .engine import Engine
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def freeze_model(model: nn.Module) -> None:
+    """src/utils/model_utils.py:8-10"""
+    for p in model.parameters():
+        p.requires_grad = False
+
+
+def flatten_seq_to_one_dim(sequences: List[List[Any]]) -> List[Any]:
+    """src/utils/model_utils.py:47-48"""
+    return list(itertools.chain(*sequences))
+
+
+def aggregate_embeddings(image_embeddings=None, text_embeddings=None, aggregation_method: str = "concat"):
+    """src/utils/model_utils.py:26-45.  'mean' keeps the reference's literal tensor semantics
+    (mean over dim=-2 of the stacked pair -> [2,B,512]); see SURVEY.md §7.3."""
+    embeds = [e for e in (image_embeddings, text_embeddings) if e is not None]
+    if not embeds:
+        raise ValueError("At least one of image_embeds or text_embeds must be provided.")
+    if aggregation_method == "concat":
+        return torch.cat(embeds, dim=-1)
+    if aggregation_method == "mean":
+        return torch.mean(torch.stack(embeds), dim=-2)
+    raise ValueError(f"Unsupported aggregation method: {aggregation_method}. Use 'concat' or 'mean'.")
+
+
+# ----------------------------------------------------------------------------- parameter trees
+class _ClipAttentionParams(nn.Module):
+    def __init__(self, width):
+        super().__init__()
+        self.k_proj = nn.Linear(width, width)
+        self.v_proj = nn.Linear(width, width)
+        self.q_proj = nn.Linear(width, width)
+        self.out_proj = nn.Linear(width, width)
+
+
+class _ClipMlpParams(nn.Module):
+    def __init__(self, width, mlp):
+        super().__init__()
+        self.fc1 = nn.Linear(width, mlp)
+        self.fc2 = nn.Linear(mlp, width)
+
+
+class _ClipLayerParams(nn.Module):
+    def __init__(self, width, mlp, eps):
+        super().__init__()
+        self.self_attn = _ClipAttentionParams(width)
+        self.layer_norm1 = nn.LayerNorm(width, eps=eps)
+        self.mlp = _ClipMlpParams(width, mlp)
+        self.layer_norm2 = nn.LayerNorm(width, eps=eps)
+
+
+class _ClipEncoderParams(nn.Module):
+    def __init__(self, width, mlp, n_layers, eps):
+        super().__init__()
+        self.layers = nn.ModuleList([_ClipLayerParams(width, mlp, eps) for _ in range(n_layers)])
+
+
+def _layer_tensors(layer: _ClipLayerParams) -> List[torch.Tensor]:
+    a, m = layer.self_attn, layer.mlp
+    return [a.k_proj.weight, a.k_proj.bias, a.v_proj.weight, a.v_proj.bias, a.q_proj.weight, a.q_proj.bias,
+            a.out_proj.weight, a.out_proj.bias, layer.layer_norm1.weight, layer.layer_norm1.bias,
+            m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, layer.layer_norm2.weight, layer.layer_norm2.bias]
+
+
+class _VisionEmbeddingParams(nn.Module):
+    def __init__(self, width, patch, image):
+        super().__init__()
+        self.class_embedding = nn.Parameter(torch.randn(width))
+        self.patch_embedding = nn.Conv2d(3, width, kernel_size=patch, stride=patch, bias=False)
+        self.position_embedding = nn.Embedding((image // patch) ** 2 + 1, width)
+
+
+class _VisionTransformerParams(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.embeddings = _VisionEmbeddingParams(c.hidden_size, c.patch_size, c.image_size)
+        self.pre_layrnorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)   # sic: upstream HF spelling
+        self.encoder = _ClipEncoderParams(c.hidden_size, c.intermediate_size, c.num_hidden_layers, c.layer_norm_eps)
+        self.post_layernorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+
+
+class ClipVisionParams(nn.Module):
+    """Same parameter names as HF CLIPVisionModelWithProjection (ViT-B/32 defaults)."""
+
+    def __init__(self, **over):
+        super().__init__()
+        self.config = SimpleNamespace(hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
+                                      num_attention_heads=12, patch_size=32, image_size=224, projection_dim=512,
+                                      hidden_act="quick_gelu", layer_norm_eps=1e-5)
+        self.config.__dict__.update(over)
+        self.vision_model = _VisionTransformerParams(self.config)
+        self.visual_projection = nn.Linear(self.config.hidden_size, self.config.projection_dim, bias=False)
+
+    def pack_list(self) -> List[torch.Tensor]:
+        v = self.vision_model
+        out = [v.embeddings.class_embedding, v.embeddings.patch_embedding.weight, v.embeddings.position_embedding.weight,
+               v.pre_layrnorm.weight, v.pre_layrnorm.bias]
+        for l in v.encoder.layers:
+            out += _layer_tensors(l)
+        return out + [v.post_layernorm.weight, v.post_layernorm.bias, self.visual_projection.weight]
+
+
+class _TextEmbeddingParams(nn.Module):
+    def __init__(self, vocab, max_pos, width):
+        super().__init__()
+        self.token_embedding = nn.Embedding(vocab, width)
+        self.position_embedding = nn.Embedding(max_pos, width)
+
+
+class _TextTransformerParams(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.embeddings = _TextEmbeddingParams(c.vocab_size, c.max_position_embeddings, c.hidden_size)
+        self.encoder = _ClipEncoderParams(c.hidden_size, c.intermediate_size, c.num_hidden_layers, c.layer_norm_eps)
+        self.final_layer_norm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+
+
+class ClipTextParams(nn.Module):
+    """Same parameter names as HF CLIPTextModelWithProjection (CLIP B/32 text defaults)."""
+
+    def __init__(self, **over):
+        super().__init__()
+        self.config = SimpleNamespace(hidden_size=512, intermediate_size=2048, num_hidden_layers=12,
+                                      num_attention_heads=8, vocab_size=49408, max_position_embeddings=77,
+                                      projection_dim=512, hidden_act="quick_gelu", layer_norm_eps=1e-5,
+                                      eos_token_id=49407)
+        self.config.__dict__.update(over)
+        self.text_model = _TextTransformerParams(self.config)
+        self.text_projection = nn.Linear(self.config.hidden_size, self.config.projection_dim, bias=False)
+
+    def pack_list(self) -> List[torch.Tensor]:
+        t = self.text_model
+        out = [t.embeddings.token_embedding.weight, t.embeddings.position_embedding.weight]
+        for l in t.encoder.layers:
+            out += _layer_tensors(l)
+        return out + [t.final_layer_norm.weight, t.final_layer_norm.bias, self.text_projection.weight]
+
+
+def _try_load_pretrained(params: nn.Module, hf_class_name: str, name: str) -> bool:
+    """Copy a HF checkpoint's tensors into our parameter tree when one is available offline/online.
+    HF is used as a FILE READER only; it never computes anything here."""
+    try:
+        import transformers
+        hf = getattr(transformers, hf_class_name).from_pretrained(name, local_files_only=True)
+        for k in ("hidden_act", "layer_norm_eps", "eos_token_id"):
+            if hasattr(hf.config, k) and hasattr(params.config, k):
+                setattr(params.config, k, getattr(hf.config, k))
+        params.load_state_dict(hf.state_dict(), strict=True)
+        return True
+    except Exception:
+        return False
+
+
+# ----------------------------------------------------------------------------- host preprocessing
+def clip_preprocess(images: Sequence[Union[np.ndarray, Image.Image]], size: int = 224) -> torch.Tensor:
+    """Host-side equivalent of CLIPImageProcessor(do_convert_rgb=False) as the reference uses it
+    (clip_image_encoder.py:29-31,69-71): resize shortest edge to `size` (bicubic), centre-crop,
+    rescale 1/255, normalise with the CLIP mean/std.  -> [N,3,size,size] fp32."""
+    out = np.empty((len(images), 3, size, size), np.float32)
+    mean = np.asarray(CLIP_MEAN, np.float32).reshape(3, 1, 1)
+    std = np.asarray(CLIP_STD, np.float32).reshape(3, 1, 1)
+    for i, im in enumerate(images):
+        if not isinstance(im, Image.Image):
+            im = Image.fromarray(np.asarray(im))
+        w, h = im.size
+        short, long_ = (w, h) if w <= h else (h, w)
+        new_short, new_long = size, int(size * long_ / short)
+        nw, nh = (new_short, new_long) if w <= h else (new_long, new_short)
+        if (nw, nh) != (w, h):
+            im = im.resize((nw, nh), resample=Image.BICUBIC)
+        left, top = (nw - size) // 2, (nh - size) // 2
+        im = im.crop((left, top, left + size, top + size))
+        a = np.asarray(im, np.float32)
+        if a.ndim == 2:
+            a = np.repeat(a[:, :, None], 3, 2)
+        out[i] = (a.transpose(2, 0, 1) * np.float32(1 / 255.0) - mean) / std
+    return torch.from_numpy(out)
+
+
+# ----------------------------------------------------------------------------- encoders
+class _TowerBase(nn.Module):
+    """Engine plumbing shared by the two towers: an Engine per device, repacked when parameters change."""
+
+    def __init__(self):
+        super().__init__()
+        self._engines: Dict[Any, Engine] = {}
+        self.tower_precision = "bf16"
+
+    @property
+    def device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+
+    def _engine(self, kind: str) -> Engine:
+        dev = self.device
+        key = (dev, self.tower_precision)
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = Engine(dev, self._desc(), tower_precision=self.tower_precision)
+            self._engines[key] = eng
+        sig = self._signature()
+        if eng.signature[kind] != sig:
+            getattr(eng, "pack_" + kind)(self.model.pack_list())
+            eng.signature[kind] = sig
+        return eng
+
+    def __getstate__(self):          # engines hold ctypes handles: never pickle / deepcopy them
+        s = self.__dict__.copy()
+        s["_engines"] = {}
+        return s
+
+
+class CLIPImageEncoder(_TowerBase):
+    """Reference: image_encoders/clip_image_encoder.py:10-79 (+ BaseImageEncoder.forward)."""
+
+    def __init__(self, model_name_or_path: str = "patrickjohncyh/fashion-clip", freeze: bool = True):
+        super().__init__()
+        self.model = ClipVisionParams()
+        self.pretrained = _try_load_pretrained(self.model, "CLIPVisionModelWithProjection", model_name_or_path)
+        if not self.pretrained:
+            warnings.warn(f"CLIP vision checkpoint '{model_name_or_path}' not available offline: random-initialised "
+                          "(load weights with load_state_dict)", stacklevel=2)
+        self.model.eval()
+        if freeze:
+            freeze_model(self.model)
+        self.processor = SimpleNamespace(size={"shortest_edge": self.model.config.image_size})
+
+    def _desc(self) -> L.ModelDesc:
+        d, c = L.default_desc(), self.model.config
+        d.vit_width, d.vit_layers, d.vit_heads, d.vit_mlp = c.hidden_size, c.num_hidden_layers, c.num_attention_heads, c.intermediate_size
+        d.vit_patch, d.vit_image, d.proj_dim, d.ln_eps = c.patch_size, c.image_size, c.projection_dim, c.layer_norm_eps
+        d.vit_act = L.ACTS[c.hidden_act]
+        return d
+
+    @property
+    def image_size(self) -> Tuple[int, int]:
+        s = self.processor.size["shortest_edge"]
+        return (s, s)
+
+    @property
+    def d_embed(self) -> int:
+        return self.model.config.projection_dim
+
+    def _pixels(self, images) -> Tuple[torch.Tensor, int]:
+        if isinstance(images, torch.Tensor):
+            b = images.size(0)
+            return images.reshape(b * images.size(1), *images.shape[2:]), b
+        if len(set(len(seq) for seq in images)) != 1:
+            raise ValueError("All sequences in images should have the same length.")
+        return clip_preprocess(flatten_seq_to_one_dim(images), self.model.config.image_size), len(images)
+
+    @torch.no_grad()
+    def encode_into(self, images, out: torch.Tensor, col: int, normalize: bool) -> int:
+        """Run the tower and write [N,512] into out[:, col:col+512]; returns the batch size B."""
+        px, b = self._pixels(images)
+        self._engine("vision").vit(px, out, col, normalize)
+        return b
+
+    @torch.no_grad()
+    def forward(self, images, normalize: bool = True, *args, **kwargs) -> torch.Tensor:
+        px, b = self._pixels(images)
+        out = torch.empty(px.shape[0], self.d_embed, dtype=torch.float32, device=self.device)
+        self._engine("vision").vit(px, out, 0, normalize)
+        return out.view(b, -1, self.d_embed)
+
+
+class CLIPTextEncoder(_TowerBase):
+    """Reference: text_encoders/clip_text_encoder.py:11-60 (+ BaseTextEncoder.forward).  Accepts
+    List[List[str]] (needs the CLIP BPE vocabulary to be available to transformers) or an already
+    tokenised dict {'input_ids','attention_mask'} of [B,L,T] tensors."""
+
+    def __init__(self, model_name_or_path: str = "patrickjohncyh/fashion-clip", freeze: bool = True):
+        super().__init__()
+        self.model = ClipTextParams()
+        self.pretrained = _try_load_pretrained(self.model, "CLIPTextModelWithProjection", model_name_or_path)
+        if not self.pretrained:
+            warnings.warn(f"CLIP text checkpoint '{model_name_or_path}' not available offline: random-initialised",
+                          stacklevel=2)
+        self.model.eval()
+        if freeze:
+            freeze_model(self.model)
+        self._tok_name = model_name_or_path
+        self.tokenizer = None
+
+    def _desc(self) -> L.ModelDesc:
+        d, c = L.default_desc(), self.model.config
+        d.txt_width, d.txt_layers, d.txt_heads, d.txt_mlp = c.hidden_size, c.num_hidden_layers, c.num_attention_heads, c.intermediate_size
+        d.txt_vocab, d.txt_max_pos, d.proj_dim, d.ln_eps = c.vocab_size, c.max_position_embeddings, c.projection_dim, c.layer_norm_eps
+        d.txt_act, d.txt_eos_id = L.ACTS[c.hidden_act], c.eos_token_id
+        return d
+
+    @property
+    def d_embed(self) -> int:
+        return self.model.config.projection_dim
+
+    def _tokenize(self, texts: List[str], tokenizer_kargs: Optional[dict]):
+        if self.tokenizer is None:
+            try:
+                from transformers import CLIPTokenizer
+                self.tokenizer = CLIPTokenizer.from_pretrained(self._tok_name)
+            except Exception as e:
+                raise RuntimeError("CLIP tokenizer files are not available; pass pre-tokenised "
+                                   "{'input_ids','attention_mask'} tensors instead of strings") from e
+        kw = tokenizer_kargs if tokenizer_kargs is not None else {"max_length": 64, "padding": "max_length", "truncation": True}
+        kw["return_tensors"] = "pt"
+        enc = self.tokenizer(text=texts, **kw)
+        return enc["input_ids"], enc["attention_mask"]
+
+    def _ids(self, texts, tokenizer_kargs=None):
+        if isinstance(texts, dict):
+            ids = texts["input_ids"]
+            b, l = ids.size(0), ids.size(1)
+            att = texts.get("attention_mask")
+            return ids.reshape(b * l, -1), None if att is None else att.reshape(b * l, -1), b
+        if len(set(len(seq) for seq in texts)) != 1:
+            raise ValueError("All sequences in texts should have the same length.")
+        ids, att = self._tokenize(flatten_seq_to_one_dim(texts), tokenizer_kargs)
+        return ids, att, len(texts)
+
+    def _lengths(self, ids: torch.Tensor):
+        """EOS position + 1 per text when the ids live on the host (no device sync otherwise)."""
+        if ids.device.type != "cpu":
+            return None
+        eos = self.model.config.eos_token_id
+        pos = ids.argmax(-1) if eos == 2 else (ids == eos).int().argmax(-1)
+        return (pos + 1).tolist()
+
+    @torch.no_grad()
+    def encode_into(self, texts, out: torch.Tensor, col: int, normalize: bool, tokenizer_kargs=None) -> int:
+        ids, att, b = self._ids(texts, tokenizer_kargs)
+        self._engine("text").text(ids, att, out, col, normalize, self._lengths(ids))
+        return b
+
+    @torch.no_grad()
+    def forward(self, texts, normalize: bool = True, *args, **kwargs) -> torch.Tensor:
+        ids, att, b = self._ids(texts, kwargs.get("tokenizer_kargs"))
+        out = torch.empty(ids.shape[0], self.d_embed, dtype=torch.float32, device=self.device)
+        self._engine("text").text(ids, att, out, 0, normalize, self._lengths(ids))
+        return out.view(b, -1, self.d_embed)
+
+
+class ItemEncoder(nn.Module):
+    """Reference: src/models/encoders/item_encoder.py:8-61 — only the type='clip' branch (:20-26) is built."""
+
+    def __init__(self, cfg: ItemEncoderConfig):
+        super().__init__()
+        self.cfg = cfg
+        if cfg.type != "clip":
+            raise NotImplementedError(
+                f"ItemEncoderConfig(type='{cfg.type}') is outside the MI355X scoring path; build the model with "
+                "OutfitXConfig(item_encoder=ItemEncoderConfig(type='clip'))")
+        self.image_enc = CLIPImageEncoder(model_name_or_path=cfg.clip_model_name)
+        self.text_enc = CLIPTextEncoder(model_name_or_path=cfg.clip_model_name)
+
+    @property
+    def d_embed(self) -> int:
+        return self.cfg.dim_per_modality * 2 if self.cfg.aggregation_method == "concat" else self.cfg.dim_per_modality
+
+    @property
+    def image_size(self):
+        return self.image_enc.image_size
+
+    def set_precision(self, tower_precision: str) -> None:
+        self.image_enc.tower_precision = tower_precision
+        self.text_enc.tower_precision = tower_precision
+
+    def forward(self, images, texts, *args, **kwargs) -> torch.Tensor:
+        if self.cfg.aggregation_method == "concat":
+            # concat fuser fused into the towers' epilogues: both write straight into one [B*L,1024] buffer
+            dev = self.image_enc.device
+            n = (images.size(0) * images.size(1)) if isinstance(images, torch.Tensor) else sum(len(s) for s in images)
+            d = self.cfg.dim_per_modality
+            out = torch.empty(n, 2 * d, dtype=torch.float32, device=dev)
+            b = self.image_enc.encode_into(images, out, 0, self.cfg.norm_out)
+            b2 = self.text_enc.encode_into(texts, out, d, self.cfg.norm_out)
+            if b != b2:
+                raise ValueError("images and texts disagree on the batch size")
+            return out.view(b, -1, 2 * d)
+        img = self.image_enc(images, normalize=self.cfg.norm_out, *args, **kwargs)
+        txt = self.text_enc(texts, normalize=self.cfg.norm_out, *args, **kwargs)
+        return aggregate_embeddings(image_embeddings=img, text_embeddings=txt, aggregation_method=self.cfg.aggregation_method)
+
+    encode_items = forward   # north-star alias (the reference has no encode_items)

@@ -1,0 +1,191 @@
+"""Thin Python host over the C ABI: owns an ofx_handle, packs torch parameters into it, lends
+torch-allocated workspaces and output tensors, and launches on torch's current HIP stream.
+
+PyTorch is plumbing here (device memory, streams); all arithmetic happens in libofx_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _f32c(t: torch.Tensor, device) -> torch.Tensor:
+    if t.device != device or t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.to(device=device, dtype=torch.float32).contiguous()
+    return t
+
+
+class Engine:
+    """One per (module, device).  `precision`: MFMA operand format of the outfit transformer
+    ('bf16x3' | 'bf16' | 'f16'); `tower_precision`: of the CLIP towers ('bf16' | 'f16')."""
+
+    def __init__(self, device: torch.device, desc: Optional[L.ModelDesc] = None,
+                 precision: str = "bf16x3", tower_precision: str = "bf16"):
+        self.lib = L.load()
+        if device.type != "cuda":
+            raise L.OfxError(f"outfitx_amd runs on an MI355X HIP device only (got {device}); there is no CPU path")
+        self.device = torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
+        d = desc if desc is not None else L.default_desc()
+        d.outfit_precision = L.PRECISIONS[precision]
+        d.tower_precision = L.PRECISIONS[tower_precision]
+        self.desc = d
+        self.h = self.lib.ofx_create(self.device.index, C.byref(d))
+        if not self.h:
+            raise L.OfxError("ofx_create failed: " + self.lib.ofx_last_error().decode())
+        self._ws: Dict[int, torch.Tensor] = {}
+        self._keep: List[torch.Tensor] = []
+        self.signature = {"outfit": None, "vision": None, "text": None}
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.ofx_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- weights
+    def _pack(self, fn, tensors: Sequence[torch.Tensor], what: str):
+        ts = [_f32c(t.detach(), self.device) for t in tensors]
+        arr = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        with torch.cuda.device(self.device):
+            L.check(fn(self.h, arr, len(ts), _stream(self.device)), f"ofx_pack_{what}_weights")
+        # the pack kernels read `ts` asynchronously on the current stream; keep temporaries alive until they are done
+        self._keep = [t for t in ts]
+
+    def pack_outfit(self, tensors): self._pack(self.lib.ofx_pack_outfit_weights, tensors, "outfit")
+    def pack_vision(self, tensors): self._pack(self.lib.ofx_pack_vision_weights, tensors, "vision")
+    def pack_text(self, tensors): self._pack(self.lib.ofx_pack_text_weights, tensors, "text")
+
+    # ---------------------------------------------------------------- workspace
+    def workspace(self, nbytes: int) -> torch.Tensor:
+        key = _stream(self.device)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(int(nbytes * 1.05) + 4096, dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
+
+    def ws_bytes(self, op: int, n: int, length: int) -> int:
+        return int(self.lib.ofx_workspace_bytes(self.h, op, n, length))
+
+    # ---------------------------------------------------------------- outfit transformer
+    def set_encoder(self, x: torch.Tensor, mask: torch.Tensor, prefix: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x [B,L,D] float, mask [B,L] bool (True = pad) -> encoder output at the prefix token [B,D] fp32."""
+        B, Lq, D = x.shape
+        x = _f32c(x, self.device)
+        m = mask.to(device=self.device)
+        m = (m if m.dtype == torch.bool else m != 0).contiguous().view(torch.uint8)
+        stride = 0
+        if prefix is not None:
+            prefix = _f32c(prefix, self.device)
+            stride = 0 if prefix.dim() == 1 else D
+        out = torch.empty(B, D, dtype=torch.float32, device=self.device)
+        nb = self.ws_bytes(L.OP_SET_ENCODER, B, Lq)
+        ws = self.workspace(nb)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ofx_set_encoder_fwd(self.h, _ptr(x), _ptr(m), _ptr(prefix), stride, B, Lq, _ptr(out),
+                                                 _ptr(ws), ws.numel(), _stream(self.device)), "ofx_set_encoder_fwd")
+        return out
+
+    def cp_head(self, row0: torch.Tensor) -> torch.Tensor:
+        B = row0.shape[0]
+        out = torch.empty(B, 1, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ofx_cp_head(self.h, _ptr(row0), B, _ptr(out), _stream(self.device)), "ofx_cp_head")
+        return out
+
+    def cir_head(self, row0: torch.Tensor) -> torch.Tensor:
+        B, D = row0.shape
+        out = torch.empty(B, D, dtype=torch.float32, device=self.device)
+        ws = self.workspace(B * D * 2 * 3 + 256)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ofx_cir_head(self.h, _ptr(row0), B, _ptr(out), _ptr(ws), ws.numel(), _stream(self.device)), "ofx_cir_head")
+        return out
+
+    def cir_prefix(self, target_text: torch.Tensor) -> torch.Tensor:
+        t = _f32c(target_text, self.device)
+        B = t.shape[0]
+        out = torch.empty(B, self.desc.d_model, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ofx_cir_prefix(self.h, _ptr(t), B, _ptr(out), _stream(self.device)), "ofx_cir_prefix")
+        return out
+
+    # ---------------------------------------------------------------- towers
+    def vit(self, pixels: torch.Tensor, out: torch.Tensor, col: int, normalize: bool) -> None:
+        """pixels [N,3,H,W] fp32 pixel_values -> out[:, col:col+512] (out is [N, ld] fp32 contiguous)."""
+        px = _f32c(pixels, self.device)
+        N = px.shape[0]
+        nb = self.ws_bytes(L.OP_VIT, N, 0)
+        ws = self.workspace(nb)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ofx_vit_b32_fwd(self.h, _ptr(px), N, _ptr(out), out.stride(0), col, int(normalize),
+                                             _ptr(ws), ws.numel(), _stream(self.device)), "ofx_vit_b32_fwd")
+
+    def text(self, ids: torch.Tensor, att: Optional[torch.Tensor], out: torch.Tensor, col: int, normalize: bool,
+             lengths: Optional[Sequence[int]] = None) -> None:
+        """ids/att [N,T] int64 -> out[:, col:col+512].  lengths: host ints (EOS position + 1) or None."""
+        ids_d = ids.to(device=self.device, dtype=torch.int64).contiguous()
+        att_d = None if att is None else att.to(device=self.device, dtype=torch.int64).contiguous()
+        N, T = ids_d.shape
+        Tc = T if lengths is None else max(1, min(T, max(int(v) for v in lengths)))
+        arr = None if lengths is None else (C.c_int * N)(*[int(v) for v in lengths])
+        nb = self.ws_bytes(L.OP_TEXT, N, Tc)
+        ws = self.workspace(nb)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ofx_clip_text_fwd(self.h, _ptr(ids_d), _ptr(att_d), arr, N, T, _ptr(out), out.stride(0), col,
+                                               int(normalize), _ptr(ws), ws.numel(), _stream(self.device)), "ofx_clip_text_fwd")
+        self._keep_ids = (ids_d, att_d)
+
+    # ---------------------------------------------------------------- scoring
+    def l2_topk(self, Q: torch.Tensor, P: torch.Tensor, k: int, index_base: int = 0):
+        Q = _f32c(Q, self.device); P = _f32c(P, self.device)
+        nq, D = Q.shape
+        npool = P.shape[0]
+        idx = torch.empty(nq, k, dtype=torch.int64, device=self.device)
+        dist = torch.empty(nq, k, dtype=torch.float32, device=self.device)
+        ws = self.workspace(self.ws_bytes(L.OP_TOPK, nq, npool))
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ofx_l2_topk(self.h, _ptr(Q), _ptr(P), nq, npool, D, k, index_base, _ptr(idx), _ptr(dist),
+                                         _ptr(ws), ws.numel(), _stream(self.device)), "ofx_l2_topk")
+        return idx, dist
+
+
+def fitb_argmin(y_hat: torch.Tensor, cand: torch.Tensor, return_dist: bool = False):
+    """torch.cdist(y[B,1,D], cand[B,C,D]).squeeze(1).argmin(-1) on the GPU, fp32, first minimum."""
+    lib = L.load()
+    dev = y_hat.device
+    if dev.type != "cuda":
+        raise L.OfxError("fitb_argmin needs HIP tensors; there is no CPU path")
+    y = _f32c(y_hat, dev); c = _f32c(cand, dev)
+    B, Cn, D = c.shape
+    idx = torch.empty(B, dtype=torch.int64, device=dev)
+    dist = torch.empty(B, Cn, dtype=torch.float32, device=dev) if return_dist else None
+    with torch.cuda.device(dev):
+        L.check(lib.ofx_fitb_argmin(_ptr(y), _ptr(c), B, Cn, D, _ptr(idx), _ptr(dist), _stream(dev)), "ofx_fitb_argmin")
+    return (idx, dist) if return_dist else idx
+
+
+def topk_merge(idx_parts: torch.Tensor, dist_parts: torch.Tensor):
+    """[parts,nq,k] per-shard candidates (global indices) -> ([nq,k] idx, [nq,k] dist), ascending, ties -> smaller idx."""
+    lib = L.load()
+    dev = idx_parts.device
+    parts, nq, k = idx_parts.shape
+    ii = idx_parts.contiguous(); dd = dist_parts.contiguous()
+    idx = torch.empty(nq, k, dtype=torch.int64, device=dev)
+    dist = torch.empty(nq, k, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        L.check(lib.ofx_topk_merge(_ptr(ii), _ptr(dd), parts, nq, k, _ptr(idx), _ptr(dist), _stream(dev)), "ofx_topk_merge")
+    return idx, dist

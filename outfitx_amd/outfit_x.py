@@ -1,0 +1,144 @@
+"""OutfitX — drop-in for the reference's `src.models.OutfitX` (src/models/outfit_x.py:17-172) whose
+forward runs on hand-written gfx950 kernels through libofx_hip.so.
+
+Same constructor, same `forward(task, **tensors)` dispatch on the task CLASS, same attribute
+names and the same `state_dict()` key set / shapes (strict-load compatible), so the
+reference's trainers (compatibility_prediction_trainer.py:59-64) and demo (demo/app.py:102-129)
+can use it unchanged.  There is NO PyTorch/CPU fallback: without the HIP library or off a HIP
+device the forward raises.
+
+`nn.TransformerEncoder` / `nn.Linear` below are parameter containers (names, shapes and torch's
+default initialisation, so the same seed yields the reference's initial weights); their torch
+forward is never called.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Type, TypeVar, Union
+
+import numpy as np
+import torch
+from PIL import Image
+from torch import nn
+
+from . import _lib as L
+from .configs import OutfitXConfig
+from .datatypes import (OutfitCompatibilityPredictionTask, OutfitComplementaryItemRetrievalTask,
+                        OutfitFillInTheBlankTask, OutfitPrecomputeEmbeddingTask)
+from .encoders import ItemEncoder
+from .engine import Engine
+
+_ACT_NAMES = {"mish": "mish", "gelu": "gelu", "relu": None}
+
+
+def _activation_id(act) -> int:
+    name = act if isinstance(act, str) else getattr(act, "__name__", "")
+    if name == "mish":
+        return L.ACT_MISH
+    if name == "gelu":
+        return L.ACT_GELU
+    raise NotImplementedError(f"transformer activation {act!r} has no fused epilogue (mish / gelu are built)")
+
+
+class OutfitX(nn.Module):
+    Tasks = TypeVar("Tasks", OutfitComplementaryItemRetrievalTask, OutfitCompatibilityPredictionTask,
+                    OutfitFillInTheBlankTask, OutfitPrecomputeEmbeddingTask)
+
+    def __init__(self, cfg: Optional[OutfitXConfig] = None, precision: str = "bf16x3", tower_precision: str = "bf16"):
+        super().__init__()
+        self.cfg = cfg if cfg is not None else OutfitXConfig()
+        t = self.cfg.transformer
+        self.item_encoder = ItemEncoder(self.cfg.item_encoder)
+        d = self.item_encoder.d_embed
+        layer = nn.TransformerEncoderLayer(d_model=d, nhead=t.n_head, dim_feedforward=t.d_ffn, dropout=t.dropout,
+                                           batch_first=t.batch_first, norm_first=t.norm_first, activation=t.activation)
+        self.transformer_encoder = nn.TransformerEncoder(encoder_layer=layer, num_layers=t.n_layers,
+                                                         enable_nested_tensor=t.enable_nested_tensor)
+        self.outfit_token = nn.Parameter(torch.randn(d) * 0.02, requires_grad=True)
+        self.cp_ffn = nn.Sequential(nn.Dropout(t.dropout), nn.Linear(d, 1))
+        self.cir_ffn = nn.Sequential(nn.Linear(d, self.cfg.d_embed, bias=False))
+        self.target_item_image_emb = nn.Parameter(torch.randn(d // 2) * 0.02, requires_grad=True)
+        self.forward_ = {
+            OutfitCompatibilityPredictionTask: self._cp_forward,
+            OutfitComplementaryItemRetrievalTask: self._cir_forward,
+            OutfitFillInTheBlankTask: self._cir_forward,
+            OutfitPrecomputeEmbeddingTask: self.precompute_embeddings,
+        }
+        if not t.norm_first:
+            raise NotImplementedError("post-norm encoder layers are outside the scoring path (reference uses norm_first)")
+        self.precision = precision
+        self.item_encoder.set_precision(tower_precision)
+        self._engines: Dict[Any, Engine] = {}
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    def __getstate__(self):
+        s = self.__dict__.copy()
+        s["_engines"] = {}
+        return s
+
+    def _outfit_tensors(self) -> List[torch.Tensor]:
+        out = [self.outfit_token, self.target_item_image_emb, self.cp_ffn[1].weight, self.cp_ffn[1].bias, self.cir_ffn[0].weight]
+        for l in self.transformer_encoder.layers:
+            out += [l.self_attn.in_proj_weight, l.self_attn.in_proj_bias, l.self_attn.out_proj.weight, l.self_attn.out_proj.bias,
+                    l.linear1.weight, l.linear1.bias, l.linear2.weight, l.linear2.bias,
+                    l.norm1.weight, l.norm1.bias, l.norm2.weight, l.norm2.bias]
+        return out
+
+    def _engine(self) -> Engine:
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("outfitx_amd builds the forward (scoring) path; the training step / backward is a "
+                                      "'next' row (SURVEY.md §8f N1).  Call under torch.no_grad() or model.eval().")
+        dev = self.device
+        key = (dev, self.precision)
+        eng = self._engines.get(key)
+        if eng is None:
+            desc = L.default_desc()
+            t = self.cfg.transformer
+            desc.d_model, desc.n_head, desc.d_ffn, desc.n_layers = self.item_encoder.d_embed, t.n_head, t.d_ffn, t.n_layers
+            desc.max_items = min(self.cfg.max_length, 31)
+            desc.outfit_act = _activation_id(t.activation)
+            desc.ln_eps = self.transformer_encoder.layers[0].norm1.eps
+            eng = Engine(dev, desc, precision=self.precision)
+            self._engines[key] = eng
+        ts = self._outfit_tensors()
+        sig = tuple((p.data_ptr(), p._version) for p in ts)
+        if eng.signature["outfit"] != sig:
+            eng.pack_outfit(ts)
+            eng.signature["outfit"] = sig
+        return eng
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, task: Type["OutfitX.Tasks"], *args, **kwargs):
+        """outfit_x.py:97-104: dispatch on the task class; unknown key -> KeyError."""
+        return self.forward_[task](*args, **kwargs)
+
+    def precompute_embeddings(self, images: List[List[Union[np.ndarray, Image.Image]]], texts: List[List[str]]):
+        """outfit_x.py:107-118: one item per 'outfit' -> [B, d_embed]."""
+        return self.item_encoder(images, texts)[:, 0, :]
+
+    def encode_items(self, images, texts):
+        """north-star alias of ItemEncoder.forward: [B,L] items -> [B,L,d_embed]."""
+        return self.item_encoder(images, texts)
+
+    def _run_encoder(self, outfit_embedding, outfit_mask, prefix=None):
+        eng = self._engine()
+        return eng, eng.set_encoder(outfit_embedding, outfit_mask, prefix)
+
+    def _cp_forward(self, outfit_embedding: Optional[torch.Tensor], outfit_mask: torch.Tensor,
+                    encoder_input_dict: Optional[dict] = None) -> torch.Tensor:
+        """outfit_x.py:120-144 -> raw compatibility logits [B,1]."""
+        if encoder_input_dict is not None:
+            outfit_embedding = self.item_encoder(**encoder_input_dict)
+        eng, row0 = self._run_encoder(outfit_embedding, outfit_mask)
+        return eng.cp_head(row0)
+
+    def _cir_forward(self, outfit_embedding: torch.Tensor, outfit_mask: torch.Tensor,
+                     target_item_text_embedding: torch.Tensor) -> torch.Tensor:
+        """outfit_x.py:147-172 -> target-item embedding [B, d_embed]."""
+        eng = self._engine()
+        prefix = eng.cir_prefix(target_item_text_embedding)
+        row0 = eng.set_encoder(outfit_embedding, outfit_mask, prefix)
+        return eng.cir_head(row0)

@@ -1,0 +1,221 @@
+"""Model-level parity on a real MI355X, through the drop-in `src.models.OutfitX` API (which calls the
+C ABI): golden vectors from the reference itself, the numpy oracle on fresh seeded inputs, and
+size-independent properties at BASELINE.json's full sizes.
+
+Tolerances (metric: max|Δ| / max|ref| over the batch, as DESIGN.md states):
+  outfit transformer, precision 'bf16x3' (default)  : 1e-3   (north-star bound; measured ~1e-5)
+  outfit transformer, 'f16' / 'bf16' single product : 3e-3 / 3e-2  (operand-rounding floor)
+  CLIP towers 'bf16' / 'f16'                         : 3e-2 / 4e-3
+  argmin / top-k indices                             : bit-exact
+"""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import W_SEED, golden, rel_err
+from oracle import np_oracle as O
+from outfitx_amd import synth
+
+pytestmark = pytest.mark.gpu
+warnings.simplefilter("ignore")
+
+
+@pytest.fixture(scope="module")
+def model():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    from src.models import OutfitX
+    from src.models.configs import ItemEncoderConfig, OutfitXConfig
+    m = OutfitX(OutfitXConfig(item_encoder=ItemEncoderConfig(type="clip")))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.full_state_dict(W_SEED).items()}, strict=True)
+    return m.cuda().eval()
+
+
+def tasks():
+    from src.models.datatypes import (OutfitCompatibilityPredictionTask, OutfitComplementaryItemRetrievalTask,
+                                      OutfitFillInTheBlankTask, OutfitPrecomputeEmbeddingTask)
+    return OutfitCompatibilityPredictionTask, OutfitComplementaryItemRetrievalTask, OutfitFillInTheBlankTask, OutfitPrecomputeEmbeddingTask
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("tag", ["ot_cfg1", "ot_ragged"])
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 1e-3), ("f16", 3e-3), ("bf16", 3e-2)])
+def test_cp_and_cir_vs_reference_golden(model, tag, prec, tol):
+    CP, CIR, FITB, _ = tasks()
+    g = golden(tag)
+    B, seed = int(g["B"]), int(g["seed"])
+    n = g["n_items"] if g["n_items"].ndim else int(g["n_items"])
+    emb, mask = synth.outfit_batch(seed, B, 16, n)
+    txt = synth.unit_rows(seed, "target_text", B, 512)
+    model.precision = prec
+    with torch.no_grad():
+        cp = model(task=CP, outfit_embedding=cu(emb), outfit_mask=cu(mask))
+        cir = model(task=CIR, outfit_embedding=cu(emb), outfit_mask=cu(mask), target_item_text_embedding=cu(txt))
+        fitb = model(task=FITB, outfit_embedding=cu(emb), outfit_mask=cu(mask), target_item_text_embedding=cu(txt))
+    model.precision = "bf16x3"
+    assert cp.shape == (B, 1) and cir.shape == (B, 1024) and cp.dtype == torch.float32
+    e_cp, e_cir = rel_err(cp.cpu().numpy(), g["cp_logits"]), rel_err(cir.cpu().numpy(), g["cir_emb"])
+    print(f"{tag} {prec}: cp {e_cp:.2e} cir {e_cir:.2e}")
+    assert e_cp < tol and e_cir < tol
+    assert torch.equal(cir, fitb)            # FITB dispatches to the same forward (outfit_x.py:87)
+
+
+def test_pad_values_and_positions_are_inert(model):
+    CP = tasks()[0]
+    emb, mask = synth.outfit_batch(21, 16, 16, synth.ragged_lengths(21, 16, 1, 16))
+    with torch.no_grad():
+        a = model(task=CP, outfit_embedding=cu(emb), outfit_mask=cu(mask))
+        emb2 = emb.copy(); emb2[mask] = 1e6                      # garbage in padded rows
+        b = model(task=CP, outfit_embedding=cu(emb2), outfit_mask=cu(mask))
+        # move the padding to the front: masked keys are skipped wherever they sit
+        emb3 = np.concatenate([emb2[:, 8:], emb2[:, :8]], 1); mask3 = np.concatenate([mask[:, 8:], mask[:, :8]], 1)
+        c = model(task=CP, outfit_embedding=cu(emb3), outfit_mask=cu(mask3))
+    assert torch.equal(a, b)
+    want = O.cp_forward(emb3, mask3, synth.outfit_transformer_weights(W_SEED))
+    assert rel_err(c.cpu().numpy(), want) < 1e-3
+
+
+def test_cp_full_size_cfg3_vs_oracle_and_batch_invariance(model):
+    """B=1024 (BASELINE config 3 batch) ragged outfits: full oracle comparison on a 48-outfit subset and
+    batch-composition invariance on all 1024 (an outfit's score cannot depend on its neighbours)."""
+    CP = tasks()[0]
+    B = 1024
+    n = synth.ragged_lengths(31, B, 1, 16)
+    emb, mask = synth.outfit_batch(31, B, 16, n)
+    with torch.no_grad():
+        full = model(task=CP, outfit_embedding=cu(emb), outfit_mask=cu(mask)).cpu().numpy()
+        perm = np.random.default_rng(0).permutation(B)
+        shuf = model(task=CP, outfit_embedding=cu(emb[perm]), outfit_mask=cu(mask[perm])).cpu().numpy()
+        solo = model(task=CP, outfit_embedding=cu(emb[5:6]), outfit_mask=cu(mask[5:6])).cpu().numpy()
+    assert np.array_equal(full[perm], shuf)
+    assert np.array_equal(full[5:6], solo)
+    sub = np.arange(0, B, 22)[:48]
+    want = O.cp_forward(emb[sub], mask[sub], synth.outfit_transformer_weights(W_SEED))
+    assert rel_err(full[sub], want) < 1e-3
+
+
+def test_vit_tower_vs_reference_golden(model):
+    g = golden("vit_n4")
+    px = synth.pixel_values(int(g["seed"]), 4)
+    enc = model.item_encoder.image_enc
+    for prec, tol in (("bf16", 3e-2), ("f16", 4e-3)):
+        enc.tower_precision = prec
+        out = enc(cu(px).view(4, 1, 3, 224, 224), normalize=False).view(4, 512)
+        e = rel_err(out.cpu().numpy(), g["image_embeds"])
+        print(f"vit {prec}: {e:.2e}")
+        assert e < tol
+    enc.tower_precision = "bf16"
+
+
+def test_text_tower_vs_reference_golden(model):
+    g = golden("text_n8")
+    ids, att = synth.token_batch(int(g["seed"]), 8, 64, g["n_real"])
+    enc = model.item_encoder.text_enc
+    for prec, tol in (("bf16", 3e-2), ("f16", 4e-3)):
+        enc.tower_precision = prec
+        dev_in = {"input_ids": cu(ids).view(8, 1, 64), "attention_mask": cu(att).view(8, 1, 64)}      # ids on device: all T tokens computed
+        host_in = {"input_ids": torch.from_numpy(ids).view(8, 1, 64), "attention_mask": torch.from_numpy(att).view(8, 1, 64)}
+        a = enc(dev_in, normalize=False).view(8, 512).cpu().numpy()
+        b = enc(host_in, normalize=False).view(8, 512).cpu().numpy()                                   # ids on host: truncated at EOS
+        print(f"text {prec}: {rel_err(a, g['text_embeds']):.2e} / {rel_err(b, g['text_embeds']):.2e}")
+        assert rel_err(a, g["text_embeds"]) < tol and rel_err(b, g["text_embeds"]) < tol
+    enc.tower_precision = "bf16"
+
+
+def test_item_encoder_cp_with_encoder_and_precompute(model):
+    CP, _, _, PE = tasks()
+    g = golden("item_encoder")
+    B, L = 2, 3
+    px = synth.pixel_values(1239, B * L).reshape(B, L, 3, 224, 224)
+    ids, att = synth.token_batch(1239, B * L, 64, np.array([4, 8, 6, 3, 9, 12]))
+    texts = {"input_ids": torch.from_numpy(ids).view(B, L, 64), "attention_mask": torch.from_numpy(att).view(B, L, 64)}
+    model.item_encoder.set_precision("f16")
+    with torch.no_grad():
+        items = model.item_encoder(cu(px), texts)
+        cp = model(task=CP, outfit_embedding=None, outfit_mask=cu(g["mask"]), encoder_input_dict={"images": cu(px), "texts": texts})
+        pe = model(task=PE, images=cu(px[:, :1]), texts={k: v[:, :1] for k, v in texts.items()})
+        model.item_encoder.cfg.aggregation_method = "mean"
+        mean = model.item_encoder(cu(px), texts)
+        model.item_encoder.cfg.aggregation_method = "concat"
+    model.item_encoder.set_precision("bf16")
+    assert items.shape == (B, L, 1024)
+    assert rel_err(items.cpu().numpy(), g["item_emb"]) < 4e-3
+    h = items.view(B, L, 2, 512).norm(dim=-1).cpu().numpy()
+    assert np.abs(h - 1).max() < 1e-5                          # each modality half is unit-norm
+    assert rel_err(cp.cpu().numpy(), g["cp_logits"]) < 2e-2
+    assert rel_err(pe.cpu().numpy(), g["precomputed"]) < 4e-3
+    assert tuple(mean.shape) == g["items_mean"].shape           # the reference's literal 'mean' semantics
+    assert rel_err(mean.cpu().numpy(), g["items_mean"]) < 4e-3
+    with pytest.raises(ValueError):
+        model.item_encoder([[np.zeros((224, 224, 3), np.uint8)], []], texts)
+
+
+def test_scoring_vs_reference_golden_bit_exact():
+    from outfitx_amd.engine import Engine, fitb_argmin
+    g = golden("scoring")
+    y = (synth.item_embeddings(1240, "y_hat", 64) * 3.0).astype(np.float32)
+    cand = synth.item_embeddings(1240, "cand", 64, 4)
+    idx, d = fitb_argmin(cu(y), cu(cand), return_dist=True)
+    assert np.array_equal(idx.cpu().numpy(), g["fitb_idx"])
+    assert rel_err(d.cpu().numpy(), g["fitb_dist"]) < 1e-6
+    Q = (synth.item_embeddings(1241, "queries", 100) * 3.0).astype(np.float32)
+    P = synth.item_embeddings(1241, "pool", 5000)
+    eng = Engine(torch.device("cuda", 0))
+    ti, td = eng.l2_topk(cu(Q), cu(P), 50)
+    assert rel_err(td.cpu().numpy(), g["topk_dist"]) < 1e-6
+    assert np.array_equal(ti.cpu().numpy(), g["topk_idx"])
+
+
+def test_topk_full_size_properties_and_sharded_merge():
+    """BASELINE config 4 shape on one GPU: 1000 queries x 100k pool, k=50; 8 row-shards merged like the
+    RCCL all-gather path.  Properties: ascending, exact agreement with fp64 distances on the selected
+    set, sharded == unsharded, ties -> smaller index (duplicated pool rows)."""
+    from outfitx_amd.engine import Engine, topk_merge
+    nq, npool, k = 1000, 100_000, 50
+    Q = (synth.item_embeddings(41, "q", nq) * 3.0).astype(np.float32)
+    P = synth.item_embeddings(41, "p", npool)
+    P[70_000:70_010] = P[123]                                   # exact duplicates -> exact ties
+    eng = Engine(torch.device("cuda", 0))
+    Qd, Pd = cu(Q), cu(P)
+    idx, dist = eng.l2_topk(Qd, Pd, k)
+    parts = [eng.l2_topk(Qd, Pd[s:s + 12_500], k, index_base=s) for s in range(0, npool, 12_500)]
+    mi, md = topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    assert torch.equal(mi, idx) and torch.equal(md, dist)
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    assert (np.diff(dist, axis=1) >= 0).all()
+    tie = dist[:, 1:] == dist[:, :-1]
+    assert (np.diff(idx, axis=1)[tie] > 0).all()
+    oi, od = O.l2_topk(Q[:64], P, k)                            # oracle on a 64-query subset
+    assert rel_err(dist[:64], od) < 1e-6
+    mism = idx[:64] != oi
+    # an index may differ from the oracle only where the two candidates' distances tie within fp32 rounding
+    assert mism.mean() < 1e-3 and np.allclose(dist[:64][mism], od[mism], rtol=3e-7, atol=0)
+
+
+def test_fitb_full_size_cfg3(model):
+    from outfitx_amd.engine import fitb_argmin
+    CIR = tasks()[1]
+    B = 1024
+    emb, mask = synth.outfit_batch(51, B, 16, 8)
+    txt = synth.unit_rows(51, "t", B, 512)
+    cand = synth.item_embeddings(51, "cand", B, 4)
+    with torch.no_grad():
+        y = model(task=CIR, outfit_embedding=cu(emb), outfit_mask=cu(mask), target_item_text_embedding=cu(txt))
+    idx, d = fitb_argmin(y, cu(cand), return_dist=True)
+    oi, od = O.fitb_argmin(y.cpu().numpy(), cand)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert rel_err(d.cpu().numpy(), od) < 1e-6
+
+
+def test_errors_are_python_exceptions(model):
+    CP = tasks()[0]
+    with pytest.raises(KeyError):
+        model(task=int)
+    with pytest.raises(Exception):
+        model.cpu()(task=CP, outfit_embedding=torch.zeros(1, 16, 1024), outfit_mask=torch.zeros(1, 16, dtype=torch.bool))
+    model.cuda()
