@@ -94,8 +94,9 @@ def test_gemm_x3_concat_is_fp32_grade():
     A = g.standard_normal((M, K), dtype=np.float32); W = (g.standard_normal((N, K), dtype=np.float32) / 32)
     A3 = torch.empty(M, 3 * K, dtype=torch.bfloat16, device="cuda"); W3 = torch.empty(N, 3 * K, dtype=torch.bfloat16, device="cuda")
     lib = L.load()
-    L.check(lib.ofx_convert(dev(A).data_ptr(), A3.data_ptr(), M, K, 1, 1, stream()))
-    L.check(lib.ofx_convert(dev(W).data_ptr(), W3.data_ptr(), N, K, 2, 1, stream()))
+    Ad, Wd = dev(A), dev(W)
+    L.check(lib.ofx_convert(Ad.data_ptr(), A3.data_ptr(), M, K, 1, 1, stream()))
+    L.check(lib.ofx_convert(Wd.data_ptr(), W3.data_ptr(), N, K, 2, 1, stream()))
     out = torch.empty(M, N, device="cuda")
     L.check(lib.ofx_gemm(A3.data_ptr(), W3.data_ptr(), out.data_ptr(), None, None, M, N, 3 * K, 3 * K, N, 0, 0, 0, 1, stream()))
     want = A.astype(np.float64) @ W.astype(np.float64).T
@@ -127,7 +128,8 @@ def test_layernorm(D, kind):
     want = O.layer_norm(x[idx].astype(np.float64), gamma.astype(np.float64), beta.astype(np.float64))
     ld = D * (3 if kind == 2 else 1)
     y = torch.zeros(rows, ld, dtype=torch.float32 if kind == 0 else torch.bfloat16, device="cuda")
-    L.check(L.load().ofx_layernorm(dev(x).data_ptr(), dev(idx).data_ptr(), dev(gamma).data_ptr(), dev(beta).data_ptr(), y.data_ptr(),
+    xd, id_, gd, bd = dev(x), dev(idx), dev(gamma), dev(beta)      # keep alive: the launch is asynchronous
+    L.check(L.load().ofx_layernorm(xd.data_ptr(), id_.data_ptr(), gd.data_ptr(), bd.data_ptr(), y.data_ptr(),
                                    rows, D, ld, kind, 1, 1e-5, stream()))
     y = y.float().cpu().numpy()
     if kind == 0:
@@ -157,7 +159,8 @@ def test_attention_mfma(dt, S, H, causal, masked):
         for i in range(n):
             att[i, g.integers(1, S + 1):] = 0
     out = torch.zeros(n * S, W, dtype=qkv.dtype, device="cuda")
-    L.check(L.load().ofx_attention(qkv.data_ptr(), out.data_ptr(), dev(att).data_ptr() if masked else None, n, S, H, 3 * W, W, W, 2 * W,
+    attd = dev(att)
+    L.check(L.load().ofx_attention(qkv.data_ptr(), out.data_ptr(), attd.data_ptr() if masked else None, n, S, H, 3 * W, W, W, 2 * W,
                                    77, causal, 0.125, DT[dt], stream()))
     x = qkv.double().cpu().numpy().reshape(n, S, 3, H, 64).transpose(2, 0, 3, 1, 4)
     dead = np.zeros((n, 1, S, S), bool)
@@ -179,7 +182,8 @@ def test_set_attention(kind, row0):
     qkv = g.standard_normal((rows, 3 * D), dtype=np.float32)
     ld = D * (3 if kind == 2 else 1)
     out = torch.zeros(rows, ld, dtype=torch.float32 if kind == 0 else torch.bfloat16, device="cuda")
-    L.check(L.load().ofx_set_attention(dev(qkv).data_ptr(), out.data_ptr(), dev(cu).data_ptr(), len(lens), H, D, ld, kind, 32, row0, 0.125, 1, stream()))
+    qd, cd = dev(qkv), dev(cu)
+    L.check(L.load().ofx_set_attention(qd.data_ptr(), out.data_ptr(), cd.data_ptr(), len(lens), H, D, ld, kind, 32, row0, 0.125, 1, stream()))
     out = out.float().cpu().numpy()
     for b, n in enumerate(lens):
         x = qkv[cu[b]:cu[b + 1]].astype(np.float64).reshape(n, 3, H, 64).transpose(1, 2, 0, 3)
