@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Headline benchmark: outfits/sec, CP forward with CLIP ViT-B/32 image + text encode
+(BASELINE.json configs[1]: 256 outfits x 8 items per GPU, 224^2, bf16) on N MI355X.
+
+One "step" = one pass of the hot path over one batch: item encoder (ViT-B/32 + text tower + concat
+fuser) -> 6-layer outfit transformer -> CP head, through the drop-in `src.models.OutfitX` API.
+Inputs are synthetic and already resident in HBM when the timed region starts (token ids stay on
+the host like the reference's tokenizer output: 1 MB, copied inside the step).  Weak scaling: each
+rank scores its own 256 outfits; the forward has no data-path collective.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+warnings.simplefilter("ignore")
+
+from outfitx_amd import synth  # noqa: E402
+
+W_SEED = 7
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+# ---- algorithmic (useful, pad-free) FLOPs, SURVEY.md §8(d) -------------------------------------
+VIT_GEMM = 12 * 50 * 14_155_776 + 49 * 2 * 3072 * 768 + 2 * 768 * 512        # per image, GEMM kernel only
+VIT_ATTN = 12 * 4 * 50 * 50 * 768
+
+
+def txt_gemm(T): return 12 * T * 6_291_456 + 2 * 512 * 512
+def txt_attn(T): return 12 * 4 * T * T * 512
+def ot_gemm(n): return 6 * (1 + n) * 16_678_912 + 2 * 1024 * 0
+def ot_attn(n): return 6 * 4 * (1 + n) ** 2 * 1024 + 2 * 1024
+
+
+def cpu_baseline(px, ids, att, mask, n_outfits, items):
+    """The numpy oracle (a port of the reference's CPU path, oracle/np_oracle.py) on a bounded sample of
+    the same workload, executed the way the reference executes it: texts padded to 64 tokens, fp32."""
+    from oracle import np_oracle as O
+    Wt = synth.outfit_transformer_weights(W_SEED)
+    Wv = synth.vision_weights(W_SEED)
+    Wx = synth.text_weights(W_SEED)
+    t0 = time.perf_counter()
+    emb = O.item_encoder(px[:n_outfits], ids[:n_outfits], att[:n_outfits], Wv, Wx)
+    logits = O.cp_forward(emb, mask[:n_outfits], Wt)
+    dt = time.perf_counter() - t0
+    return logits, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--outfits", type=int, default=256, help="outfits per GPU per step")
+    ap.add_argument("--items", type=int, default=8)
+    ap.add_argument("--precision", default="bf16x3", help="outfit transformer MFMA operand format")
+    ap.add_argument("--tower-precision", default="bf16", help="CLIP towers MFMA operand format (bf16|f16)")
+    ap.add_argument("--cpu-outfits", type=int, default=2, help="sample size of the CPU baseline (0 = skip)")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from src.models import OutfitX
+    from src.models.configs import ItemEncoderConfig, OutfitXConfig
+    from src.models.datatypes import OutfitCompatibilityPredictionTask as CP
+    from outfitx_amd import _lib as L
+
+    model = OutfitX(OutfitXConfig(item_encoder=ItemEncoderConfig(type="clip")), precision=a.precision,
+                    tower_precision=a.tower_precision)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.full_state_dict(W_SEED).items()}, strict=True)
+    model = model.to(dev).eval()
+
+    B, n = a.outfits, a.items
+    seed = 1236 + rank
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    u8 = torch.randint(0, 256, (B, n, 3, 224, 224), generator=g, device=dev, dtype=torch.uint8)
+    mean = torch.tensor(synth.CLIP_MEAN, device=dev).view(1, 1, 3, 1, 1); std = torch.tensor(synth.CLIP_STD, device=dev).view(1, 1, 3, 1, 1)
+    px = ((u8.float() * (1 / 255.0) - mean) / std).contiguous()          # [B,n,3,224,224] fp32, host preprocessing excluded
+    del u8
+    ids_np, att_np = synth.token_batch(seed, B * n, 64, 8)              # BOS + 6 words + EOS, padded to 64
+    texts = {"input_ids": torch.from_numpy(ids_np).view(B, n, 64), "attention_mask": torch.from_numpy(att_np).view(B, n, 64)}
+    mask = torch.zeros(B, n, dtype=torch.bool, device=dev)
+
+    def step():
+        with torch.no_grad():
+            return model(task=CP, outfit_embedding=None, outfit_mask=mask, encoder_input_dict={"images": px, "texts": texts})
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        out = step()
+    fence()
+    lib = L.load()
+    lib.ofx_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ms, fl, cnt = (C.c_double * 4)(), (C.c_double * 4)(), (C.c_longlong * 4)()
+    L.check(lib.ofx_profile_read(ms, fl, cnt), "ofx_profile_read")
+    lib.ofx_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        T_real = 8
+        alg_gemm_outfit = n * (VIT_GEMM + txt_gemm(T_real)) + ot_gemm(n)
+        alg_all_outfit = alg_gemm_outfit + n * (VIT_ATTN + txt_attn(T_real)) + ot_attn(n)
+        gemm_ms, gemm_launches = ms[0], int(cnt[0])
+        achieved = alg_gemm_outfit * B * a.steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        res = {
+            "metric": "outfits/sec CP forward (8-item sets, 224^2, bf16)",
+            "value": round(world * B * a.steps / elapsed, 2),
+            "unit": "outfits/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if a.tower_precision == "bf16" else a.tower_precision,
+            "data": "synthetic (seeded uniform-uint8 images after CLIP normalise, 8-token ids, random-init weights of the reference architecture)",
+            "config": {"workload": "BASELINE configs[1]: CP forward with CLIP ViT-B/32 image+text encode, 256 outfits x 8 items per GPU, 224^2",
+                       "outfits_per_gpu": B, "items": n, "parallelism": f"dp{world} (batch sharded, no data-path collective)",
+                       "tower_precision": a.tower_precision, "outfit_precision": a.precision},
+            "roofline": {"bound": "mfma", "kernel": "gemm_128x128_kernel (all dense contractions of the step)",
+                         "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": gemm_launches // max(a.steps, 1),
+                         "avg_launch_us": round(gemm_ms * 1e3 / max(gemm_launches, 1), 2),
+                         "algorithmic_gflop_per_outfit": round(alg_gemm_outfit / 1e9, 3)},
+            "step_breakdown_ms": {"gemm": round(ms[0] / a.steps, 3), "norm_embed": round(ms[1] / a.steps, 3),
+                                  "attention": round(ms[2] / a.steps, 3), "other": round(ms[3] / a.steps, 3)},
+            "whole_step_tflops_useful": round(alg_all_outfit * world * B * a.steps / elapsed / 1e12, 2),
+        }
+        if a.cpu_outfits > 0:
+            k = min(a.cpu_outfits, B)
+            ref, dt = cpu_baseline(px[:k].cpu().numpy(), texts["input_ids"][:k].numpy(), texts["attention_mask"][:k].numpy(),
+                                   mask[:k].cpu().numpy(), k, n)
+            got = out[:k].float().cpu().numpy()
+            res["cpu_baseline"] = {"value": round(k / dt, 4), "unit": "outfits/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
+                                   "sample": f"{k} outfits x {n} items of the same batch ({k * n} images 224^2, {k * n} texts padded to 64 tokens as the "
+                                             f"reference feeds them), fp32 numpy oracle (BLAS threads = all cores), {dt:.1f} s"}
+            res["parity_rel_err_vs_oracle"] = float(np.abs(got - ref).max() / np.abs(ref).max())
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

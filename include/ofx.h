@@ -123,6 +123,13 @@ int ofx_l2_topk(ofx_handle* h, const float* Q, const float* P, int nq, int np, i
 int ofx_topk_merge(const int64_t* idx_in, const float* dist_in, int parts, int nq, int k, int64_t* idx, float* dist,
                    ofx_stream stream);
 
+/* ------------------------------------------------------------------ profiling --------------- */
+/* HIP-event timing of every launch, by category {0 GEMM, 1 norm/embed, 2 attention, 3 other}.
+ * enable(1) clears and starts recording; read() waits for the events (host sync) and returns the
+ * summed milliseconds, executed FLOPs (GEMM only) and launch counts; arrays of 4. */
+void ofx_profile_enable(int on);
+int ofx_profile_read(double* ms, double* flops, long long* launches);
+
 /* ------------------------------------------------------------------ op level (tests) ------- */
 int ofx_gemm(const void* A, const void* W, void* C, const float* bias, const float* resid, int M, int N, int K,
              int lda, int ldc, int ldr, int act, int out_kind, int op_dtype, ofx_stream stream);

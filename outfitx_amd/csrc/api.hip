@@ -19,6 +19,41 @@ void ofx_set_error(const char* fmt, ...) {
 extern "C" const char* ofx_last_error(void) { return g_err; }
 extern "C" int ofx_abi_version(void) { return OFX_ABI_VERSION; }
 
+// ------------------------------------------------------------------------------- profiling
+bool g_ofx_prof_on = false;
+namespace {
+struct ProfRec { hipEvent_t a, b; int cat; double flops; };
+std::vector<ProfRec> g_prof;
+size_t g_prof_used = 0;
+}
+void ofx_prof_begin(int cat, hipStream_t s, double flops) {
+    if (g_prof_used == g_prof.size()) {
+        ProfRec r; r.cat = cat; r.flops = 0;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+        g_prof.push_back(r);
+    }
+    ProfRec& r = g_prof[g_prof_used];
+    r.cat = cat; r.flops = flops;
+    (void)hipEventRecord(r.a, s);
+}
+void ofx_prof_end(hipStream_t s) {
+    if (g_prof_used < g_prof.size()) { (void)hipEventRecord(g_prof[g_prof_used].b, s); ++g_prof_used; }
+}
+extern "C" void ofx_profile_enable(int on) { g_ofx_prof_on = on != 0; g_prof_used = 0; }
+// Waits for the recorded events (host sync: call outside the timed region) and sums per category.
+extern "C" int ofx_profile_read(double* ms, double* flops, long long* launches) {
+    for (int c = 0; c < PROF_NCAT; ++c) { ms[c] = 0; flops[c] = 0; launches[c] = 0; }
+    for (size_t i = 0; i < g_prof_used; ++i) {
+        ProfRec& r = g_prof[i];
+        OFX_HIP(hipEventSynchronize(r.b));
+        float t = 0;
+        OFX_HIP(hipEventElapsedTime(&t, r.a, r.b));
+        ms[r.cat] += t; flops[r.cat] += r.flops; launches[r.cat] += 1;
+    }
+    g_prof_used = 0;
+    return OFX_OK;
+}
+
 int ofx_launch_fitb(const float* y, const float* cand, int B, int C, int D, int64_t* idx, float* dist, hipStream_t s);
 int ofx_launch_l2_topk(const float* Q, const float* P, int nq, int np, int D, int k, int64_t index_base, int64_t* idx,
                        float* dist, void* ws, size_t ws_bytes, hipStream_t s);

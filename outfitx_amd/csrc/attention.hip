@@ -258,6 +258,7 @@ int ofx_launch_attention_mfma(const AttnArgs& g, int op_dtype, hipStream_t s) {
     k.n_head = g.n_head; k.ld = g.ld; k.ldo = g.ldo; k.k_off = g.k_off; k.v_off = g.v_off; k.mask_ld = g.mask_ld;
     k.causal = g.causal; k.scale = g.scale;
     const int grid = (g.nseq * g.n_head + 3) / 4;
+    ProfScope prof(PROF_ATTN, s);
     if (op_dtype == OFX_F16) hipLaunchKernelGGL(attention_mfma_kernel<f16_t>, dim3(grid), dim3(256), 0, s, k);
     else hipLaunchKernelGGL(attention_mfma_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, k);
     OFX_LAUNCH_CHECK();
@@ -272,6 +273,7 @@ int ofx_launch_set_attention(const SetAttnArgs& g, int op_dtype, hipStream_t s) 
     k.qkv = g.qkv; k.out = (char*)g.out; k.cu = g.cu_seqlens; k.nseq = g.nseq; k.n_head = g.n_head; k.D = g.D; k.ldo = g.ldo;
     k.out_kind = g.out_kind; k.only_row0 = g.only_row0; k.scale = g.scale;
     const int grid = g.nseq * g.n_head;
+    ProfScope prof(PROF_ATTN, s);
 #define SA(T, N) hipLaunchKernelGGL((set_attention_kernel<T, N>), dim3(grid), dim3(64), 0, s, k)
     if (op_dtype == OFX_F16) { if (g.max_len <= 20) SA(f16_t, 20); else SA(f16_t, 32); }
     else { if (g.max_len <= 20) SA(bf16_t, 20); else SA(bf16_t, 32); }

@@ -210,6 +210,7 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
         attr_set = true;
     }
+    ProfScope prof(PROF_GEMM, s, 2.0 * g.M * g.N * g.K);
     if (op_dtype == OFX_BF16)
         hipLaunchKernelGGL(gemm_128x128_kernel<bf16_t>, dim3(k.nwg), dim3(256), GEMM_LDS_BYTES, s, k);
     else

@@ -68,6 +68,7 @@ int ofx_launch_layernorm_dev(const LnArgs& a, const int* rows_dev, int op_dtype,
     OFX_REQUIRE(a.ldy % 4 == 0 && a.ldy >= (a.out_kind == 2 ? 3 * a.D : a.D), OFX_ESHAPE, "layernorm: bad ldy=%d", a.ldy);
     int grid = (a.rows + 3) / 4;
     if (grid > 8192) grid = 8192;
+    ProfScope prof(PROF_NORM, s);
 #define LN_CASE(T, N) hipLaunchKernelGGL((layernorm_kernel<T, N>), dim3(grid), dim3(256), 0, s, a, rows_dev)
     if (op_dtype == OFX_F16) {
         if (a.D == 512) LN_CASE(f16_t, 2); else if (a.D == 768) LN_CASE(f16_t, 3); else LN_CASE(f16_t, 4);
@@ -327,6 +328,7 @@ int ofx_launch_patchify(const float* px, void* out, int N, int img, int patch, i
     size_t total = (size_t)N * 3 * img * img / 8;
     int grid = (int)((total + 255) / 256);
     if (grid > 32768) grid = 32768;
+    ProfScope prof(PROF_OTHER, s);
     if (op_dtype == OFX_F16) hipLaunchKernelGGL(patchify_kernel<f16_t>, dim3(grid), dim3(256), 0, s, px, (f16_t*)out, N, img, patch);
     else hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, px, (bf16_t*)out, N, img, patch);
     OFX_LAUNCH_CHECK();
@@ -336,6 +338,7 @@ int ofx_launch_vit_embed_ln(const float* patch_out, const float* cls, const floa
                             float* x, int N, int S, int D, float eps, hipStream_t s) {
     OFX_REQUIRE(D == 768 || D == 512 || D == 1024, OFX_ESHAPE, "vit_embed_ln: D=%d", D);
     const int grid = rows_grid(N * S);
+    ProfScope prof(PROF_NORM, s);
     if (D == 768) hipLaunchKernelGGL(vit_embed_ln_kernel<3>, dim3(grid), dim3(256), 0, s, patch_out, cls, pos, g, b, x, N, S, eps);
     else if (D == 512) hipLaunchKernelGGL(vit_embed_ln_kernel<2>, dim3(grid), dim3(256), 0, s, patch_out, cls, pos, g, b, x, N, S, eps);
     else hipLaunchKernelGGL(vit_embed_ln_kernel<4>, dim3(grid), dim3(256), 0, s, patch_out, cls, pos, g, b, x, N, S, eps);

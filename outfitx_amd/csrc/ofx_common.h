@@ -96,6 +96,17 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- optional HIP-event profiling of launches by category (bench.py's live roofline) ----
+enum { PROF_GEMM = 0, PROF_NORM = 1, PROF_ATTN = 2, PROF_OTHER = 3, PROF_NCAT = 4 };
+extern bool g_ofx_prof_on;
+void ofx_prof_begin(int cat, hipStream_t s, double flops);
+void ofx_prof_end(hipStream_t s);
+struct ProfScope {
+    hipStream_t s; bool on;
+    ProfScope(int cat, hipStream_t st, double flops = 0.0) : s(st), on(g_ofx_prof_on) { if (on) ofx_prof_begin(cat, s, flops); }
+    ~ProfScope() { if (on) ofx_prof_end(s); }
+};
+
 // ---- internal launchers (defined in the .hip files, used by api.hip) ----
 struct GemmArgs {
     const void* A;      // [M, lda] operand type, K-contiguous
