@@ -1,0 +1,63 @@
+"""Multi-GPU layout of the scoring path: one process per GPU (torchrun), `torch.distributed` with
+backend 'nccl' (= RCCL over xGMI on ROCm) or 'gloo' (CPU tests).
+
+* CP / FITB / item encode: outfits are independent -> the batch is split across ranks, weights are
+  replicated, and the forward needs NO collective.  `shard_range` gives a rank's
+  slice; `gather_scores` is the optional final all-gather of [B/N] logits (4 KB).
+* CIR retrieval (BASELINE config 4): the POOL is row-sharded.  Every rank scores all queries
+  against its shard (fp32-exact distances + local top-k), then ONE all-gather of the per-shard
+  (dist, global index) candidate lists — nq*k*12 B per rank, 600 KB at 1000x50, latency-bound on
+  the fully connected xGMI mesh — and a local merge with a deterministic tie-break (smaller global
+  index).  This step has no reference call site: the reference scores CIR on one GPU
+  (complementary_item_retrieval_trainer.py:240-249); results are identical to the unsharded call.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced [lo, hi) of n units for `rank` (first n % world ranks get one more)."""
+    q, r = divmod(n, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def gather_scores(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """All-gather per-rank score slices (possibly uneven) back into batch order."""
+    world = dist.get_world_size(group)
+    sizes = [shard_range(n_total, r, world) for r in range(world)]
+    mx = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad, group=group)
+    return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(out, sizes)], 0)
+
+
+def sharded_topk(queries: torch.Tensor, pool_shard: torch.Tensor, k: int, shard_base: int,
+                 local_topk: Callable, merge: Callable, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """CIR scoring with a row-sharded pool.
+    local_topk(Q, P, k, index_base) -> (idx [nq,k] int64 global, dist [nq,k] f32)   (Engine.l2_topk on the GPU)
+    merge(idx_parts [W,nq,k], dist_parts [W,nq,k]) -> (idx [nq,k], dist [nq,k])      (engine.topk_merge on the GPU)
+    Every rank returns the same global top-k."""
+    world = dist.get_world_size(group)
+    idx, dst = local_topk(queries, pool_shard, k, shard_base)
+    if world == 1:
+        return idx, dst
+    idx_all = torch.empty((world,) + tuple(idx.shape), dtype=idx.dtype, device=idx.device)
+    dst_all = torch.empty((world,) + tuple(dst.shape), dtype=dst.dtype, device=dst.device)
+    # list-of-views form: accepted by both RCCL and gloo (the payload is ~600 KB, latency-bound either way)
+    dist.all_gather([idx_all[r] for r in range(world)], idx.contiguous(), group=group)
+    dist.all_gather([dst_all[r] for r in range(world)], dst.contiguous(), group=group)
+    return merge(idx_all, dst_all)
+
+
+def cir_topk(engine, queries: torch.Tensor, pool_shard: torch.Tensor, k: int, shard_base: int, group=None):
+    """GPU path: Engine.l2_topk + RCCL all-gather + topk_merge kernel."""
+    from .engine import topk_merge
+    return sharded_topk(queries, pool_shard, k, shard_base,
+                        lambda Q, P, kk, base: engine.l2_topk(Q, P, kk, index_base=base), topk_merge, group)
