@@ -125,10 +125,13 @@ int ofx_topk_merge(const int64_t* idx_in, const float* dist_in, int parts, int n
 
 /* ------------------------------------------------------------------ profiling --------------- */
 /* HIP-event timing of every launch, by category {0 GEMM, 1 norm/embed, 2 attention, 3 other}.
- * enable(1) clears and starts recording; read() waits for the events (host sync) and returns the
+ * enable(mask) clears and starts recording the categories in the bit mask (1 GEMM | 2 norm | 4 attention | 8 other; 0 = off); read() waits for the events (host sync) and returns the
  * summed milliseconds, executed FLOPs (GEMM only) and launch counts; arrays of 4. */
 void ofx_profile_enable(int on);
 int ofx_profile_read(double* ms, double* flops, long long* launches);
+
+/* Process-wide tuning knobs (benchmarks only).  knob 0: GEMM rasterisation group (row panels per L2 group, default 8). */
+int ofx_tune(int knob, int value);
 
 /* ------------------------------------------------------------------ op level (tests) ------- */
 int ofx_gemm(const void* A, const void* W, void* C, const float* bias, const float* resid, int M, int N, int K,

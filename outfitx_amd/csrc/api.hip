@@ -21,6 +21,7 @@ extern "C" int ofx_abi_version(void) { return OFX_ABI_VERSION; }
 
 // ------------------------------------------------------------------------------- profiling
 bool g_ofx_prof_on = false;
+int g_ofx_prof_mask = 0xf;
 namespace {
 struct ProfRec { hipEvent_t a, b; int cat; double flops; };
 std::vector<ProfRec> g_prof;
@@ -39,7 +40,8 @@ void ofx_prof_begin(int cat, hipStream_t s, double flops) {
 void ofx_prof_end(hipStream_t s) {
     if (g_prof_used < g_prof.size()) { (void)hipEventRecord(g_prof[g_prof_used].b, s); ++g_prof_used; }
 }
-extern "C" void ofx_profile_enable(int on) { g_ofx_prof_on = on != 0; g_prof_used = 0; }
+// on: 0 off; otherwise a bit mask of categories to time (1 GEMM, 2 norm/embed, 4 attention, 8 other; 15 = all)
+extern "C" void ofx_profile_enable(int on) { g_ofx_prof_on = on != 0; g_ofx_prof_mask = on; g_prof_used = 0; }
 // Waits for the recorded events (host sync: call outside the timed region) and sums per category.
 extern "C" int ofx_profile_read(double* ms, double* flops, long long* launches) {
     for (int c = 0; c < PROF_NCAT; ++c) { ms[c] = 0; flops[c] = 0; launches[c] = 0; }
@@ -500,6 +502,17 @@ extern "C" int ofx_l2_topk(ofx_handle*, const float* Q, const float* P, int nq, 
 }
 extern "C" int ofx_topk_merge(const int64_t* idx_in, const float* dist_in, int parts, int nq, int k, int64_t* idx, float* dist, ofx_stream stream) {
     return ofx_launch_topk_merge(idx_in, dist_in, parts, nq, k, idx, dist, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------- tuning
+extern int g_gemm_group_m, g_gemm_ablate, g_gemm_kernel;
+extern "C" int ofx_tune(int knob, int value) {
+    switch (knob) {
+        case 0: g_gemm_group_m = value; return OFX_OK;
+        case 1: g_gemm_ablate = value; return OFX_OK;
+        case 2: g_gemm_kernel = value; return OFX_OK;
+        default: ofx_set_error("ofx_tune: unknown knob %d", knob); return OFX_EINVAL;
+    }
 }
 
 // ------------------------------------------------------------------------------------- op level

@@ -15,6 +15,8 @@
 //    whole 128/256-byte row segments with bias / activation / fp32 residual fused.
 //  * 1-D grid with an XCD-aware remap: the blocks that share an A row-panel are consecutive on
 //    one XCD so the panel is fetched into that XCD's L2 once.
+#include <type_traits>
+
 #include "ofx_common.h"
 
 namespace {
@@ -32,7 +34,7 @@ struct KArgs {
     const float* bias;
     const float* resid;
     const int* m_dev;   // optional device-side row count (pad-free varlen sets); M is then the upper bound
-    int M, N, K, lda, ldc, ldr, act, out_kind, tiles_n, nwg;
+    int M, N, K, lda, ldc, ldr, act, out_kind, tiles_n, tiles_m, nwg, group_m;
 };
 
 __device__ __forceinline__ void glds16(const char* g, OFX_LDS char* l) {
@@ -82,7 +84,7 @@ __device__ __forceinline__ void epilogue(const KArgs& p, OFX_LDS float* ep, int 
     }
 }
 
-template <typename T>
+template <typename T, int ABL>   // ABL: 0 product kernel; 1 no LDS-DMA; 2 no MFMA; 3 no LDS fragment reads (diagnostics, wrong results)
 __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
     typedef typename OpT<T>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -98,7 +100,17 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
         const int nx = 8, q = p.nwg / nx, r = p.nwg % nx, x = bid % nx, i = bid / nx;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
     }
-    const int tm = bid / p.tiles_n, tn = bid % p.tiles_n;
+    // grouped rasterisation: consecutive blocks (= the blocks resident on one XCD at a time) cover
+    // group_m row panels x several column tiles, so BOTH the A panels and the W tiles they touch fit the XCD's 4 MiB L2
+    int tm, tn;
+    {
+        const int per_group = p.group_m * p.tiles_n;
+        const int gidx = bid / per_group, first = gidx * p.group_m;
+        const int gm = min(p.group_m, p.tiles_m - first);
+        const int r = bid - gidx * per_group;
+        tm = first + r % gm;
+        tn = r / gm;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     if (p.m_dev) {                                      // block-uniform: whole tiles past the live rows leave
         const int m_live = *p.m_dev;
@@ -122,6 +134,7 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
     const int a_dst = wave * 4 * 1024, w_dst = BM * BK * 2 + wave * 4 * 1024;
 
     auto issue = [&](int kt, int stage) {
+        if (ABL == 1) return;
         OFX_LDS char* base = lds + stage * STAGE_BYTES;
         const size_t koff = (size_t)kt * BK * 2;
 #pragma unroll
@@ -141,6 +154,7 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    v8 af[2][4], wf[2][4];
     const int nk = p.K / BK;
     issue(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -153,19 +167,27 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
         }
         __builtin_amdgcn_s_barrier();
         OFX_LDS char* base = lds + cur * STAGE_BYTES;
+        // all 16 fragment reads of the k-tile go out first; the MFMAs then wait on counted lgkmcnt
+        static_assert(true, "");
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int chk = ((ks * 4 + fq) ^ fsw) * 16;
-            v8 af[4], wf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *(OFX_LDS v8*)(base + a_frag + i * 16 * 128 + chk);
+            for (int j = 0; j < 4; ++j) if (ABL != 3 || kt == 0) wf[ks][j] = *(OFX_LDS v8*)(base + w_frag + j * 16 * 128 + chk);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wf[j] = *(OFX_LDS v8*)(base + w_frag + j * 16 * 128 + chk);
+            for (int i = 0; i < 4; ++i) if (ABL != 3 || kt == 0) af[ks][i] = *(OFX_LDS v8*)(base + a_frag + i * 16 * 128 + chk);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = OpT<T>::mfma16(wf[j], af[i], acc[i][j]);
-        }
+                for (int j = 0; j < 4; ++j) {
+                    if (ABL == 2) { asm volatile("" :: "v"(wf[ks][j]), "v"(af[ks][i])); }
+                    else acc[i][j] = OpT<T>::mfma16(wf[ks][j], af[ks][i], acc[i][j]);
+                }
+        __builtin_amdgcn_s_setprio(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
@@ -186,7 +208,230 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
     }
 }
 
+
+// ================================================================================================
+// v2: 256x256x64 tile, 512 threads = 8 waves (2 x 4), wave tile 128x64 = 8x4 MFMA tiles x 2 k-steps.
+// Half the LDS-fill bytes and two thirds of the LDS fragment reads per FLOP of the 128^2 kernel
+// (the ablation in DESIGN.md §4 shows the fill path, not the MFMA pipe, bounds that kernel).
+// Per k-tile: [vmcnt -> barrier -> 24 ds_read_b128 into registers -> barrier] frees the stage at
+// once, so the LDS-DMA of k-tile t+2 is issued before the 64 MFMAs of k-tile t and two k-tiles
+// (128 KiB per CU) stay in flight.  LDS: 2 stages x 64 KiB + 32 KiB epilogue staging = 160 KiB.
+constexpr int EPI2_BYTES_PER_WAVE = 16 * 64 * 4;       // 16 rows x 64 fp32, XOR-swizzled, no padding
+
+// Epilogue of the 128x64 wave tile: 8 passes of 16 rows through the wave's private LDS staging (XOR-swizzled
+// 16-B chunks), leaving as whole 256/128-byte row segments.  The fp32 residual of pass i+2 is requested
+// while pass i is written out (DEPTH passes = 8 KiB per wave in flight): with one block per CU nothing else hides it.
+template <typename T, int ACT>
+__device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x4 (&acc)[8][4], int gm0, int gn0, int lane) {
+    typedef typename OpT<T>::v4 v4;
+    constexpr int DEPTH = 2;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int chunk = lane & 15, rsub = lane >> 4;
+    const int gn = gn0 + chunk * 4;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias4 = *(const f32x4*)(p.bias + gn);
+    const bool has_res = p.resid != nullptr;
+    f32x4 res[DEPTH + 1][4];
+    auto fetch = [&](int pass, f32x4 (&dst)[4]) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int gm = gm0 + pass * 16 + it * 4 + rsub;
+            dst[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (has_res && gm < p.M) dst[it] = *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn);
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) fetch(d, res[d]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i + DEPTH < 8) fetch(i + DEPTH, res[(i + DEPTH) % (DEPTH + 1)]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(OFX_LDS f32x4*)(ep + fr * 256 + (((j * 4 + fq) ^ (fr & 7)) << 4)) = acc[i][j];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 4 + rsub;
+            const int gm = gm0 + i * 16 + row;
+            f32x4 v = *(OFX_LDS f32x4*)(ep + row * 256 + ((chunk ^ (row & 7)) << 4));
+            if (gm < p.M) {
+                v += bias4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (ACT == OFX_ACT_QUICK_GELU) v[e] = act_quick_gelu(v[e]);
+                    else if (ACT == OFX_ACT_GELU) v[e] = act_gelu(v[e]);
+                    else if (ACT == OFX_ACT_MISH) v[e] = act_mish(v[e]);
+                }
+                v += res[i % (DEPTH + 1)][it];
+                if (p.out_kind == 0) {
+                    *(f32x4*)(p.C + ((size_t)gm * p.ldc + gn) * 4) = v;
+                } else {
+                    v4 hi;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hi[e] = (T)v[e];
+                    T* crow = (T*)p.C + (size_t)gm * p.ldc + gn;
+                    *(v4*)crow = hi;
+                    if (p.out_kind == 2) {
+                        v4 lo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) lo[e] = (T)(v[e] - (float)hi[e]);
+                        *(v4*)(crow + p.N) = lo;
+                        *(v4*)(crow + 2 * p.N) = hi;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// WR x WC waves, wave tile 128 x 64, NST LDS stages.  <2,4,2> = 256x256 tile, 8 waves, one block per CU;
+// <2,2,1> = 256x128 tile, 4 waves, LDS is a single landing stage (the k-tile being multiplied lives in
+// registers), 64 KiB per block so TWO independent blocks share a CU and overlap each other's load phases.
+template <typename T, int WR, int WC, int NST>
+__global__ __launch_bounds__(64 * WR * WC, 2) void gemm_big_kernel(KArgs p) {
+    typedef typename OpT<T>::v8 v8;
+    constexpr int TM = WR * 128, TN = WC * 64, NW = WR * WC;
+    constexpr int STAGE = (TM + TN) * BK * 2;
+    constexpr int A_PER_WAVE = (TM / 8) / NW, W_PER_WAVE = (TN / 8) / NW, NLD = A_PER_WAVE + W_PER_WAVE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    OFX_LDS char* lds = (OFX_LDS char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC;
+
+    int bid = blockIdx.x;
+    {
+        const int nx = 8, q = p.nwg / nx, r = p.nwg % nx, x = bid % nx, i = bid / nx;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    int tm, tn;
+    {
+        const int per_group = p.group_m * p.tiles_n;
+        const int gidx = bid / per_group, first = gidx * p.group_m;
+        const int gm = min(p.group_m, p.tiles_m - first);
+        const int r = bid - gidx * per_group;
+        tm = first + r % gm;
+        tn = r / gm;
+    }
+    const int m0 = tm * TM, n0 = tn * TN;
+    if (p.m_dev) {
+        const int m_live = *p.m_dev;
+        p.M = m_live < p.M ? m_live : p.M;
+        if (m0 >= p.M) return;
+    }
+
+    // LDS-DMA: chunks of 1 KiB = 8 rows x 128 B, swizzle on the source address
+    const int lrow = lane >> 3, lchk = lane & 7;
+    // uniform 64-bit tile bases + 32-bit per-lane offsets (saddr form: keeps 12 address VGPRs instead of 24)
+    const char* a_base = p.A + (size_t)m0 * p.lda * 2;
+    const char* w_base = p.W + (size_t)n0 * p.K * 2;
+    unsigned a_off[A_PER_WAVE], w_off[W_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < A_PER_WAVE; ++i) {
+        const int row = (wave * A_PER_WAVE + i) * 8 + lrow;
+        const int rr = m0 + row < p.M ? row : p.M - 1 - m0;          // clamp rows past M onto the last live row
+        a_off[i] = ((unsigned)rr * p.lda + (lchk ^ ((row >> 1) & 7)) * 8) * 2;
+    }
+#pragma unroll
+    for (int i = 0; i < W_PER_WAVE; ++i) {
+        const int row = (wave * W_PER_WAVE + i) * 8 + lrow;
+        w_off[i] = ((unsigned)row * p.K + (lchk ^ ((row >> 1) & 7)) * 8) * 2;
+    }
+    const int a_dst = wave * A_PER_WAVE * 1024, w_dst = TM * BK * 2 + wave * W_PER_WAVE * 1024;
+    auto issue = [&](int kt, int stage) {
+        OFX_LDS char* base = lds + stage * STAGE;
+        const char* ak = a_base + (size_t)kt * BK * 2;
+        const char* wk = w_base + (size_t)kt * BK * 2;
+#pragma unroll
+        for (int i = 0; i < A_PER_WAVE; ++i) glds16(ak + a_off[i], base + a_dst + i * 1024);
+#pragma unroll
+        for (int i = 0; i < W_PER_WAVE; ++i) glds16(wk + w_off[i], base + w_dst + i * 1024);
+    };
+
+    const int fr = lane & 15, fq = lane >> 4, fsw = fr >> 1;
+    const int a_frag = (wr * 128 + fr) * 128;
+    const int w_frag = TM * BK * 2 + (wc * 64 + fr) * 128;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    issue(0, 0);
+    if (NST == 2) issue(nk > 1 ? 1 : 0, 1);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = NST == 2 ? (kt & 1) : 0;
+        // k-tile kt landed (this wave's pieces); with two stages k-tile kt+1 may stay in flight
+        if (NST == 2) {
+            if (NLD == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                       // ... and everybody else's
+        OFX_LDS char* base = lds + cur * STAGE;
+        v8 af[2][8], wf[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chk = ((ks * 4 + fq) ^ fsw) * 16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[ks][j] = *(OFX_LDS v8*)(base + w_frag + j * 16 * 128 + chk);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[ks][i] = *(OFX_LDS v8*)(base + a_frag + i * 16 * 128 + chk);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // every wave holds its fragments: the stage is free
+        // 64 MFMAs; the next k-tile's LDS-DMA goes out one piece per 5 MFMAs in program order, so the matrix
+        // pipe keeps running while the wave issues them.  No branch in the stream: past the end the prefetch
+        // is clamped to the last k-tile (a redundant fill of a stage nobody reads again).
+        OFX_LDS char* nbase = lds + cur * STAGE;
+        const int kn = kt + NST < nk ? kt + NST : nk - 1;
+        const char* ak = a_base + (size_t)kn * BK * 2;
+        const char* wk = w_base + (size_t)kn * BK * 2;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int m = 0; m < 64; ++m) {
+            if (m % 5 == 0 && m / 5 < NLD) {
+                const int q = m / 5;
+                if (q < A_PER_WAVE) glds16(ak + a_off[q], nbase + a_dst + q * 1024);
+                else glds16(wk + w_off[q - A_PER_WAVE], nbase + w_dst + (q - A_PER_WAVE) * 1024);
+            }
+            const int ks = m >> 5, i = (m >> 2) & 7, j = m & 3;
+            acc[i][j] = OpT<T>::mfma16(wf[ks][j], af[ks][i], acc[i][j]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the clamped tail prefetches before the wave can end
+
+    OFX_LDS char* ep = lds + NST * STAGE + wave * EPI2_BYTES_PER_WAVE;   // private staging, outside the stages
+    const int gm0 = m0 + wr * 128, gn0 = n0 + wc * 64;
+    switch (p.act) {
+        case OFX_ACT_QUICK_GELU: epilogue2<T, OFX_ACT_QUICK_GELU>(p, ep, acc, gm0, gn0, lane); break;
+        case OFX_ACT_GELU: epilogue2<T, OFX_ACT_GELU>(p, ep, acc, gm0, gn0, lane); break;
+        case OFX_ACT_MISH: epilogue2<T, OFX_ACT_MISH>(p, ep, acc, gm0, gn0, lane); break;
+        default: epilogue2<T, OFX_ACT_NONE>(p, ep, acc, gm0, gn0, lane); break;
+    }
+}
+
+template <typename T, int WR, int WC, int NST>
+static int launch_big(KArgs& k, int M, int N, hipStream_t s) {
+    constexpr int TM = WR * 128, TN = WC * 64, NW = WR * WC;
+    constexpr int LDSB = NST * (TM + TN) * BK * 2 + NW * EPI2_BYTES_PER_WAVE;
+    static bool attr = false;
+    if (!attr) {
+        OFX_HIP(hipFuncSetAttribute((const void*)gemm_big_kernel<T, WR, WC, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+        attr = true;
+    }
+    k.tiles_n = N / TN; k.tiles_m = (M + TM - 1) / TM; k.nwg = k.tiles_m * k.tiles_n;
+    hipLaunchKernelGGL((gemm_big_kernel<T, WR, WC, NST>), dim3(k.nwg), dim3(64 * NW), LDSB, s, k);
+    return OFX_OK;
+}
+
 }  // namespace
+
+int g_gemm_group_m = 0;   // 0 = adaptive
+int g_gemm_ablate = 0;    // diagnostics only (tools/gemm_bench.py)
+int g_gemm_kernel = 0;    // 0 auto, 1 force 128x128, 2 force 256x256 (8 waves, 2 stages), 3 force 256x128 (4 waves, register-resident k-tile)
 
 int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
     OFX_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, OFX_ESHAPE, "gemm: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
@@ -201,20 +446,41 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
     KArgs k;
     k.A = (const char*)g.A; k.W = (const char*)g.W; k.C = (char*)g.C; k.bias = g.bias; k.resid = g.resid; k.m_dev = g.m_dev;
     k.M = g.M; k.N = g.N; k.K = g.K; k.lda = g.lda; k.ldc = g.ldc; k.ldr = g.ldr; k.act = g.act; k.out_kind = g.out_kind;
-    k.tiles_n = g.N / BN;
-    const int tiles_m = (g.M + BM - 1) / BM;
-    k.nwg = tiles_m * k.tiles_n;
     static bool attr_set = false;
     if (!attr_set) {
-        OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-        OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+        OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<bf16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+        OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<f16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+        OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+        OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+        OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<bf16_t, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
         attr_set = true;
     }
+    // big tiles when they still fill the chip, else the 128^2 kernel
+    int kind = g_gemm_kernel;
+    if (kind == 0) {   // measured crossover points (tools/gemm_bench.py, profiles/r01_gemm_variants.txt)
+        const long t2 = (long)((g.M + 255) / 256) * (g.N / 256), t3 = (long)((g.M + 255) / 256) * (g.N / 128);
+        kind = (g.N % 256 == 0 && t2 >= 1024) ? 2 : (g.N % 128 == 0 && t3 >= 512) ? 3 : 1;
+    }
+    if (kind == 2 && g.N % 256) kind = 1;
     ProfScope prof(PROF_GEMM, s, 2.0 * g.M * g.N * g.K);
-    if (op_dtype == OFX_BF16)
-        hipLaunchKernelGGL(gemm_128x128_kernel<bf16_t>, dim3(k.nwg), dim3(256), GEMM_LDS_BYTES, s, k);
-    else
-        hipLaunchKernelGGL(gemm_128x128_kernel<f16_t>, dim3(k.nwg), dim3(256), GEMM_LDS_BYTES, s, k);
+    if (kind == 2 || kind == 3) {
+        k.group_m = g_gemm_group_m > 0 ? g_gemm_group_m : 4;
+        int rc;
+        if (kind == 2) rc = op_dtype == OFX_F16 ? launch_big<f16_t, 2, 4, 2>(k, g.M, g.N, s) : launch_big<bf16_t, 2, 4, 2>(k, g.M, g.N, s);
+        else rc = op_dtype == OFX_F16 ? launch_big<f16_t, 2, 2, 1>(k, g.M, g.N, s) : launch_big<bf16_t, 2, 2, 1>(k, g.M, g.N, s);
+        if (rc != OFX_OK) return rc;
+    } else {
+        k.tiles_n = g.N / BN; k.tiles_m = (g.M + BM - 1) / BM; k.nwg = k.tiles_m * k.tiles_n;
+        // row panels per L2 group: (group_m + 64/group_m) panels of 128 x K operands should fit ~3 MiB of the XCD's L2
+        int gm = g_gemm_group_m;
+        if (gm <= 0) { gm = (int)((3u << 20) / ((size_t)BM * g.K * 2) / 2); gm = gm < 1 ? 1 : (gm > 8 ? 8 : gm); }
+        k.group_m = gm;
+        if (op_dtype == OFX_F16) hipLaunchKernelGGL((gemm_128x128_kernel<f16_t, 0>), dim3(k.nwg), dim3(256), GEMM_LDS_BYTES, s, k);
+        else if (g_gemm_ablate == 1) hipLaunchKernelGGL((gemm_128x128_kernel<bf16_t, 1>), dim3(k.nwg), dim3(256), GEMM_LDS_BYTES, s, k);
+        else if (g_gemm_ablate == 2) hipLaunchKernelGGL((gemm_128x128_kernel<bf16_t, 2>), dim3(k.nwg), dim3(256), GEMM_LDS_BYTES, s, k);
+        else if (g_gemm_ablate == 3) hipLaunchKernelGGL((gemm_128x128_kernel<bf16_t, 3>), dim3(k.nwg), dim3(256), GEMM_LDS_BYTES, s, k);
+        else hipLaunchKernelGGL((gemm_128x128_kernel<bf16_t, 0>), dim3(k.nwg), dim3(256), GEMM_LDS_BYTES, s, k);
+    }
     OFX_LAUNCH_CHECK();
     return OFX_OK;
 }

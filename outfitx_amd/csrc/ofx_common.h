@@ -67,14 +67,15 @@ template <> struct OpT<f16_t> {
 };
 
 // ---- activations (fp32) ----
-__device__ __forceinline__ float act_quick_gelu(float u) { return u / (1.0f + __expf(-1.702f * u)); }
+// v_rcp_f32 (1 ulp) instead of an IEEE division: results feed a bf16/f16 operand or are compared at 1e-5
+__device__ __forceinline__ float act_quick_gelu(float u) { return u * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * u)); }
 __device__ __forceinline__ float act_gelu(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f)); }
 __device__ __forceinline__ float act_mish(float u) {
     // u * tanh(softplus(u)); softplus threshold 20 as torch.  tanh(log(1+e^u)) = ((1+e^u)^2-1)/((1+e^u)^2+1)
     if (u > 20.0f) return u;
     float e = __expf(u);
     float n = e * (e + 2.0f);
-    return u * (n / (n + 2.0f));
+    return u * (n * __builtin_amdgcn_rcpf(n + 2.0f));
 }
 __device__ __forceinline__ float apply_act(float u, int act) {
     switch (act) {
@@ -99,11 +100,12 @@ __device__ __forceinline__ float wave_max(float v) {
 // ---- optional HIP-event profiling of launches by category (bench.py's live roofline) ----
 enum { PROF_GEMM = 0, PROF_NORM = 1, PROF_ATTN = 2, PROF_OTHER = 3, PROF_NCAT = 4 };
 extern bool g_ofx_prof_on;
+extern int g_ofx_prof_mask;   // bit per category
 void ofx_prof_begin(int cat, hipStream_t s, double flops);
 void ofx_prof_end(hipStream_t s);
 struct ProfScope {
     hipStream_t s; bool on;
-    ProfScope(int cat, hipStream_t st, double flops = 0.0) : s(st), on(g_ofx_prof_on) { if (on) ofx_prof_begin(cat, s, flops); }
+    ProfScope(int cat, hipStream_t st, double flops = 0.0) : s(st), on(g_ofx_prof_on && ((g_ofx_prof_mask >> cat) & 1)) { if (on) ofx_prof_begin(cat, s, flops); }
     ~ProfScope() { if (on) ofx_prof_end(s); }
 };
 

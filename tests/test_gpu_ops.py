@@ -53,6 +53,32 @@ def test_gemm_plain(dt, M, N, K):
     assert rel_err(out.cpu().numpy(), want) < 2e-5
 
 
+@pytest.mark.parametrize("kern", [2, 3])
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K", [(1, 256, 64), (255, 256, 128), (257, 512, 768), (1000, 768, 3072), (5000, 256, 192)])
+def test_gemm_big_tile_kernels(kern, dt, M, N, K):
+    """The 256x256 (knob 2 = 2) and 256x128 (= 3) kernels forced on for shapes the dispatcher would give to the 128^2 one."""
+    lib = L.load()
+    g = np.random.default_rng(M + N + K)
+    A = to_op(g.standard_normal((M, K), dtype=np.float32), dt)
+    W = to_op(g.standard_normal((N, K), dtype=np.float32) / np.sqrt(K), dt)
+    bias = dev(g.standard_normal(N, dtype=np.float32))
+    x = dev(g.standard_normal((M, N), dtype=np.float32)); x0 = x.clone()
+    o3 = torch.zeros(M, 3 * N, dtype=A.dtype, device="cuda")
+    lib.ofx_tune(2, kern)
+    try:
+        L.check(lib.ofx_gemm(A.data_ptr(), W.data_ptr(), x.data_ptr(), bias.data_ptr(), x.data_ptr(), M, N, K, K, N, N, 3, 0, DT[dt], stream()))
+        L.check(lib.ofx_gemm(A.data_ptr(), W.data_ptr(), o3.data_ptr(), None, None, M, N, K, K, 3 * N, 0, 0, 2, DT[dt], stream()))
+        torch.cuda.synchronize()
+    finally:
+        lib.ofx_tune(2, 0)
+    z = A.double().cpu().numpy() @ W.double().cpu().numpy().T
+    assert rel_err(x.cpu().numpy(), O.mish(z + bias.double().cpu().numpy()) + x0.double().cpu().numpy()) < 2e-5
+    o3 = o3.float().cpu().numpy()
+    assert np.array_equal(o3[:, :N], o3[:, 2 * N:])
+    assert rel_err(o3[:, :N] + o3[:, N:2 * N], z) < (3e-5 if dt == "bf16" else 1e-6 + 2e-6)
+
+
 @pytest.mark.parametrize("act", [0, 1, 2, 3])
 def test_gemm_epilogue_bias_act_residual(act):
     M, N, K = 333, 256, 512
