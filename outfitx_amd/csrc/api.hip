@@ -26,22 +26,33 @@ namespace {
 struct ProfRec { hipEvent_t a, b; int cat; double flops; };
 std::vector<ProfRec> g_prof;
 size_t g_prof_used = 0;
+bool g_prof_over = false;
 }
 void ofx_prof_begin(int cat, hipStream_t s, double flops) {
-    if (g_prof_used == g_prof.size()) {
-        ProfRec r; r.cat = cat; r.flops = 0;
-        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
-        g_prof.push_back(r);
+    if (g_prof_used == g_prof.size()) {              // pool exhausted: stop recording rather than stall the launch path
+        g_prof_over = true;
+        return;
     }
+    g_prof_over = false;
     ProfRec& r = g_prof[g_prof_used];
     r.cat = cat; r.flops = flops;
     (void)hipEventRecord(r.a, s);
 }
 void ofx_prof_end(hipStream_t s) {
-    if (g_prof_used < g_prof.size()) { (void)hipEventRecord(g_prof[g_prof_used].b, s); ++g_prof_used; }
+    if (!g_prof_over && g_prof_used < g_prof.size()) { (void)hipEventRecord(g_prof[g_prof_used].b, s); ++g_prof_used; }
 }
 // on: 0 off; otherwise a bit mask of categories to time (1 GEMM, 2 norm/embed, 4 attention, 8 other; 15 = all)
-extern "C" void ofx_profile_enable(int on) { g_ofx_prof_on = on != 0; g_ofx_prof_mask = on; g_prof_used = 0; }
+extern "C" void ofx_profile_enable(int on) {
+    // create the event pool up front (never inside a timed region): room for 4096 bracketed launches
+    while (on && g_prof.size() < 4096) {
+        ProfRec r; r.cat = 0; r.flops = 0;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) break;
+        g_prof.push_back(r);
+    }
+    if (on) g_prof_used = 0;               // turning recording ON clears; turning it off keeps the records for read()
+    g_ofx_prof_on = on != 0;
+    if (on) g_ofx_prof_mask = on;
+}
 // Waits for the recorded events (host sync: call outside the timed region) and sums per category.
 extern "C" int ofx_profile_read(double* ms, double* flops, long long* launches) {
     for (int c = 0; c < PROF_NCAT; ++c) { ms[c] = 0; flops[c] = 0; launches[c] = 0; }
@@ -281,7 +292,7 @@ extern "C" int ofx_pack_text_weights(ofx_handle* h, const void* const* P, int n,
 
 // ------------------------------------------------------------------------------------- workspace
 namespace {
-struct SetWs { int* cu; float* X; char* H; float* QKV; char* U; };
+struct SetWs { int* cu; float* X; char* H; float* QKV; char* U; char* HP; char* UP; };
 size_t carve_set(const ofx_handle* h, Bump& b, int B, int L, SetWs* w) {
     const size_t M = (size_t)B * (L + 1), D = h->d.d_model, km = h->ot_kmul, Fp = h->ot_ffn_pad;
     SetWs t;
@@ -290,10 +301,12 @@ size_t carve_set(const ofx_handle* h, Bump& b, int B, int L, SetWs* w) {
     t.H = b.take<char>(M * km * D * 2);
     t.QKV = b.take<float>(M * 3 * D);
     t.U = b.take<char>(M * km * Fp * 2);
+    t.HP = b.take<char>((size_t)B * km * D * 2);   // last layer: prefix rows only
+    t.UP = b.take<char>((size_t)B * km * Fp * 2);
     if (w) *w = t;
     return b.off;
 }
-struct ClipWs { float* X; char* H; char* QKV; char* U; int* idx; char* PL; float* E; };
+struct ClipWs { float* X; char* H; char* QKV; char* U; int* idx; char* PL; float* E; float* XP; char* HP; char* UP; };
 size_t carve_clip(Bump& b, size_t rows, size_t n, size_t W, size_t MLP, size_t PD, size_t u_min_bytes, size_t qkv_min_bytes, ClipWs* w) {
     ClipWs t;
     t.X = b.take<float>(rows * W);
@@ -303,6 +316,9 @@ size_t carve_clip(Bump& b, size_t rows, size_t n, size_t W, size_t MLP, size_t P
     t.idx = b.take<int>(n);
     t.PL = b.take<char>(n * W * 2);
     t.E = b.take<float>(n * PD);
+    t.XP = b.take<float>(n * W);          // last layer runs on the pooled rows only
+    t.HP = b.take<char>(n * W * 2);
+    t.UP = b.take<char>(n * MLP * 2);
     if (w) *w = t;
     return b.off;
 }
@@ -354,26 +370,33 @@ extern "C" int ofx_set_encoder_fwd(ofx_handle* h, const float* x, const uint8_t*
     const int* m_dev = w.cu + B;
     for (int l = 0; l < d.n_layers; ++l) {
         const OutfitLayer& Ly = h->ol[l];
+        const bool last = l + 1 == d.n_layers;          // only row 0 of every outfit feeds the heads (outfit_x.py:142,170)
         LnArgs ln{w.X, nullptr, Ly.g1, Ly.be1, w.H, M, D, km * D, okind, d.ln_eps};
         TRY(ofx_launch_layernorm_dev(ln, m_dev, dt, s));
         GemmArgs g1{}; g1.A = w.H; g1.W = Ly.w_in; g1.C = w.QKV; g1.bias = Ly.b_in; g1.resid = nullptr; g1.m_dev = m_dev;
         g1.M = M; g1.N = 3 * D; g1.K = km * D; g1.lda = km * D; g1.ldc = 3 * D; g1.ldr = 0; g1.act = OFX_ACT_NONE; g1.out_kind = OFX_OUT_F32;
         TRY(ofx_launch_gemm(g1, dt, s));
-        SetAttnArgs sa{w.QKV, w.H, w.cu, B, d.n_head, D, km * D, okind, L + 1, 0, 0.125f};
+        SetAttnArgs sa{w.QKV, w.H, w.cu, B, d.n_head, D, km * D, okind, L + 1, last ? 1 : 0, 0.125f};
         TRY(ofx_launch_set_attention(sa, dt, s));
-        GemmArgs g2{}; g2.A = w.H; g2.W = Ly.w_out; g2.C = w.X; g2.bias = Ly.b_out; g2.resid = w.X; g2.m_dev = m_dev;
-        g2.M = M; g2.N = D; g2.K = km * D; g2.lda = km * D; g2.ldc = D; g2.ldr = D; g2.act = OFX_ACT_NONE; g2.out_kind = OFX_OUT_F32;
+        float* X = w.X; char* H = w.H; char* U = w.U; int Ml = M; const int* md = m_dev;
+        if (last) {
+            TRY(ofx_launch_gather_rows(w.H, w.cu, w.HP, B, km * D * 2, km * D * 2, s));
+            TRY(ofx_launch_gather_rows(w.X, w.cu, out_row0, B, D * 4, D * 4, s));
+            X = out_row0; H = w.HP; U = w.UP; Ml = B; md = nullptr;
+        }
+        GemmArgs g2{}; g2.A = H; g2.W = Ly.w_out; g2.C = X; g2.bias = Ly.b_out; g2.resid = X; g2.m_dev = md;
+        g2.M = Ml; g2.N = D; g2.K = km * D; g2.lda = km * D; g2.ldc = D; g2.ldr = D; g2.act = OFX_ACT_NONE; g2.out_kind = OFX_OUT_F32;
         TRY(ofx_launch_gemm(g2, dt, s));
-        LnArgs ln2{w.X, nullptr, Ly.g2, Ly.be2, w.H, M, D, km * D, okind, d.ln_eps};
-        TRY(ofx_launch_layernorm_dev(ln2, m_dev, dt, s));
-        GemmArgs g3{}; g3.A = w.H; g3.W = Ly.w_1; g3.C = w.U; g3.bias = Ly.b_1; g3.resid = nullptr; g3.m_dev = m_dev;
-        g3.M = M; g3.N = Fp; g3.K = km * D; g3.lda = km * D; g3.ldc = km * Fp; g3.ldr = 0; g3.act = d.outfit_act; g3.out_kind = okind;
+        LnArgs ln2{X, nullptr, Ly.g2, Ly.be2, H, Ml, D, km * D, okind, d.ln_eps};
+        TRY(ofx_launch_layernorm_dev(ln2, md, dt, s));
+        GemmArgs g3{}; g3.A = H; g3.W = Ly.w_1; g3.C = U; g3.bias = Ly.b_1; g3.resid = nullptr; g3.m_dev = md;
+        g3.M = Ml; g3.N = Fp; g3.K = km * D; g3.lda = km * D; g3.ldc = km * Fp; g3.ldr = 0; g3.act = d.outfit_act; g3.out_kind = okind;
         TRY(ofx_launch_gemm(g3, dt, s));
-        GemmArgs g4{}; g4.A = w.U; g4.W = Ly.w_2; g4.C = w.X; g4.bias = Ly.b_2; g4.resid = w.X; g4.m_dev = m_dev;
-        g4.M = M; g4.N = D; g4.K = km * Fp; g4.lda = km * Fp; g4.ldc = D; g4.ldr = D; g4.act = OFX_ACT_NONE; g4.out_kind = OFX_OUT_F32;
+        GemmArgs g4{}; g4.A = U; g4.W = Ly.w_2; g4.C = X; g4.bias = Ly.b_2; g4.resid = X; g4.m_dev = md;
+        g4.M = Ml; g4.N = D; g4.K = km * Fp; g4.lda = km * Fp; g4.ldc = D; g4.ldr = D; g4.act = OFX_ACT_NONE; g4.out_kind = OFX_OUT_F32;
         TRY(ofx_launch_gemm(g4, dt, s));
     }
-    return ofx_launch_gather_row0(w.X, w.cu, out_row0, B, D, s);
+    return OFX_OK;
 }
 
 extern "C" int ofx_cp_head(ofx_handle* h, const float* row0, int B, float* logits, ofx_stream stream) {
@@ -401,28 +424,43 @@ extern "C" int ofx_cir_prefix(ofx_handle* h, const float* txt, int B, float* out
 }
 
 // ------------------------------------------------------------------------------------ CLIP towers
-static int clip_layers(const std::vector<ClipLayer>& Ls, const ClipWs& w, int rows, int nseq, int S, int W, int MLP,
-                       int heads, int act, float eps, int causal, const int64_t* key_mask, int mask_ld, int dt, hipStream_t s) {
-    for (const ClipLayer& L : Ls) {
-        LnArgs ln{w.X, nullptr, L.g1, L.be1, w.H, rows, W, W, OFX_OUT_OP, eps};
-        TRY(ofx_launch_layernorm(ln, dt, s));
-        GemmArgs g1{}; g1.A = w.H; g1.W = L.w_qkv; g1.C = w.QKV; g1.bias = L.b_qkv; g1.M = rows; g1.N = 3 * W; g1.K = W; g1.lda = W;
-        g1.ldc = 3 * W; g1.act = OFX_ACT_NONE; g1.out_kind = OFX_OUT_OP;
-        TRY(ofx_launch_gemm(g1, dt, s));
-        AttnArgs at{w.QKV, w.H, key_mask, nseq, S, heads, 3 * W, W, W, 2 * W, mask_ld, causal, 0.125f};
-        TRY(ofx_launch_attention_mfma(at, dt, s));
-        GemmArgs g2{}; g2.A = w.H; g2.W = L.w_o; g2.C = w.X; g2.bias = L.b_o; g2.resid = w.X; g2.M = rows; g2.N = W; g2.K = W; g2.lda = W;
-        g2.ldc = W; g2.ldr = W; g2.act = OFX_ACT_NONE; g2.out_kind = OFX_OUT_F32;
-        TRY(ofx_launch_gemm(g2, dt, s));
-        LnArgs ln2{w.X, nullptr, L.g2, L.be2, w.H, rows, W, W, OFX_OUT_OP, eps};
-        TRY(ofx_launch_layernorm(ln2, dt, s));
-        GemmArgs g3{}; g3.A = w.H; g3.W = L.w_fc1; g3.C = w.U; g3.bias = L.b_fc1; g3.M = rows; g3.N = MLP; g3.K = W; g3.lda = W;
-        g3.ldc = MLP; g3.act = act; g3.out_kind = OFX_OUT_OP;
-        TRY(ofx_launch_gemm(g3, dt, s));
-        GemmArgs g4{}; g4.A = w.U; g4.W = L.w_fc2; g4.C = w.X; g4.bias = L.b_fc2; g4.resid = w.X; g4.M = rows; g4.N = W; g4.K = MLP;
-        g4.lda = MLP; g4.ldc = W; g4.ldr = W; g4.act = OFX_ACT_NONE; g4.out_kind = OFX_OUT_F32;
-        TRY(ofx_launch_gemm(g4, dt, s));
+// One CLIP encoder layer on `rows` rows.  When `pool_idx` is given (last layer) everything after the attention
+// runs only on the n pooled rows (CLS / EOS): they are the only ones the tower's output depends on.
+static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, int S, int W, int MLP, int heads, int act,
+                      float eps, int causal, const int64_t* key_mask, int mask_ld, int dt, const int* pool_idx, hipStream_t s) {
+    LnArgs ln{w.X, nullptr, L.g1, L.be1, w.H, rows, W, W, OFX_OUT_OP, eps};
+    TRY(ofx_launch_layernorm(ln, dt, s));
+    GemmArgs g1{}; g1.A = w.H; g1.W = L.w_qkv; g1.C = w.QKV; g1.bias = L.b_qkv; g1.M = rows; g1.N = 3 * W; g1.K = W; g1.lda = W;
+    g1.ldc = 3 * W; g1.act = OFX_ACT_NONE; g1.out_kind = OFX_OUT_OP;
+    TRY(ofx_launch_gemm(g1, dt, s));
+    AttnArgs at{w.QKV, w.H, key_mask, nseq, S, heads, 3 * W, W, W, 2 * W, mask_ld, causal, 0.125f};
+    TRY(ofx_launch_attention_mfma(at, dt, s));
+    float* X = w.X; char* H = w.H; char* U = w.U; int M = rows;
+    if (pool_idx) {
+        TRY(ofx_launch_gather_rows(w.H, pool_idx, w.HP, nseq, W * 2, W * 2, s));
+        TRY(ofx_launch_gather_rows(w.X, pool_idx, w.XP, nseq, W * 4, W * 4, s));
+        X = w.XP; H = w.HP; U = w.UP; M = nseq;
     }
+    GemmArgs g2{}; g2.A = H; g2.W = L.w_o; g2.C = X; g2.bias = L.b_o; g2.resid = X; g2.M = M; g2.N = W; g2.K = W; g2.lda = W;
+    g2.ldc = W; g2.ldr = W; g2.act = OFX_ACT_NONE; g2.out_kind = OFX_OUT_F32;
+    TRY(ofx_launch_gemm(g2, dt, s));
+    LnArgs ln2{X, nullptr, L.g2, L.be2, H, M, W, W, OFX_OUT_OP, eps};
+    TRY(ofx_launch_layernorm(ln2, dt, s));
+    GemmArgs g3{}; g3.A = H; g3.W = L.w_fc1; g3.C = U; g3.bias = L.b_fc1; g3.M = M; g3.N = MLP; g3.K = W; g3.lda = W;
+    g3.ldc = MLP; g3.act = act; g3.out_kind = OFX_OUT_OP;
+    TRY(ofx_launch_gemm(g3, dt, s));
+    GemmArgs g4{}; g4.A = U; g4.W = L.w_fc2; g4.C = X; g4.bias = L.b_fc2; g4.resid = X; g4.M = M; g4.N = W; g4.K = MLP;
+    g4.lda = MLP; g4.ldc = W; g4.ldr = W; g4.act = OFX_ACT_NONE; g4.out_kind = OFX_OUT_F32;
+    return ofx_launch_gemm(g4, dt, s);
+}
+
+// All layers; the pooled rows end up compacted in w.XP [nseq, W].
+static int clip_layers(const std::vector<ClipLayer>& Ls, const ClipWs& w, int rows, int nseq, int S, int W, int MLP,
+                       int heads, int act, float eps, int causal, const int64_t* key_mask, int mask_ld, int dt,
+                       const int* pool_idx, hipStream_t s) {
+    for (size_t l = 0; l < Ls.size(); ++l)
+        TRY(clip_layer(Ls[l], w, rows, nseq, S, W, MLP, heads, act, eps, causal, key_mask, mask_ld, dt,
+                       l + 1 == Ls.size() ? pool_idx : nullptr, s));
     return OFX_OK;
 }
 
@@ -449,9 +487,9 @@ extern "C" int ofx_vit_b32_fwd(ofx_handle* h, const float* pixels, int N, float*
         gp.act = OFX_ACT_NONE; gp.out_kind = OFX_OUT_F32;
         TRY(ofx_launch_gemm(gp, dt, s));
         TRY(ofx_launch_vit_embed_ln((const float*)w.QKV, h->v_cls, h->v_pos, h->v_pre_g, h->v_pre_b, w.X, n, S, W, d.ln_eps, s));
-        TRY(clip_layers(h->vl, w, rows, n, S, W, d.vit_mlp, d.vit_heads, d.vit_act, d.ln_eps, 0, nullptr, 0, dt, s));
-        TRY(ofx_launch_iota_rows(w.idx, n, S, s));
-        LnArgs ln{w.X, w.idx, h->v_post_g, h->v_post_b, w.PL, n, W, W, OFX_OUT_OP, d.ln_eps};
+        TRY(ofx_launch_iota_rows(w.idx, n, S, s));                        // CLS rows
+        TRY(clip_layers(h->vl, w, rows, n, S, W, d.vit_mlp, d.vit_heads, d.vit_act, d.ln_eps, 0, nullptr, 0, dt, w.idx, s));
+        LnArgs ln{w.XP, nullptr, h->v_post_g, h->v_post_b, w.PL, n, W, W, OFX_OUT_OP, d.ln_eps};
         TRY(ofx_launch_layernorm(ln, dt, s));
         GemmArgs gj{}; gj.A = w.PL; gj.W = h->v_proj_w; gj.C = w.E; gj.M = n; gj.N = d.proj_dim; gj.K = W; gj.lda = W; gj.ldc = d.proj_dim;
         gj.act = OFX_ACT_NONE; gj.out_kind = OFX_OUT_F32;
@@ -481,9 +519,9 @@ extern "C" int ofx_clip_text_fwd(ofx_handle* h, const int64_t* ids, const int64_
     OFX_REQUIRE(need <= ws_bytes, OFX_EWORKSPACE, "clip_text_fwd: workspace %zu < %zu bytes", ws_bytes, need);
     const int W = d.txt_width, dt = h->tw_dtype, rows = N * Tc;
     TRY(ofx_launch_text_embed(ids, h->t_tok, h->t_pos, w.X, N, T, Tc, W, d.txt_vocab, s));
-    TRY(clip_layers(h->tl, w, rows, N, Tc, W, d.txt_mlp, d.txt_heads, d.txt_act, d.ln_eps, 1, attn_mask, T, dt, s));
-    TRY(ofx_launch_text_eos_index(ids, w.idx, N, T, Tc, d.txt_eos_id, s));
-    LnArgs ln{w.X, w.idx, h->t_fin_g, h->t_fin_b, w.PL, N, W, W, OFX_OUT_OP, d.ln_eps};
+    TRY(ofx_launch_text_eos_index(ids, w.idx, N, T, Tc, d.txt_eos_id, s));      // EOS rows
+    TRY(clip_layers(h->tl, w, rows, N, Tc, W, d.txt_mlp, d.txt_heads, d.txt_act, d.ln_eps, 1, attn_mask, T, dt, w.idx, s));
+    LnArgs ln{w.XP, nullptr, h->t_fin_g, h->t_fin_b, w.PL, N, W, W, OFX_OUT_OP, d.ln_eps};
     TRY(ofx_launch_layernorm(ln, dt, s));
     GemmArgs gj{}; gj.A = w.PL; gj.W = h->t_proj_w; gj.C = w.E; gj.M = N; gj.N = d.proj_dim; gj.K = W; gj.lda = W; gj.ldc = d.proj_dim;
     gj.act = OFX_ACT_NONE; gj.out_kind = OFX_OUT_F32;

@@ -24,13 +24,13 @@ struct AttnK {
 };
 
 constexpr int V_ROW = 160;                 // bytes per V row in LDS (64 x 2 B + 32 pad): tr-read conflict-free
-constexpr int V_TILE = 64 * V_ROW;
 
-template <typename T>
+template <typename T, int NT>   // NT = ceil(S / 16) in {1, 2, 4}: number of 16-row query / key tiles
 __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnK a) {
     typedef typename OpT<T>::v8 v8;
     typedef typename OpT<T>::v4 v4;
-    __shared__ __attribute__((aligned(16))) char smem[4 * V_TILE];
+    constexpr int KS = (NT + 1) / 2, VROWS = 32 * KS, VT = VROWS * V_ROW;
+    __shared__ __attribute__((aligned(16))) char smem[4 * VT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int npairs = a.nseq * a.n_head;
     const int pair_raw = blockIdx.x * 4 + wave;
@@ -42,9 +42,9 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnK a) {
     const int r16 = lane & 15, q4 = lane >> 4;
 
     // ---- V -> LDS, zero rows beyond S (0 * garbage must stay 0)
-    OFX_LDS char* vl = (OFX_LDS char*)smem + wave * V_TILE;
+    OFX_LDS char* vl = (OFX_LDS char*)smem + wave * VT;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < VROWS / 8; ++it) {
         const int key = it * 8 + (lane >> 3);
         v8 val;
 #pragma unroll
@@ -54,9 +54,9 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnK a) {
     }
 
     // ---- K (A operand) and Q (B operand) fragments straight from global, rows clamped
-    v8 kf[4][2], qf[4][2];
+    v8 kf[NT][2], qf[NT][2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NT; ++t) {
         int row = 16 * t + r16;
         row = row < S ? row : S - 1;
         const T* rp = base + (size_t)row * a.ld + q4 * 8;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnK a) {
     // ---- dead-key bits for this lane's 16 keys (key = 16t + 4q4 + r), independent of the query
     unsigned dead_bits = 0;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int key = 16 * t + 4 * q4 + r;
@@ -80,11 +80,11 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnK a) {
         }
 
     // ---- S^T[key][query]: st[t][u][r] = score(query 16u + r16, key 16t + 4q4 + r)
-    f32x4 st[4][4];
+    f32x4 st[NT][NT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NT; ++u) {
             f32x4 c = {0.f, 0.f, 0.f, 0.f};
             c = OpT<T>::mfma16(kf[t][0], qf[u][0], c);
             st[t][u] = OpT<T>::mfma16(kf[t][1], qf[u][1], c);
@@ -92,13 +92,13 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnK a) {
 
     // ---- wavefront softmax per query column; P written back normalised
     const float sc = a.scale * 1.4426950408889634f;        // exp(x) = exp2(x * log2 e)
-    v8 pf[4][2];
+    v8 pf[NT][KS];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NT; ++u) {
         const int query = 16 * u + r16;
         float m = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = 16 * t + 4 * q4 + r;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnK a) {
         if (m == -INFINITY) m = 0.f;
         float sum = 0.f;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float e = exp2f(st[t][u][r] - m);
@@ -124,18 +124,18 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnK a) {
         const float inv = 1.0f / sum;
         // P fragment of k-step ks: element j <-> key 16(2ks + (j>>2)) + 4q4 + (j&3)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pf[u][ks][j] = (T)(st[2 * ks + (j >> 2)][u][j & 3] * inv);
+            for (int j = 0; j < 8; ++j) pf[u][ks][j] = 2 * ks + (j >> 2) < NT ? (T)(st[(2 * ks + (j >> 2)) % NT][u][j & 3] * inv) : (T)0.0f;
     }
 
     // ---- O^T[d][query] = V^T · P^T; V fragments by transposed LDS reads (EXEC is all ones here)
-    f32x4 ot[4][4];
+    f32x4 ot[4][NT];
 #pragma unroll
     for (int nd = 0; nd < 4; ++nd) {
-        v8 vf[2];
+        v8 vf[KS];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 const int key0 = 32 * ks + 16 * h2 + 4 * q4;
@@ -146,17 +146,18 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnK a) {
                 for (int e = 0; e < 4; ++e) vf[ks][4 * h2 + e] = trv[e];
             }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NT; ++u) {
             f32x4 c = {0.f, 0.f, 0.f, 0.f};
-            c = OpT<T>::mfma16(vf[0], pf[u][0], c);
-            ot[nd][u] = OpT<T>::mfma16(vf[1], pf[u][1], c);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) c = OpT<T>::mfma16(vf[ks], pf[u][ks], c);
+            ot[nd][u] = c;
         }
     }
 
     // ---- store: ot[nd][u][r] = O[query 16u + r16][d 16nd + 4q4 + r]
     if (live) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NT; ++u) {
             const int query = 16 * u + r16;
             if (query < S) {
                 T* op = (T*)a.out + (size_t)(seq * S + query) * a.ldo + head * 64 + 4 * q4;
@@ -259,8 +260,11 @@ int ofx_launch_attention_mfma(const AttnArgs& g, int op_dtype, hipStream_t s) {
     k.causal = g.causal; k.scale = g.scale;
     const int grid = (g.nseq * g.n_head + 3) / 4;
     ProfScope prof(PROF_ATTN, s);
-    if (op_dtype == OFX_F16) hipLaunchKernelGGL(attention_mfma_kernel<f16_t>, dim3(grid), dim3(256), 0, s, k);
-    else hipLaunchKernelGGL(attention_mfma_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, k);
+#define AT(T, N) hipLaunchKernelGGL((attention_mfma_kernel<T, N>), dim3(grid), dim3(256), 0, s, k)
+    const int nt = g.seq_len <= 16 ? 1 : g.seq_len <= 32 ? 2 : 4;
+    if (op_dtype == OFX_F16) { if (nt == 1) AT(f16_t, 1); else if (nt == 2) AT(f16_t, 2); else AT(f16_t, 4); }
+    else { if (nt == 1) AT(bf16_t, 1); else if (nt == 2) AT(bf16_t, 2); else AT(bf16_t, 4); }
+#undef AT
     OFX_LAUNCH_CHECK();
     return OFX_OK;
 }

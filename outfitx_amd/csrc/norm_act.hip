@@ -289,6 +289,15 @@ __global__ __launch_bounds__(256) void set_build_kernel(const float* x, const ui
     }
 }
 
+// dst[r] = src[idx[r]] for rows of row_bytes (multiple of 16)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const char* src, const int* idx, char* dst, int rows, int row_bytes, int src_ld_bytes) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int r = blockIdx.x * 4 + w; r < rows; r += gridDim.x * 4) {
+        const char* sp = src + (size_t)idx[r] * src_ld_bytes;
+        for (int c = lane * 16; c < row_bytes; c += 64 * 16) *(f32x4*)(dst + (size_t)r * row_bytes + c) = *(const f32x4*)(sp + c);
+    }
+}
+
 // out[b] = X[cu[b]]
 __global__ __launch_bounds__(256) void gather_row0_kernel(const float* X, const int* cu, float* out, int B, int D) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -372,6 +381,13 @@ int ofx_launch_set_build(const float* x, const uint8_t* mask, const float* prefi
     OFX_REQUIRE(B > 0 && B <= 65536 * 16 && L >= 0 && D % 4 == 0, OFX_ESHAPE, "set_build: B=%d L=%d D=%d", B, L, D);
     hipLaunchKernelGGL(set_offsets_kernel, dim3(1), dim3(1024), 0, s, mask, cu, B, L);
     hipLaunchKernelGGL(set_build_kernel, dim3(rows_grid(B * (L + 1))), dim3(256), 0, s, x, mask, prefix, prefix_stride, cu, X, B, L, D);
+    OFX_LAUNCH_CHECK();
+    return OFX_OK;
+}
+int ofx_launch_gather_rows(const void* src, const int* idx, void* dst, int rows, int row_bytes, int src_ld_bytes, hipStream_t s) {
+    OFX_REQUIRE(row_bytes % 16 == 0 && src_ld_bytes % 16 == 0, OFX_ESHAPE, "gather_rows: row bytes must be multiples of 16");
+    ProfScope prof(PROF_OTHER, s);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(rows_grid(rows)), dim3(256), 0, s, (const char*)src, idx, (char*)dst, rows, row_bytes, src_ld_bytes);
     OFX_LAUNCH_CHECK();
     return OFX_OK;
 }

@@ -358,9 +358,18 @@ class CLIPTextEncoder(_TowerBase):
         return (pos + 1).tolist()
 
     @torch.no_grad()
-    def encode_into(self, texts, out: torch.Tensor, col: int, normalize: bool, tokenizer_kargs=None) -> int:
+    def prepare(self, texts, tokenizer_kargs=None):
+        """Host part of the text path (tokenise, EOS lengths, stage ids on the device).  ItemEncoder calls it before
+        the image tower is enqueued so no blocking copy sits in the middle of the step."""
         ids, att, b = self._ids(texts, tokenizer_kargs)
-        self._engine("text").text(ids, att, out, col, normalize, self._lengths(ids))
+        lengths = self._lengths(ids)
+        ids_d, att_d = self._engine("text").stage_tokens(ids, att)
+        return ids_d, att_d, lengths, b
+
+    @torch.no_grad()
+    def encode_into(self, texts, out: torch.Tensor, col: int, normalize: bool, tokenizer_kargs=None, prepared=None) -> int:
+        ids, att, lengths, b = prepared if prepared is not None else self.prepare(texts, tokenizer_kargs)
+        self._engine("text").text(ids, att, out, col, normalize, lengths)
         return b
 
     @torch.no_grad()
@@ -403,8 +412,9 @@ class ItemEncoder(nn.Module):
             n = (images.size(0) * images.size(1)) if isinstance(images, torch.Tensor) else sum(len(s) for s in images)
             d = self.cfg.dim_per_modality
             out = torch.empty(n, 2 * d, dtype=torch.float32, device=dev)
+            prepared = self.text_enc.prepare(texts)            # host work + H2D first, then both towers are enqueued back to back
             b = self.image_enc.encode_into(images, out, 0, self.cfg.norm_out)
-            b2 = self.text_enc.encode_into(texts, out, d, self.cfg.norm_out)
+            b2 = self.text_enc.encode_into(texts, out, d, self.cfg.norm_out, prepared=prepared)
             if b != b2:
                 raise ValueError("images and texts disagree on the batch size")
             return out.view(b, -1, 2 * d)

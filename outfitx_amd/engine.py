@@ -134,11 +134,21 @@ class Engine:
             L.check(self.lib.ofx_vit_b32_fwd(self.h, _ptr(px), N, _ptr(out), out.stride(0), col, int(normalize),
                                              _ptr(ws), ws.numel(), _stream(self.device)), "ofx_vit_b32_fwd")
 
+    def stage_tokens(self, ids: torch.Tensor, att: Optional[torch.Tensor]):
+        """Token ids / mask -> device int64 (non-blocking from pinned memory).  Call this BEFORE enqueuing a long
+        kernel sequence: a blocking H2D copy in the middle of a step stalls the host behind everything queued."""
+        def mv(t):
+            if t is None:
+                return None
+            if t.device == self.device and t.dtype == torch.int64 and t.is_contiguous():
+                return t
+            return t.to(device=self.device, dtype=torch.int64, non_blocking=t.device.type == "cpu" and t.is_pinned()).contiguous()
+        return mv(ids), mv(att)
+
     def text(self, ids: torch.Tensor, att: Optional[torch.Tensor], out: torch.Tensor, col: int, normalize: bool,
              lengths: Optional[Sequence[int]] = None) -> None:
         """ids/att [N,T] int64 -> out[:, col:col+512].  lengths: host ints (EOS position + 1) or None."""
-        ids_d = ids.to(device=self.device, dtype=torch.int64).contiguous()
-        att_d = None if att is None else att.to(device=self.device, dtype=torch.int64).contiguous()
+        ids_d, att_d = self.stage_tokens(ids, att)
         N, T = ids_d.shape
         Tc = T if lengths is None else max(1, min(T, max(int(v) for v in lengths)))
         arr = None if lengths is None else (C.c_int * N)(*[int(v) for v in lengths])
