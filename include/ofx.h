@@ -132,6 +132,8 @@ int ofx_profile_read(double* ms, double* flops, long long* launches);
 
 /* Process-wide tuning knobs (benchmarks only).  knob 0: GEMM rasterisation group (row panels per L2 group, default 8). */
 int ofx_tune(int knob, int value);
+/* Diagnostics: when buf != NULL the big-tile GEMM writes {shader cycles, 100 MHz ticks} of its main loop per block (16 B each). */
+void ofx_debug_gemm_clock(void* buf);
 
 /* ------------------------------------------------------------------ op level (tests) ------- */
 int ofx_gemm(const void* A, const void* W, void* C, const float* bias, const float* resid, int M, int N, int K,

@@ -58,6 +58,7 @@ SIGNATURES = {
     "ofx_profile_enable": (None, [_i]),
     "ofx_profile_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "ofx_tune": (_i, [_i, _i]),
+    "ofx_debug_gemm_clock": (None, [_vp]),
     "ofx_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ofx_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "ofx_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),

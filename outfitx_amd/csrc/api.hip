@@ -543,12 +543,17 @@ extern "C" int ofx_topk_merge(const int64_t* idx_in, const float* dist_in, int p
 }
 
 // ------------------------------------------------------------------------------------- tuning
-extern int g_gemm_group_m, g_gemm_ablate, g_gemm_kernel;
+extern int g_gemm_group_m, g_gemm_ablate, g_gemm_kernel, g_gemm_skew, g_gemm_pref;
+extern unsigned long long* g_gemm_dbg;
+/* diagnostics: per-block {shader cycles, 100 MHz ticks} of the big-tile GEMM main loop go to buf (device, 16 B per block); NULL = off */
+extern "C" void ofx_debug_gemm_clock(void* buf) { g_gemm_dbg = (unsigned long long*)buf; }
 extern "C" int ofx_tune(int knob, int value) {
     switch (knob) {
         case 0: g_gemm_group_m = value; return OFX_OK;
         case 1: g_gemm_ablate = value; return OFX_OK;
         case 2: g_gemm_kernel = value; return OFX_OK;
+        case 3: g_gemm_skew = value; return OFX_OK;
+        case 4: g_gemm_pref = value; return OFX_OK;
         default: ofx_set_error("ofx_tune: unknown knob %d", knob); return OFX_EINVAL;
     }
 }

@@ -34,7 +34,8 @@ struct KArgs {
     const float* bias;
     const float* resid;
     const int* m_dev;   // optional device-side row count (pad-free varlen sets); M is then the upper bound
-    int M, N, K, lda, ldc, ldr, act, out_kind, tiles_n, tiles_m, nwg, group_m;
+    unsigned long long* dbg;   // diagnostics only (tools/gemm_bench.py --clock): per block {shader cycles, 100 MHz ticks} of the main loop
+    int M, N, K, lda, ldc, ldr, act, out_kind, tiles_n, tiles_m, nwg, group_m, skew;
 };
 
 __device__ __forceinline__ void glds16(const char* g, OFX_LDS char* l) {
@@ -285,7 +286,7 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
 // WR x WC waves, wave tile 128 x 64, NST LDS stages.  <2,4,2> = 256x256 tile, 8 waves, one block per CU;
 // <2,2,1> = 256x128 tile, 4 waves, LDS is a single landing stage (the k-tile being multiplied lives in
 // registers), 64 KiB per block so TWO independent blocks share a CU and overlap each other's load phases.
-template <typename T, int WR, int WC, int NST>
+template <typename T, int WR, int WC, int NST, int ABL = 0>   // ABL (diagnostics, wrong results): 1 no LDS-DMA, 2 no fragment reads after k-tile 0, 3 both, 4 both + no barriers, 5 every k-tile re-reads k-slice 0 (cache-resident operands)
 __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_big_kernel(KArgs p) {
     typedef typename OpT<T>::v8 v8;
     constexpr int TM = WR * 128, TN = WC * 64, NW = WR * WC;
@@ -293,6 +294,12 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_big_kernel(KArgs p) {
     constexpr int A_PER_WAVE = (TM / 8) / NW, W_PER_WAVE = (TN / 8) / NW, NLD = A_PER_WAVE + W_PER_WAVE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     OFX_LDS char* lds = (OFX_LDS char*)smem;
+    const unsigned long long cstart = p.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+    // One-time phase skew: the second block that lands on each CU (dispatch ids 256..511) starts `skew` x ~4 us late,
+    // so the two co-resident blocks alternate main loop / epilogue instead of bursting their stores together.
+    // Speed only: nothing depends on which blocks actually share a CU.
+    if (p.skew > 0 && NST == 1 && blockIdx.x >= 256 && blockIdx.x < 512)
+        for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(127);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WC, wc = wave % WC;
@@ -337,9 +344,10 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_big_kernel(KArgs p) {
     }
     const int a_dst = wave * A_PER_WAVE * 1024, w_dst = TM * BK * 2 + wave * W_PER_WAVE * 1024;
     auto issue = [&](int kt, int stage) {
+        if (ABL == 1 || ABL == 3 || ABL == 4) return;
         OFX_LDS char* base = lds + stage * STAGE;
-        const char* ak = a_base + (size_t)kt * BK * 2;
-        const char* wk = w_base + (size_t)kt * BK * 2;
+        const char* ak = a_base + (size_t)(ABL == 5 ? 0 : kt) * BK * 2;
+        const char* wk = w_base + (size_t)(ABL == 5 ? 0 : kt) * BK * 2;
 #pragma unroll
         for (int i = 0; i < A_PER_WAVE; ++i) glds16(ak + a_off[i], base + a_dst + i * 1024);
 #pragma unroll
@@ -356,7 +364,10 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_big_kernel(KArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    v8 af[2][8], wf[2][4];
     const int nk = p.K / BK;
+    unsigned long long c0 = 0, r0 = 0;
+    if (p.dbg) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     issue(0, 0);
     if (NST == 2) issue(nk > 1 ? 1 : 0, 1);
     for (int kt = 0; kt < nk; ++kt) {
@@ -368,30 +379,31 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_big_kernel(KArgs p) {
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();                       // ... and everybody else's
+        if (ABL != 4) __builtin_amdgcn_s_barrier();         // ... and everybody else's
         OFX_LDS char* base = lds + cur * STAGE;
-        v8 af[2][8], wf[2][4];
+        if (ABL < 2 || ABL == 5 || kt == 0) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int chk = ((ks * 4 + fq) ^ fsw) * 16;
+            for (int ks = 0; ks < 2; ++ks) {
+                const int chk = ((ks * 4 + fq) ^ fsw) * 16;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wf[ks][j] = *(OFX_LDS v8*)(base + w_frag + j * 16 * 128 + chk);
+                for (int j = 0; j < 4; ++j) wf[ks][j] = *(OFX_LDS v8*)(base + w_frag + j * 16 * 128 + chk);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) af[ks][i] = *(OFX_LDS v8*)(base + a_frag + i * 16 * 128 + chk);
+                for (int i = 0; i < 8; ++i) af[ks][i] = *(OFX_LDS v8*)(base + a_frag + i * 16 * 128 + chk);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                       // every wave holds its fragments: the stage is free
+        if (ABL != 4) __builtin_amdgcn_s_barrier();         // every wave holds its fragments: the stage is free
         // 64 MFMAs; the next k-tile's LDS-DMA goes out one piece per 5 MFMAs in program order, so the matrix
         // pipe keeps running while the wave issues them.  No branch in the stream: past the end the prefetch
         // is clamped to the last k-tile (a redundant fill of a stage nobody reads again).
         OFX_LDS char* nbase = lds + cur * STAGE;
-        const int kn = kt + NST < nk ? kt + NST : nk - 1;
+        const int kn = ABL == 5 ? 0 : (kt + NST < nk ? kt + NST : nk - 1);
         const char* ak = a_base + (size_t)kn * BK * 2;
         const char* wk = w_base + (size_t)kn * BK * 2;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int m = 0; m < 64; ++m) {
-            if (m % 5 == 0 && m / 5 < NLD) {
+            if (ABL != 1 && ABL != 3 && ABL != 4 && m % 5 == 0 && m / 5 < NLD) {
                 const int q = m / 5;
                 if (q < A_PER_WAVE) glds16(ak + a_off[q], nbase + a_dst + q * 1024);
                 else glds16(wk + w_off[q - A_PER_WAVE], nbase + w_dst + (q - A_PER_WAVE) * 1024);
@@ -402,6 +414,15 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_big_kernel(KArgs p) {
         __builtin_amdgcn_s_setprio(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the clamped tail prefetches before the wave can end
+    unsigned long long cloop_end = 0;
+    if (p.dbg) {
+        cloop_end = __builtin_amdgcn_s_memtime();
+        if (tid == 0) {
+            p.dbg[4 * blockIdx.x] = cloop_end - c0;
+            p.dbg[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+            p.dbg[4 * blockIdx.x + 2] = c0 - cstart;
+        }
+    }
 
     OFX_LDS char* ep = lds + NST * STAGE + wave * EPI2_BYTES_PER_WAVE;   // private staging, outside the stages
     const int gm0 = m0 + wr * 128, gn0 = n0 + wc * 64;
@@ -411,19 +432,185 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_big_kernel(KArgs p) {
         case OFX_ACT_MISH: epilogue2<T, OFX_ACT_MISH>(p, ep, acc, gm0, gn0, lane); break;
         default: epilogue2<T, OFX_ACT_NONE>(p, ep, acc, gm0, gn0, lane); break;
     }
+    if (p.dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) p.dbg[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memtime() - cloop_end;
+    }
 }
 
-template <typename T, int WR, int WC, int NST>
+// ------------------------------------------------------------------------------------------------
+// Ping-pong variant of the 256x256 tile (8 waves): waves 0-3 (group 0, rows 0-127) and waves 4-7 (group 1) run
+// the same per-k-tile program offset by ONE barrier slot, so on every SIMD one wave reads its 24 fragments and
+// issues LDS-DMA while the other wave runs its 64 MFMAs.  Slot schedule (B = block barrier, j = k-tile):
+//   group 0:  [W0] B [R0] B [M0 W1] B [R1 I2] B [M1 W2] B [R2 I3] B ...
+//   group 1:  [W0] B [  ] B [R0 W1] B [M0 I2] B [R1 W2] B [M1 I3] B ...
+// k-tile j >= 2 is issued by both groups in slot 2j-1 (after both groups read k-tile j-2, slots 2j-3 / 2j-2: WAR),
+// waited for (vmcnt(0)) at the end of slot 2j and read in slots 2j+1 / 2j+2 (RAW: every wave's wait precedes the
+// barrier that opens slot 2j+1).  Two 64 KiB stages + 32 KiB private epilogue staging.
+template <typename T>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(KArgs p) {
+    typedef typename OpT<T>::v8 v8;
+    constexpr int TM = 256, TN = 256, STAGE = (TM + TN) * BK * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    OFX_LDS char* lds = (OFX_LDS char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    int bid = blockIdx.x;
+    {
+        const int nx = 8, q = p.nwg / nx, r = p.nwg % nx, x = bid % nx, i = bid / nx;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    int tm, tn;
+    {
+        const int per_group = p.group_m * p.tiles_n;
+        const int gidx = bid / per_group, first = gidx * p.group_m;
+        const int gm = min(p.group_m, p.tiles_m - first);
+        const int r = bid - gidx * per_group;
+        tm = first + r % gm;
+        tn = r / gm;
+    }
+    const int m0 = tm * TM, n0 = tn * TN;
+    if (p.m_dev) {
+        const int m_live = *p.m_dev;
+        p.M = m_live < p.M ? m_live : p.M;
+        if (m0 >= p.M) return;
+    }
+
+    const int lrow = lane >> 3, lchk = lane & 7;
+    const char* a_base = p.A + (size_t)m0 * p.lda * 2;
+    const char* w_base = p.W + (size_t)n0 * p.K * 2;
+    unsigned a_off[4], w_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + lrow;
+        const int rr = m0 + row < p.M ? row : p.M - 1 - m0;
+        a_off[i] = ((unsigned)rr * p.lda + (lchk ^ ((row >> 1) & 7)) * 8) * 2;
+        w_off[i] = ((unsigned)row * p.K + (lchk ^ ((row >> 1) & 7)) * 8) * 2;
+    }
+    const int a_dst = wave * 4 * 1024, w_dst = TM * BK * 2 + wave * 4 * 1024;
+    auto issue_all = [&](int kt, int stage) {
+        OFX_LDS char* base = lds + stage * STAGE;
+        const char* ak = a_base + (size_t)kt * BK * 2;
+        const char* wk = w_base + (size_t)kt * BK * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(ak + a_off[i], base + a_dst + i * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(wk + w_off[i], base + w_dst + i * 1024);
+    };
+
+    const int fr = lane & 15, fq = lane >> 4, fsw = fr >> 1;
+    const int a_frag = (wr * 128 + fr) * 128;
+    const int w_frag = TM * BK * 2 + (wc * 64 + fr) * 128;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    v8 af[2][8], wf[2][4];
+
+#define OFX_READ_FRAGS(STG)                                                                                   \
+    {                                                                                                         \
+        OFX_LDS char* base_ = lds + (STG) * STAGE;                                                            \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                    \
+            const int chk = ((ks * 4 + fq) ^ fsw) * 16;                                                       \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) wf[ks][j] = *(OFX_LDS v8*)(base_ + w_frag + j * 16 * 128 + chk); \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) af[ks][i] = *(OFX_LDS v8*)(base_ + a_frag + i * 16 * 128 + chk); \
+        }                                                                                                     \
+    }
+
+    const int nk = p.K / BK;
+    issue_all(0, 0);
+    issue_all(nk > 1 ? 1 : 0, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // k-tile 0 landed (my pieces)
+    __builtin_amdgcn_s_barrier();                           // ---- end of slot 0
+    if (wr == 0) {
+        for (int t = 0; t < nk; ++t) {
+            // slot 2t+1: stage (t+1)&1 held k-tile t-1, read by group 1 in slot 2t -> refill it, then read k-tile t
+            if (t >= 1 && t + 1 < nk) issue_all(t + 1, (t + 1) & 1);
+            OFX_READ_FRAGS(t & 1)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // slot 2t+2
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int m = 0; m < 64; ++m) {
+                const int ks = m >> 5, i = (m >> 2) & 7, j = m & 3;
+                acc[i][j] = OpT<T>::mfma16(wf[ks][j], af[ks][i], acc[i][j]);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my pieces of k-tile t+1 landed
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_s_barrier();                       // group 1's last MFMA slot
+    } else {
+        __builtin_amdgcn_s_barrier();                       // slot 1: group 0 reads k-tile 0
+        for (int t = 0; t < nk; ++t) {
+            // slot 2t+2
+            OFX_READ_FRAGS(t & 1)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my pieces of k-tile t+1 landed (issued in slot 2t+1)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // slot 2t+3: both groups have read stage t&1 -> refill it with k-tile t+2 under the MFMAs
+            // (past the end the piece addresses are clamped to the last k-tile: a redundant fill nobody reads)
+            OFX_LDS char* nbase = lds + (t & 1) * STAGE;
+            const int kn = t + 2 < nk ? t + 2 : nk - 1;
+            const char* ak = a_base + (size_t)kn * BK * 2;
+            const char* wk = w_base + (size_t)kn * BK * 2;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int m = 0; m < 64; ++m) {
+                if (m % 5 == 0 && m / 5 < 8) {
+                    const int q = m / 5;
+                    if (q < 4) glds16(ak + a_off[q], nbase + a_dst + q * 1024);
+                    else glds16(wk + w_off[q - 4], nbase + w_dst + (q - 4) * 1024);
+                }
+                const int ks = m >> 5, i = (m >> 2) & 7, j = m & 3;
+                acc[i][j] = OpT<T>::mfma16(wf[ks][j], af[ks][i], acc[i][j]);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+#undef OFX_READ_FRAGS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    OFX_LDS char* ep = lds + 2 * STAGE + wave * EPI2_BYTES_PER_WAVE;
+    const int gm0 = m0 + wr * 128, gn0 = n0 + wc * 64;
+    switch (p.act) {
+        case OFX_ACT_QUICK_GELU: epilogue2<T, OFX_ACT_QUICK_GELU>(p, ep, acc, gm0, gn0, lane); break;
+        case OFX_ACT_GELU: epilogue2<T, OFX_ACT_GELU>(p, ep, acc, gm0, gn0, lane); break;
+        case OFX_ACT_MISH: epilogue2<T, OFX_ACT_MISH>(p, ep, acc, gm0, gn0, lane); break;
+        default: epilogue2<T, OFX_ACT_NONE>(p, ep, acc, gm0, gn0, lane); break;
+    }
+}
+
+template <typename T>
+static int launch_pp(KArgs& k, int M, int N, hipStream_t s) {
+    constexpr int LDSB = 2 * (256 + 256) * BK * 2 + 8 * EPI2_BYTES_PER_WAVE;
+    static bool attr = false;
+    if (!attr) {
+        OFX_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+        attr = true;
+    }
+    k.tiles_n = N / 256; k.tiles_m = (M + 255) / 256; k.nwg = k.tiles_m * k.tiles_n;
+    hipLaunchKernelGGL(gemm_pp_kernel<T>, dim3(k.nwg), dim3(512), LDSB, s, k);
+    return OFX_OK;
+}
+
+template <typename T, int WR, int WC, int NST, int ABL = 0>
 static int launch_big(KArgs& k, int M, int N, hipStream_t s) {
     constexpr int TM = WR * 128, TN = WC * 64, NW = WR * WC;
     constexpr int LDSB = NST * (TM + TN) * BK * 2 + NW * EPI2_BYTES_PER_WAVE;
     static bool attr = false;
     if (!attr) {
-        OFX_HIP(hipFuncSetAttribute((const void*)gemm_big_kernel<T, WR, WC, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+        OFX_HIP(hipFuncSetAttribute((const void*)gemm_big_kernel<T, WR, WC, NST, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
         attr = true;
     }
     k.tiles_n = N / TN; k.tiles_m = (M + TM - 1) / TM; k.nwg = k.tiles_m * k.tiles_n;
-    hipLaunchKernelGGL((gemm_big_kernel<T, WR, WC, NST>), dim3(k.nwg), dim3(64 * NW), LDSB, s, k);
+    hipLaunchKernelGGL((gemm_big_kernel<T, WR, WC, NST, ABL>), dim3(k.nwg), dim3(64 * NW), LDSB, s, k);
     return OFX_OK;
 }
 
@@ -431,7 +618,10 @@ static int launch_big(KArgs& k, int M, int N, hipStream_t s) {
 
 int g_gemm_group_m = 0;   // 0 = adaptive
 int g_gemm_ablate = 0;    // diagnostics only (tools/gemm_bench.py)
-int g_gemm_kernel = 0;    // 0 auto, 1 force 128x128, 2 force 256x256 (8 waves, 2 stages), 3 force 256x128 (4 waves, register-resident k-tile)
+unsigned long long* g_gemm_dbg = nullptr;   // diagnostics only
+int g_gemm_pref = 2;      // short-K big GEMMs: 0 -> 256x128 kernel, 1 -> 256x256, 2 -> 256x256 ping-pong
+int g_gemm_skew = 0;      // start skew of the second co-resident block (x 8128 cycles), 256x128 kernel only
+int g_gemm_kernel = 0;    // 0 auto, 1 force 128x128, 2 force 256x256 (8 waves, 2 stages), 3 force 256x128 (4 waves, register-resident k-tile), 4 force 256x256 ping-pong
 
 int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
     OFX_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, OFX_ESHAPE, "gemm: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
@@ -444,7 +634,7 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
                 "gemm: operands must be 16-byte aligned");
     OFX_REQUIRE(op_dtype == OFX_BF16 || op_dtype == OFX_F16, OFX_EINVAL, "gemm: operand dtype must be bf16 or f16");
     KArgs k;
-    k.A = (const char*)g.A; k.W = (const char*)g.W; k.C = (char*)g.C; k.bias = g.bias; k.resid = g.resid; k.m_dev = g.m_dev;
+    k.A = (const char*)g.A; k.W = (const char*)g.W; k.C = (char*)g.C; k.bias = g.bias; k.resid = g.resid; k.m_dev = g.m_dev; k.dbg = g_gemm_dbg; k.skew = g_gemm_skew;
     k.M = g.M; k.N = g.N; k.K = g.K; k.lda = g.lda; k.ldc = g.ldc; k.ldr = g.ldr; k.act = g.act; k.out_kind = g.out_kind;
     static bool attr_set = false;
     if (!attr_set) {
@@ -459,14 +649,22 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
     int kind = g_gemm_kernel;
     if (kind == 0) {   // measured crossover points (tools/gemm_bench.py, profiles/r01_gemm_variants.txt)
         const long t2 = (long)((g.M + 255) / 256) * (g.N / 256), t3 = (long)((g.M + 255) / 256) * (g.N / 128);
-        kind = (g.N % 256 == 0 && t2 >= 1024) ? 2 : (g.N % 128 == 0 && t3 >= 512) ? 3 : 1;
+        if (g.N % 256 == 0 && t2 >= 1024 && (g.K > 1024 || g_gemm_pref >= 1)) kind = g_gemm_pref == 2 && g.K <= 1024 ? 4 : 2;   // 256x256, one block per CU
+        else if (g.N % 128 == 0 && t3 >= 512) kind = 3;                    // short K / mid-size M: 256x128, two blocks per CU
+        else kind = 1;
     }
-    if (kind == 2 && g.N % 256) kind = 1;
+    if ((kind == 2 || kind == 4) && g.N % 256) kind = 1;
     ProfScope prof(PROF_GEMM, s, 2.0 * g.M * g.N * g.K);
-    if (kind == 2 || kind == 3) {
-        k.group_m = g_gemm_group_m > 0 ? g_gemm_group_m : 4;
+    if (kind == 2 || kind == 3 || kind == 4) {
+        k.group_m = g_gemm_group_m > 0 ? g_gemm_group_m : (kind == 3 ? 4 : 8);
         int rc;
-        if (kind == 2) rc = op_dtype == OFX_F16 ? launch_big<f16_t, 2, 4, 2>(k, g.M, g.N, s) : launch_big<bf16_t, 2, 4, 2>(k, g.M, g.N, s);
+        if (kind == 4) rc = op_dtype == OFX_F16 ? launch_pp<f16_t>(k, g.M, g.N, s) : launch_pp<bf16_t>(k, g.M, g.N, s);
+        else if (kind == 2 && g_gemm_ablate == 1) rc = launch_big<bf16_t, 2, 4, 2, 1>(k, g.M, g.N, s);
+        else if (kind == 2 && g_gemm_ablate == 2) rc = launch_big<bf16_t, 2, 4, 2, 2>(k, g.M, g.N, s);
+        else if (kind == 2 && g_gemm_ablate == 3) rc = launch_big<bf16_t, 2, 4, 2, 3>(k, g.M, g.N, s);
+        else if (kind == 2 && g_gemm_ablate == 4) rc = launch_big<bf16_t, 2, 4, 2, 4>(k, g.M, g.N, s);
+        else if (kind == 2 && g_gemm_ablate == 5) rc = launch_big<bf16_t, 2, 4, 2, 5>(k, g.M, g.N, s);
+        else if (kind == 2) rc = op_dtype == OFX_F16 ? launch_big<f16_t, 2, 4, 2>(k, g.M, g.N, s) : launch_big<bf16_t, 2, 4, 2>(k, g.M, g.N, s);
         else rc = op_dtype == OFX_F16 ? launch_big<f16_t, 2, 2, 1>(k, g.M, g.N, s) : launch_big<bf16_t, 2, 2, 1>(k, g.M, g.N, s);
         if (rc != OFX_OK) return rc;
     } else {

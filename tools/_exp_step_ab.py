@@ -1,0 +1,30 @@
+import sys, time, warnings, ctypes as C
+sys.path.insert(0, '/root/repo'); warnings.simplefilter('ignore')
+import torch, numpy as np
+from outfitx_amd import synth, _lib as L
+from src.models import OutfitX
+from src.models.configs import ItemEncoderConfig, OutfitXConfig
+from src.models.datatypes import OutfitCompatibilityPredictionTask as CP
+dev = torch.device('cuda', 0)
+model = OutfitX(OutfitXConfig(item_encoder=ItemEncoderConfig(type="clip")))
+model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.full_state_dict(7).items()}, strict=True)
+model = model.to(dev).eval()
+B, n = 256, 8
+px = torch.randn(B, n, 3, 224, 224, device=dev)
+ids_np, att_np = synth.token_batch(1, B * n, 64, 8)
+texts = {"input_ids": torch.from_numpy(ids_np).view(B, n, 64).pin_memory(), "attention_mask": torch.from_numpy(att_np).view(B, n, 64).pin_memory()}
+mask = torch.zeros(B, n, dtype=torch.bool, device=dev)
+def step():
+    with torch.no_grad():
+        return model(task=CP, outfit_embedding=None, outfit_mask=mask, encoder_input_dict={"images": px, "texts": texts})
+lib = L.load()
+for _ in range(3): step()
+torch.cuda.synchronize()
+for rnd in range(3):
+    for pref, gm in ((0, 0), (1, 0), (1, 4), (2, 0)):
+        lib.ofx_tune(4, pref); lib.ofx_tune(0, gm)
+        step(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(6): step()
+        torch.cuda.synchronize()
+        print(f"profile pref {pref} group {gm}: {(time.perf_counter()-t0)/6*1e3:7.2f} ms/step", flush=True)

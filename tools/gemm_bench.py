@@ -15,10 +15,13 @@ SHAPES = [("vit qkv", 102400, 2304, 768, "b"), ("vit out", 102400, 768, 768, "r"
 
 def main():
     lib = L.load()
-    variants = [dict(kv.split("=") for kv in v.split(",")) for v in sys.argv[1:]] or [{"0": "1"}, {"0": "8"}]
+    variants = [dict(kv.split("=") for kv in v.split(",")) for v in sys.argv[1:] if "=" in v] or [{"0": "1"}, {"0": "8"}]
+    only = [v for v in sys.argv[1:] if "=" not in v]
     s = torch.cuda.current_stream().cuda_stream
     g = torch.Generator(device="cuda"); g.manual_seed(0)
     for name, M, N, K, ep in SHAPES:
+        if only and not any(o in name for o in only):
+            continue
         A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
         W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
         C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16 if ep in "bg" else torch.float32)
