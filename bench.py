@@ -146,6 +146,12 @@ def main():
         alg_all_outfit = alg_gemm_outfit + n * (VIT_ATTN + txt_attn(T_real)) + ot_attn(n)
         gemm_ms, gemm_launches = ms[0], int(cnt[0])
         achieved = alg_gemm_outfit * B / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0   # one sampled step
+        traffic = None        # PMC counters cannot be read inside a timed run: the committed rocprofv3 --pmc pass of this same command
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")) as f:
+                traffic = round(json.load(f)["gemm_hbm_bytes_per_launch"])
+        except Exception:
+            pass
         res = {
             "metric": "outfits/sec CP forward (8-item sets, 224^2, bf16)",
             "value": round(world * B * a.steps / elapsed, 2),
@@ -158,9 +164,10 @@ def main():
             "config": {"workload": "BASELINE configs[1]: CP forward with CLIP ViT-B/32 image+text encode, 256 outfits x 8 items per GPU, 224^2",
                        "outfits_per_gpu": B, "items": n, "parallelism": f"dp{world} (batch sharded, no data-path collective)",
                        "tower_precision": a.tower_precision, "outfit_precision": a.precision},
-            "roofline": {"bound": "mfma", "kernel": "gemm_big_kernel<2,4,2> / <2,2,1> / gemm_128x128_kernel (every dense contraction of the step)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_big_kernel<2,4,2> / <2,2,1> / gemm_128x128_kernel (every dense contraction of the step)",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "traffic_note": "bytes/launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/r01_traffic_pmc.json (separate --pmc passes); algorithmic ~344e6",
                          "launches_per_step": gemm_launches, "sampled_steps": 1,
                          "avg_launch_us": round(gemm_ms * 1e3 / max(gemm_launches, 1), 2),
                          "algorithmic_gflop_per_outfit": round(alg_gemm_outfit / 1e9, 3)},
