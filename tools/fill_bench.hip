@@ -1,0 +1,68 @@
+// Raw global->LDS fill rate per CU from an L2-resident buffer: LDS-DMA (global_load_lds_dwordx4) vs
+// register staging (global_load_dwordx4 + ds_write_b128), 4 or 8 waves per block, one block per CU.
+// hipcc --offload-arch=gfx950 -O3 tools/fill_bench.hip -o /tmp/fill_bench && /tmp/fill_bench
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <vector>
+#include <algorithm>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define LDS __attribute__((address_space(3)))
+#define GLB __attribute__((address_space(1)))
+
+template <int MODE, int NW>   // MODE 0: LDS-DMA, 1: register staging; NW waves; each iteration fills 64 KiB
+__global__ __launch_bounds__(64 * NW) void fill(const char* src, unsigned long long* out, int iters, size_t span) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    LDS char* lds = (LDS char*)smem;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int PIECES = 64 / NW;                     // 1 KiB pieces per wave per iteration
+    const char* base = src + (size_t)(blockIdx.x % 8) * 65536;   // a few blocks share lines: L2-resident
+    f32x4 keep = {0, 0, 0, 0};
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        const char* p = base + ((size_t)it * 65536) % span;
+        LDS char* dst = lds + (it & 1) * 65536;
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i)
+                __builtin_amdgcn_global_load_lds((const GLB void*)(p + (wave * PIECES + i) * 1024 + lane * 16), (LDS void*)(dst + (wave * PIECES + i) * 1024), 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            f32x4 r[PIECES];
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) r[i] = *(const f32x4*)(p + (wave * PIECES + i) * 1024 + lane * 16);
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) *(LDS f32x4*)(dst + (wave * PIECES + i) * 1024 + lane * 16) = r[i];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        keep += *(LDS f32x4*)(dst + ((lane * 16 + it * 64) & 65535));
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+    if (keep[0] == 12345.678f) out[0] = 0;
+}
+
+template <int MODE, int NW> void run(const char* name, const char* src, unsigned long long* out, size_t span) {
+    const int iters = 200, blocks = 256;
+    hipFuncSetAttribute((const void*)fill<MODE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((fill<MODE, NW>), dim3(blocks), dim3(64 * NW), 131072, 0, src, out, iters, span);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(blocks);
+    hipMemcpy(h.data(), out, blocks * 8, hipMemcpyDeviceToHost);
+    std::sort(h.begin(), h.end());
+    const double cyc = (double)h[blocks / 2] / iters;
+    printf("%-34s %7.0f cycles per 64 KiB  = %5.1f B/clk/CU\n", name, cyc, 65536.0 / cyc);
+}
+int main() {
+    char* src; unsigned long long* out;
+    const size_t span = 8u << 20;
+    hipMalloc(&src, span + (1 << 20)); hipMemset(src, 1, span + (1 << 20)); hipMalloc(&out, 256 * 8);
+    run<0, 8>("LDS-DMA, 8 waves", src, out, 65536);
+    run<0, 4>("LDS-DMA, 4 waves", src, out, 65536);
+    run<1, 8>("register staging, 8 waves", src, out, 65536);
+    run<1, 4>("register staging, 4 waves", src, out, 65536);
+    run<0, 8>("LDS-DMA, 8 waves, 8 MiB span", src, out, span);
+    run<1, 8>("register staging, 8 waves, 8 MiB span", src, out, span);
+    return 0;
+}
