@@ -220,62 +220,92 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
 constexpr int EPI2_BYTES_PER_WAVE = 16 * 64 * 4;       // 16 rows x 64 fp32, XOR-swizzled, no padding
 
 // Epilogue of the 128x64 wave tile: 8 passes of 16 rows through the wave's private LDS staging (XOR-swizzled
-// 16-B chunks), leaving as whole 256/128-byte row segments.  The fp32 residual of pass i+2 is requested
-// while pass i is written out (DEPTH passes = 8 KiB per wave in flight): with one block per CU nothing else hides it.
+// 16-B chunks), leaving as whole 128/256-byte row segments with 16-byte stores (the store tail is issue-bound:
+// guide T21).  fp32 output: 16 lanes x 4 columns per row, the fp32 residual of pass i+2 requested while pass i is
+// written out.  bf16/f16 output: 8 lanes x 8 columns per row -> one dwordx4 store per lane instead of two dwordx2.
+template <typename T, int ACT>
+__device__ __forceinline__ float act_apply(float v) {
+    if (ACT == OFX_ACT_QUICK_GELU) return act_quick_gelu(v);
+    if (ACT == OFX_ACT_GELU) return act_gelu(v);
+    if (ACT == OFX_ACT_MISH) return act_mish(v);
+    return v;
+}
+
 template <typename T, int ACT>
 __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x4 (&acc)[8][4], int gm0, int gn0, int lane) {
-    typedef typename OpT<T>::v4 v4;
-    constexpr int DEPTH = 2;
+    typedef typename OpT<T>::v8 v8;
     const int fr = lane & 15, fq = lane >> 4;
-    const int chunk = lane & 15, rsub = lane >> 4;
-    const int gn = gn0 + chunk * 4;
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bias4 = *(const f32x4*)(p.bias + gn);
-    const bool has_res = p.resid != nullptr;
-    f32x4 res[DEPTH + 1][4];
-    auto fetch = [&](int pass, f32x4 (&dst)[4]) {
+    if (p.out_kind == 0) {
+        constexpr int DEPTH = 2;
+        const int chunk = lane & 15, rsub = lane >> 4;
+        const int gn = gn0 + chunk * 4;
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias4 = *(const f32x4*)(p.bias + gn);
+        const bool has_res = p.resid != nullptr;
+        f32x4 res[DEPTH + 1][4];
+        auto fetch = [&](int pass, f32x4 (&dst)[4]) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int gm = gm0 + pass * 16 + it * 4 + rsub;
-            dst[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (has_res && gm < p.M) dst[it] = *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn);
-        }
-    };
+            for (int it = 0; it < 4; ++it) {
+                const int gm = gm0 + pass * 16 + it * 4 + rsub;
+                dst[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (has_res && gm < p.M) dst[it] = *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn);
+            }
+        };
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) fetch(d, res[d]);
+        for (int d = 0; d < DEPTH; ++d) fetch(d, res[d]);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        if (i + DEPTH < 8) fetch(i + DEPTH, res[(i + DEPTH) % (DEPTH + 1)]);
+        for (int i = 0; i < 8; ++i) {
+            if (i + DEPTH < 8) fetch(i + DEPTH, res[(i + DEPTH) % (DEPTH + 1)]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *(OFX_LDS f32x4*)(ep + fr * 256 + (((j * 4 + fq) ^ (fr & 7)) << 4)) = acc[i][j];
+            for (int j = 0; j < 4; ++j) *(OFX_LDS f32x4*)(ep + fr * 256 + (((j * 4 + fq) ^ (fr & 7)) << 4)) = acc[i][j];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int row = it * 4 + rsub;
-            const int gm = gm0 + i * 16 + row;
-            f32x4 v = *(OFX_LDS f32x4*)(ep + row * 256 + ((chunk ^ (row & 7)) << 4));
-            if (gm < p.M) {
-                v += bias4;
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 4 + rsub;
+                const int gm = gm0 + i * 16 + row;
+                f32x4 v = *(OFX_LDS f32x4*)(ep + row * 256 + ((chunk ^ (row & 7)) << 4));
+                if (gm < p.M) {
+                    v += bias4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (ACT == OFX_ACT_QUICK_GELU) v[e] = act_quick_gelu(v[e]);
-                    else if (ACT == OFX_ACT_GELU) v[e] = act_gelu(v[e]);
-                    else if (ACT == OFX_ACT_MISH) v[e] = act_mish(v[e]);
-                }
-                v += res[i % (DEPTH + 1)][it];
-                if (p.out_kind == 0) {
+                    for (int e = 0; e < 4; ++e) v[e] = act_apply<T, ACT>(v[e]);
+                    v += res[i % (DEPTH + 1)][it];
                     *(f32x4*)(p.C + ((size_t)gm * p.ldc + gn) * 4) = v;
-                } else {
-                    v4 hi;
+                }
+            }
+        }
+    } else {
+        const int c8 = lane & 7, rsub = lane >> 3;          // 8 columns per lane, 8 rows per wave-instruction
+        const int gn = gn0 + c8 * 8;
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+        if (p.bias) { b0 = *(const f32x4*)(p.bias + gn); b1 = *(const f32x4*)(p.bias + gn + 4); }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) hi[e] = (T)v[e];
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(OFX_LDS f32x4*)(ep + fr * 256 + (((j * 4 + fq) ^ (fr & 7)) << 4)) = acc[i][j];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = it * 8 + rsub;
+                const int gm = gm0 + i * 16 + row;
+                f32x4 v0 = *(OFX_LDS f32x4*)(ep + row * 256 + (((2 * c8) ^ (row & 7)) << 4));
+                f32x4 v1 = *(OFX_LDS f32x4*)(ep + row * 256 + (((2 * c8 + 1) ^ (row & 7)) << 4));
+                if (gm < p.M) {
+                    v0 += b0; v1 += b1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v0[e] = act_apply<T, ACT>(v0[e]); v1[e] = act_apply<T, ACT>(v1[e]); }
+                    if (p.resid) {
+                        v0 += *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn);
+                        v1 += *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn + 4);
+                    }
+                    v8 hi;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { hi[e] = (T)v0[e]; hi[4 + e] = (T)v1[e]; }
                     T* crow = (T*)p.C + (size_t)gm * p.ldc + gn;
-                    *(v4*)crow = hi;
+                    *(v8*)crow = hi;
                     if (p.out_kind == 2) {
-                        v4 lo;
+                        v8 lo;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) lo[e] = (T)(v[e] - (float)hi[e]);
-                        *(v4*)(crow + p.N) = lo;
-                        *(v4*)(crow + 2 * p.N) = hi;
+                        for (int e = 0; e < 4; ++e) { lo[e] = (T)(v0[e] - (float)hi[e]); lo[4 + e] = (T)(v1[e] - (float)hi[4 + e]); }
+                        *(v8*)(crow + p.N) = lo;
+                        *(v8*)(crow + 2 * p.N) = hi;
                     }
                 }
             }
@@ -628,7 +658,7 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
     OFX_REQUIRE(g.N % BN == 0, OFX_ESHAPE, "gemm: N=%d must be a multiple of %d (pad the weight at pack time)", g.N, BN);
     OFX_REQUIRE(g.K % BK == 0, OFX_ESHAPE, "gemm: K=%d must be a multiple of %d", g.K, BK);
     OFX_REQUIRE(g.lda >= g.K && g.lda % 8 == 0, OFX_ESHAPE, "gemm: lda=%d must be >= K and a multiple of 8", g.lda);
-    OFX_REQUIRE(g.ldc % 4 == 0 && g.ldc >= (g.out_kind == 2 ? 3 * g.N : g.N), OFX_ESHAPE, "gemm: bad ldc=%d", g.ldc);
+    OFX_REQUIRE(g.ldc % (g.out_kind == 0 ? 4 : 8) == 0 && g.ldc >= (g.out_kind == 2 ? 3 * g.N : g.N), OFX_ESHAPE, "gemm: bad ldc=%d", g.ldc);
     OFX_REQUIRE(!g.resid || (g.ldr % 4 == 0 && g.ldr >= g.N), OFX_ESHAPE, "gemm: bad ldr=%d", g.ldr);
     OFX_REQUIRE(((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.W % 16 == 0) && ((uintptr_t)g.C % 16 == 0), OFX_EINVAL,
                 "gemm: operands must be 16-byte aligned");
