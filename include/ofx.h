@@ -138,6 +138,10 @@ void ofx_debug_gemm_clock(void* buf);
 /* ------------------------------------------------------------------ op level (tests) ------- */
 int ofx_gemm(const void* A, const void* W, void* C, const float* bias, const float* resid, int M, int N, int K,
              int lda, int ldc, int ldr, int act, int out_kind, int op_dtype, ofx_stream stream);
+/* ofx_gemm with split-K scratch: slab of ofx_gemm_splitk_ws(M,N,K) bytes (0 = the shape is not split) */
+size_t ofx_gemm_splitk_ws(int M, int N, int K);
+int ofx_gemm_splitk(const void* A, const void* W, void* C, const float* bias, const float* resid, int M, int N, int K,
+                    int lda, int ldc, int ldr, int act, int out_kind, int op_dtype, void* slab, size_t slab_bytes, ofx_stream stream);
 int ofx_layernorm(const float* x, const int* row_idx, const float* gamma, const float* beta, void* y, int rows,
                   int D, int ldy, int out_kind, int op_dtype, float eps, ofx_stream stream);
 int ofx_attention(const void* qkv, void* out, const int64_t* key_mask, int nseq, int seq_len, int n_head, int ld,

@@ -60,6 +60,8 @@ SIGNATURES = {
     "ofx_tune": (_i, [_i, _i]),
     "ofx_debug_gemm_clock": (None, [_vp]),
     "ofx_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ofx_gemm_splitk_ws": (_sz, [_i, _i, _i]),
+    "ofx_gemm_splitk": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ofx_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "ofx_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "ofx_set_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),

@@ -292,7 +292,7 @@ extern "C" int ofx_pack_text_weights(ofx_handle* h, const void* const* P, int n,
 
 // ------------------------------------------------------------------------------------- workspace
 namespace {
-struct SetWs { int* cu; float* X; char* H; float* QKV; char* U; char* HP; char* UP; };
+struct SetWs { int* cu; float* X; char* H; float* QKV; char* U; char* HP; char* UP; char* slab; size_t slab_bytes; };
 size_t carve_set(const ofx_handle* h, Bump& b, int B, int L, SetWs* w) {
     const size_t M = (size_t)B * (L + 1), D = h->d.d_model, km = h->ot_kmul, Fp = h->ot_ffn_pad;
     SetWs t;
@@ -303,10 +303,19 @@ size_t carve_set(const ofx_handle* h, Bump& b, int B, int L, SetWs* w) {
     t.U = b.take<char>(M * km * Fp * 2);
     t.HP = b.take<char>((size_t)B * km * D * 2);   // last layer: prefix rows only
     t.UP = b.take<char>((size_t)B * km * Fp * 2);
+    // split-K scratch for the under-filled GEMMs of small batches (largest need over the shapes used)
+    t.slab_bytes = 0;
+    for (int m : {(int)M, B}) {
+        t.slab_bytes = std::max(t.slab_bytes, ofx_gemm_splitk_bytes(m, 3 * (int)D, (int)(km * D)));
+        t.slab_bytes = std::max(t.slab_bytes, ofx_gemm_splitk_bytes(m, (int)D, (int)(km * D)));
+        t.slab_bytes = std::max(t.slab_bytes, ofx_gemm_splitk_bytes(m, (int)Fp, (int)(km * D)));
+        t.slab_bytes = std::max(t.slab_bytes, ofx_gemm_splitk_bytes(m, (int)D, (int)(km * Fp)));
+    }
+    t.slab = b.take<char>(t.slab_bytes);
     if (w) *w = t;
     return b.off;
 }
-struct ClipWs { float* X; char* H; char* QKV; char* U; int* idx; char* PL; float* E; float* XP; char* HP; char* UP; };
+struct ClipWs { float* X; char* H; char* QKV; char* U; int* idx; char* PL; float* E; float* XP; char* HP; char* UP; char* slab; size_t slab_bytes; };
 size_t carve_clip(Bump& b, size_t rows, size_t n, size_t W, size_t MLP, size_t PD, size_t u_min_bytes, size_t qkv_min_bytes, ClipWs* w) {
     ClipWs t;
     t.X = b.take<float>(rows * W);
@@ -319,6 +328,9 @@ size_t carve_clip(Bump& b, size_t rows, size_t n, size_t W, size_t MLP, size_t P
     t.XP = b.take<float>(n * W);          // last layer runs on the pooled rows only
     t.HP = b.take<char>(n * W * 2);
     t.UP = b.take<char>(n * MLP * 2);
+    t.slab_bytes = std::max(std::max(ofx_gemm_splitk_bytes((int)n, (int)W, (int)W), ofx_gemm_splitk_bytes((int)n, (int)MLP, (int)W)),
+                            std::max(ofx_gemm_splitk_bytes((int)n, (int)W, (int)MLP), ofx_gemm_splitk_bytes((int)n, (int)PD, (int)W)));
+    t.slab = b.take<char>(t.slab_bytes);
     if (w) *w = t;
     return b.off;
 }
@@ -375,6 +387,7 @@ extern "C" int ofx_set_encoder_fwd(ofx_handle* h, const float* x, const uint8_t*
         TRY(ofx_launch_layernorm_dev(ln, m_dev, dt, s));
         GemmArgs g1{}; g1.A = w.H; g1.W = Ly.w_in; g1.C = w.QKV; g1.bias = Ly.b_in; g1.resid = nullptr; g1.m_dev = m_dev;
         g1.M = M; g1.N = 3 * D; g1.K = km * D; g1.lda = km * D; g1.ldc = 3 * D; g1.ldr = 0; g1.act = OFX_ACT_NONE; g1.out_kind = OFX_OUT_F32;
+        g1.slab = w.slab; g1.slab_bytes = w.slab_bytes;
         TRY(ofx_launch_gemm(g1, dt, s));
         SetAttnArgs sa{w.QKV, w.H, w.cu, B, d.n_head, D, km * D, okind, L + 1, last ? 1 : 0, 0.125f};
         TRY(ofx_launch_set_attention(sa, dt, s));
@@ -386,14 +399,17 @@ extern "C" int ofx_set_encoder_fwd(ofx_handle* h, const float* x, const uint8_t*
         }
         GemmArgs g2{}; g2.A = H; g2.W = Ly.w_out; g2.C = X; g2.bias = Ly.b_out; g2.resid = X; g2.m_dev = md;
         g2.M = Ml; g2.N = D; g2.K = km * D; g2.lda = km * D; g2.ldc = D; g2.ldr = D; g2.act = OFX_ACT_NONE; g2.out_kind = OFX_OUT_F32;
+        g2.slab = w.slab; g2.slab_bytes = w.slab_bytes;
         TRY(ofx_launch_gemm(g2, dt, s));
         LnArgs ln2{X, nullptr, Ly.g2, Ly.be2, H, Ml, D, km * D, okind, d.ln_eps};
         TRY(ofx_launch_layernorm_dev(ln2, md, dt, s));
         GemmArgs g3{}; g3.A = H; g3.W = Ly.w_1; g3.C = U; g3.bias = Ly.b_1; g3.resid = nullptr; g3.m_dev = md;
         g3.M = Ml; g3.N = Fp; g3.K = km * D; g3.lda = km * D; g3.ldc = km * Fp; g3.ldr = 0; g3.act = d.outfit_act; g3.out_kind = okind;
+        g3.slab = w.slab; g3.slab_bytes = w.slab_bytes;
         TRY(ofx_launch_gemm(g3, dt, s));
         GemmArgs g4{}; g4.A = U; g4.W = Ly.w_2; g4.C = X; g4.bias = Ly.b_2; g4.resid = X; g4.m_dev = md;
         g4.M = Ml; g4.N = D; g4.K = km * Fp; g4.lda = km * Fp; g4.ldc = D; g4.ldr = D; g4.act = OFX_ACT_NONE; g4.out_kind = OFX_OUT_F32;
+        g4.slab = w.slab; g4.slab_bytes = w.slab_bytes;
         TRY(ofx_launch_gemm(g4, dt, s));
     }
     return OFX_OK;
@@ -443,14 +459,17 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
     }
     GemmArgs g2{}; g2.A = H; g2.W = L.w_o; g2.C = X; g2.bias = L.b_o; g2.resid = X; g2.M = M; g2.N = W; g2.K = W; g2.lda = W;
     g2.ldc = W; g2.ldr = W; g2.act = OFX_ACT_NONE; g2.out_kind = OFX_OUT_F32;
+    if (pool_idx) { g2.slab = w.slab; g2.slab_bytes = w.slab_bytes; }
     TRY(ofx_launch_gemm(g2, dt, s));
     LnArgs ln2{X, nullptr, L.g2, L.be2, H, M, W, W, OFX_OUT_OP, eps};
     TRY(ofx_launch_layernorm(ln2, dt, s));
     GemmArgs g3{}; g3.A = H; g3.W = L.w_fc1; g3.C = U; g3.bias = L.b_fc1; g3.M = M; g3.N = MLP; g3.K = W; g3.lda = W;
     g3.ldc = MLP; g3.act = act; g3.out_kind = OFX_OUT_OP;
+    if (pool_idx) { g3.slab = w.slab; g3.slab_bytes = w.slab_bytes; }
     TRY(ofx_launch_gemm(g3, dt, s));
     GemmArgs g4{}; g4.A = U; g4.W = L.w_fc2; g4.C = X; g4.bias = L.b_fc2; g4.resid = X; g4.M = M; g4.N = W; g4.K = MLP;
     g4.lda = MLP; g4.ldc = W; g4.ldr = W; g4.act = OFX_ACT_NONE; g4.out_kind = OFX_OUT_F32;
+    if (pool_idx) { g4.slab = w.slab; g4.slab_bytes = w.slab_bytes; }
     return ofx_launch_gemm(g4, dt, s);
 }
 
@@ -543,7 +562,7 @@ extern "C" int ofx_topk_merge(const int64_t* idx_in, const float* dist_in, int p
 }
 
 // ------------------------------------------------------------------------------------- tuning
-extern int g_gemm_group_m, g_gemm_ablate, g_gemm_kernel, g_gemm_skew, g_gemm_pref;
+extern int g_gemm_group_m, g_gemm_ablate, g_gemm_kernel, g_gemm_skew, g_gemm_pref, g_gemm_splitk;
 extern unsigned long long* g_gemm_dbg;
 /* diagnostics: per-block {shader cycles, 100 MHz ticks} of the big-tile GEMM main loop go to buf (device, 16 B per block); NULL = off */
 extern "C" void ofx_debug_gemm_clock(void* buf) { g_gemm_dbg = (unsigned long long*)buf; }
@@ -554,6 +573,7 @@ extern "C" int ofx_tune(int knob, int value) {
         case 2: g_gemm_kernel = value; return OFX_OK;
         case 3: g_gemm_skew = value; return OFX_OK;
         case 4: g_gemm_pref = value; return OFX_OK;
+        case 5: g_gemm_splitk = value; return OFX_OK;
         default: ofx_set_error("ofx_tune: unknown knob %d", knob); return OFX_EINVAL;
     }
 }
@@ -563,6 +583,13 @@ extern "C" int ofx_gemm(const void* A, const void* W, void* C, const float* bias
                         int lda, int ldc, int ldr, int act, int out_kind, int op_dtype, ofx_stream stream) {
     GemmArgs g{}; g.A = A; g.W = W; g.C = C; g.bias = bias; g.resid = resid; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc;
     g.ldr = ldr; g.act = act; g.out_kind = out_kind;
+    return ofx_launch_gemm(g, op_dtype, (hipStream_t)stream);
+}
+extern "C" size_t ofx_gemm_splitk_ws(int M, int N, int K) { return ofx_gemm_splitk_bytes(M, N, K); }
+extern "C" int ofx_gemm_splitk(const void* A, const void* W, void* C, const float* bias, const float* resid, int M, int N, int K,
+                               int lda, int ldc, int ldr, int act, int out_kind, int op_dtype, void* slab, size_t slab_bytes, ofx_stream stream) {
+    GemmArgs g{}; g.A = A; g.W = W; g.C = C; g.bias = bias; g.resid = resid; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc;
+    g.ldr = ldr; g.act = act; g.out_kind = out_kind; g.slab = slab; g.slab_bytes = slab_bytes;
     return ofx_launch_gemm(g, op_dtype, (hipStream_t)stream);
 }
 extern "C" int ofx_layernorm(const float* x, const int* row_idx, const float* gamma, const float* beta, void* y, int rows,

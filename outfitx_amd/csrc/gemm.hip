@@ -19,6 +19,8 @@
 
 #include "ofx_common.h"
 
+int g_gemm_splitk = 1;     // 0 disables split-K
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -36,6 +38,9 @@ struct KArgs {
     const int* m_dev;   // optional device-side row count (pad-free varlen sets); M is then the upper bound
     unsigned long long* dbg;   // diagnostics only (tools/gemm_bench.py --clock): per block {shader cycles, 100 MHz ticks} of the main loop
     int M, N, K, lda, ldc, ldr, act, out_kind, tiles_n, tiles_m, nwg, group_m, skew;
+    int m_slab;                 // rows per slab plane (the host-side M, never the clamped live count)
+    int splits, kt_per_split;   // 128x128 kernel only: blockIdx.y owns k-tiles [y*kt_per_split, ...) and writes a raw fp32 slab
+    float* slab;                // [splits, M, N] partial sums when splits > 1
 };
 
 __device__ __forceinline__ void glds16(const char* g, OFX_LDS char* l) {
@@ -156,9 +161,10 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     v8 af[2][4], wf[2][4];
-    const int nk = p.K / BK;
-    issue(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
+    const int kt0 = p.splits > 1 ? blockIdx.y * p.kt_per_split : 0;
+    const int nk = p.splits > 1 ? min(p.K / BK, kt0 + p.kt_per_split) : p.K / BK;
+    issue(kt0, kt0 & 1);
+    for (int kt = kt0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
             issue(kt + 1, cur ^ 1);
@@ -174,9 +180,9 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
         for (int ks = 0; ks < 2; ++ks) {
             const int chk = ((ks * 4 + fq) ^ fsw) * 16;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (ABL != 3 || kt == 0) wf[ks][j] = *(OFX_LDS v8*)(base + w_frag + j * 16 * 128 + chk);
+            for (int j = 0; j < 4; ++j) if (ABL != 3 || kt == kt0) wf[ks][j] = *(OFX_LDS v8*)(base + w_frag + j * 16 * 128 + chk);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (ABL != 3 || kt == 0) af[ks][i] = *(OFX_LDS v8*)(base + a_frag + i * 16 * 128 + chk);
+            for (int i = 0; i < 4; ++i) if (ABL != 3 || kt == kt0) af[ks][i] = *(OFX_LDS v8*)(base + a_frag + i * 16 * 128 + chk);
         }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -201,6 +207,12 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
         for (int j = 0; j < 4; ++j)
             *(OFX_LDS f32x4*)(ep + (i * 16 + fr) * EPI_STRIDE + j * 16 + fq * 4) = acc[i][j];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (p.splits > 1) {                                  // raw partial sums; bias / activation / residual happen in splitk_reduce
+        KArgs q = p;
+        q.C = (char*)(p.slab + (size_t)blockIdx.y * p.m_slab * p.N); q.ldc = p.N; q.out_kind = 0; q.bias = nullptr; q.resid = nullptr;
+        epilogue<T, OFX_ACT_NONE>(q, ep, m0 + wm * 64, n0 + wn * 64, lane);
+        return;
+    }
     switch (p.act) {
         case OFX_ACT_QUICK_GELU: epilogue<T, OFX_ACT_QUICK_GELU>(p, ep, m0 + wm * 64, n0 + wn * 64, lane); break;
         case OFX_ACT_GELU: epilogue<T, OFX_ACT_GELU>(p, ep, m0 + wm * 64, n0 + wn * 64, lane); break;
@@ -308,6 +320,41 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
                         *(v8*)(crow + 2 * p.N) = hi;
                     }
                 }
+            }
+        }
+    }
+}
+
+// Split-K second pass: out = epilogue( sum_s slab[s] ) in a fixed order (deterministic), 4 columns per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(KArgs p) {
+    typedef typename OpT<T>::v4 v4;
+    const int M = p.m_dev ? min(*p.m_dev, p.M) : p.M;
+    const int n4 = p.N / 4;
+    const size_t total = (size_t)M * n4, plane = (size_t)p.m_slab * p.N;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int gm = (int)(i / n4), gn = (int)(i % n4) * 4;
+        const float* sp = p.slab + (size_t)gm * p.N + gn;
+        f32x4 v = *(const f32x4*)sp;
+        for (int s = 1; s < p.splits; ++s) v += *(const f32x4*)(sp + s * plane);
+        if (p.bias) v += *(const f32x4*)(p.bias + gn);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+        if (p.resid) v += *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn);
+        if (p.out_kind == 0) {
+            *(f32x4*)(p.C + ((size_t)gm * p.ldc + gn) * 4) = v;
+        } else {
+            v4 hi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hi[e] = (T)v[e];
+            T* crow = (T*)p.C + (size_t)gm * p.ldc + gn;
+            *(v4*)crow = hi;
+            if (p.out_kind == 2) {
+                v4 lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lo[e] = (T)(v[e] - (float)hi[e]);
+                *(v4*)(crow + p.N) = lo;
+                *(v4*)(crow + 2 * p.N) = hi;
             }
         }
     }
@@ -646,6 +693,25 @@ static int launch_big(KArgs& k, int M, int N, hipStream_t s) {
 
 }  // namespace
 
+// Split-K plan for the 128x128 kernel: used when the tile grid leaves most of the chip idle and K is deep.
+// Returns the number of K splits (1 = none).  Shared by the launcher and the workspace sizing (api.hip).
+int ofx_gemm_splitk_plan(int M, int N, int K) {
+    if (g_gemm_splitk == 0 || N % 128 || K % 64) return 1;
+    const long blocks = (long)((M + 127) / 128) * (N / 128);
+    const int nk = K / 64;
+    if (blocks >= 256 || nk < 16) return 1;
+    int s = (int)((512 + blocks - 1) / blocks);
+    if (s > 8) s = 8;
+    if (s > nk / 4) s = nk / 4;                       // at least 4 k-tiles per split
+    if (s < 2) return 1;
+    const int kps = (nk + s - 1) / s;
+    return (nk + kps - 1) / kps;                      // every split owns at least one k-tile
+}
+size_t ofx_gemm_splitk_bytes(int M, int N, int K) {
+    const int s = ofx_gemm_splitk_plan(M, N, K);
+    return s > 1 ? (size_t)s * M * N * 4 : 0;
+}
+
 int g_gemm_group_m = 0;   // 0 = adaptive
 int g_gemm_ablate = 0;    // diagnostics only (tools/gemm_bench.py)
 unsigned long long* g_gemm_dbg = nullptr;   // diagnostics only
@@ -664,7 +730,7 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
                 "gemm: operands must be 16-byte aligned");
     OFX_REQUIRE(op_dtype == OFX_BF16 || op_dtype == OFX_F16, OFX_EINVAL, "gemm: operand dtype must be bf16 or f16");
     KArgs k;
-    k.A = (const char*)g.A; k.W = (const char*)g.W; k.C = (char*)g.C; k.bias = g.bias; k.resid = g.resid; k.m_dev = g.m_dev; k.dbg = g_gemm_dbg; k.skew = g_gemm_skew;
+    k.A = (const char*)g.A; k.W = (const char*)g.W; k.C = (char*)g.C; k.bias = g.bias; k.resid = g.resid; k.m_dev = g.m_dev; k.dbg = g_gemm_dbg; k.skew = g_gemm_skew; k.splits = 1; k.slab = nullptr; k.m_slab = g.M; k.kt_per_split = 0;
     k.M = g.M; k.N = g.N; k.K = g.K; k.lda = g.lda; k.ldc = g.ldc; k.ldr = g.ldr; k.act = g.act; k.out_kind = g.out_kind;
     static bool attr_set = false;
     if (!attr_set) {
@@ -703,11 +769,22 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
         int gm = g_gemm_group_m;
         if (gm <= 0) { gm = (int)((3u << 20) / ((size_t)BM * g.K * 2) / 2); gm = gm < 1 ? 1 : (gm > 8 ? 8 : gm); }
         k.group_m = gm;
-        if (op_dtype == OFX_F16) hipLaunchKernelGGL((gemm_128x128_kernel<f16_t, 0>), dim3(k.nwg), dim3(256), GEMM_LDS_BYTES, s, k);
-        else if (g_gemm_ablate == 1) hipLaunchKernelGGL((gemm_128x128_kernel<bf16_t, 1>), dim3(k.nwg), dim3(256), GEMM_LDS_BYTES, s, k);
-        else if (g_gemm_ablate == 2) hipLaunchKernelGGL((gemm_128x128_kernel<bf16_t, 2>), dim3(k.nwg), dim3(256), GEMM_LDS_BYTES, s, k);
-        else if (g_gemm_ablate == 3) hipLaunchKernelGGL((gemm_128x128_kernel<bf16_t, 3>), dim3(k.nwg), dim3(256), GEMM_LDS_BYTES, s, k);
-        else hipLaunchKernelGGL((gemm_128x128_kernel<bf16_t, 0>), dim3(k.nwg), dim3(256), GEMM_LDS_BYTES, s, k);
+        const int splits = g.slab ? ofx_gemm_splitk_plan(g.M, g.N, g.K) : 1;
+        k.splits = splits; k.slab = (float*)g.slab; k.m_slab = g.M;
+        k.kt_per_split = splits > 1 ? (g.K / BK + splits - 1) / splits : 0;
+        if (splits > 1) OFX_REQUIRE(g.slab_bytes >= (size_t)splits * g.M * g.N * 4, OFX_EWORKSPACE, "gemm: split-K slab too small");
+        const dim3 grid(k.nwg, splits > 1 ? splits : 1);
+        if (op_dtype == OFX_F16) hipLaunchKernelGGL((gemm_128x128_kernel<f16_t, 0>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
+        else if (g_gemm_ablate == 1) hipLaunchKernelGGL((gemm_128x128_kernel<bf16_t, 1>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
+        else if (g_gemm_ablate == 2) hipLaunchKernelGGL((gemm_128x128_kernel<bf16_t, 2>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
+        else if (g_gemm_ablate == 3) hipLaunchKernelGGL((gemm_128x128_kernel<bf16_t, 3>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
+        else hipLaunchKernelGGL((gemm_128x128_kernel<bf16_t, 0>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
+        if (splits > 1) {
+            size_t tot = (size_t)g.M * (g.N / 4);
+            int rg = (int)((tot + 255) / 256); if (rg > 2048) rg = 2048;
+            if (op_dtype == OFX_F16) hipLaunchKernelGGL(splitk_reduce_kernel<f16_t>, dim3(rg), dim3(256), 0, s, k);
+            else hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(rg), dim3(256), 0, s, k);
+        }
     }
     OFX_LAUNCH_CHECK();
     return OFX_OK;

@@ -117,11 +117,15 @@ struct GemmArgs {
     const float* bias;  // [N] or null
     const float* resid; // fp32 [M, ldr] or null; may alias C when out_kind == F32
     const int* m_dev = nullptr; // optional device-side live row count (<= M)
+    void* slab = nullptr;       // optional split-K scratch (fp32 [splits, M, N]); see ofx_gemm_splitk_bytes
+    size_t slab_bytes = 0;
     int M, N, K, lda, ldc, ldr;
     int act;            // ofx_act
     int out_kind;       // 0 fp32 | 1 operand type | 2 split3 (hi|lo|hi at column blocks of width N, ldc >= 3N; bf16 only)
 };
 int ofx_launch_gemm(const GemmArgs& g, int op_dtype /*OFX_BF16|OFX_F16*/, hipStream_t s);
+int ofx_gemm_splitk_plan(int M, int N, int K);
+size_t ofx_gemm_splitk_bytes(int M, int N, int K);
 
 struct LnArgs {
     const float* x;        // [rows_in, D] fp32

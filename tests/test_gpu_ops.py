@@ -79,6 +79,36 @@ def test_gemm_big_tile_kernels(kern, dt, M, N, K):
     assert rel_err(o3[:, :N] + o3[:, N:2 * N], z) < (3e-5 if dt == "bf16" else 1e-6 + 2e-6)
 
 
+@pytest.mark.parametrize("M,N,K,kind", [(288, 1024, 3072, 0), (544, 3072, 3072, 0), (100, 2048, 3072, 2), (2304, 1024, 6144, 0), (17, 128, 1024, 1)])
+def test_gemm_split_k_is_deterministic_and_exact(M, N, K, kind):
+    """Under-filled deep-K shapes (the set transformer at small batch) go through split-K: slab partials + a fused
+    reduce/epilogue in a fixed order -> same tolerance as the single-pass kernel and bit-identical run to run."""
+    lib = L.load()
+    g = np.random.default_rng(M + N + K)
+    A = to_op(g.standard_normal((M, K), dtype=np.float32), "bf16")
+    W = to_op(g.standard_normal((N, K), dtype=np.float32) / np.sqrt(K), "bf16")
+    bias = dev(g.standard_normal(N, dtype=np.float32))
+    x0 = dev(g.standard_normal((M, N), dtype=np.float32))
+    nb = lib.ofx_gemm_splitk_ws(M, N, K)
+    assert nb > 0, "shape was expected to be split"
+    slab = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    outs = []
+    for rep in range(2):
+        ld = N * (3 if kind == 2 else 1)
+        out = x0.clone() if kind == 0 else torch.zeros(M, ld, dtype=torch.bfloat16, device="cuda")
+        L.check(lib.ofx_gemm_splitk(A.data_ptr(), W.data_ptr(), out.data_ptr(), bias.data_ptr(), out.data_ptr() if kind == 0 else None,
+                                    M, N, K, K, ld, N if kind == 0 else 0, 3, kind, 1, slab.data_ptr(), nb, stream()))
+        outs.append(out.float().cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    z = O.mish(A.double().cpu().numpy() @ W.double().cpu().numpy().T + bias.double().cpu().numpy())
+    if kind == 0:
+        assert rel_err(outs[0], z + x0.double().cpu().numpy()) < 2e-5
+    elif kind == 1:
+        assert rel_err(outs[0], z) < 2 ** -8
+    else:
+        assert rel_err(outs[0][:, :N] + outs[0][:, N:2 * N], z) < 3e-5
+
+
 @pytest.mark.parametrize("act", [0, 1, 2, 3])
 def test_gemm_epilogue_bias_act_residual(act):
     M, N, K = 333, 256, 512
