@@ -222,3 +222,26 @@ def test_pool_sharded_topk_and_score_gather_world2_gloo(tmp_path):
                         "--master-port", str(port), str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("ok") == 2
+
+
+def test_embedding_store_roundtrip(tmp_path):
+    from outfitx_amd import embedding_store as S
+    g = np.random.default_rng(3)
+    ids0, ids1 = [5, 9, 2], [100, 7]
+    e0, e1 = g.standard_normal((3, 1024)).astype(np.float32), g.standard_normal((2, 1024)).astype(np.float32)
+    S.save_pickle_shard(str(tmp_path), "fashion-clip", 1, ids1, e1)
+    p0 = S.save_pickle_shard(str(tmp_path), "fashion-clip", 0, ids0, e0)
+    assert os.path.basename(p0) == "fashion-clip_embedding_subset_0.pkl"          # the reference's file name
+    with open(p0, "rb") as f:
+        d = pickle.load(f)
+    assert set(d) == {"ids", "embeddings"} and d["embeddings"].dtype == np.float32      # and its layout
+    ids, emb = S.load_pickle_shards(str(tmp_path), "fashion-clip")
+    assert ids.tolist() == ids0 + ids1 and np.array_equal(emb, np.concatenate([e0, e1]))
+    S.convert_to_mmap(str(tmp_path), "fashion-clip")
+    t = S.EmbeddingTable.open(str(tmp_path), "fashion-clip")
+    assert isinstance(t.embeddings, np.memmap)
+    assert np.array_equal(t.gather([7, 5, 7, 2]), np.stack([e1[1], e0[0], e1[1], e0[2]]))
+    with pytest.raises(KeyError):
+        t.gather([12345])
+    with pytest.raises(FileNotFoundError):
+        S.load_pickle_shards(str(tmp_path), "other-model")

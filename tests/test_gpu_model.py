@@ -219,3 +219,58 @@ def test_errors_are_python_exceptions(model):
     with pytest.raises(Exception):
         model.cpu()(task=CP, outfit_embedding=torch.zeros(1, 16, 1024), outfit_mask=torch.zeros(1, 16, dtype=torch.bool))
     model.cuda()
+
+
+def test_edge_cases_empty_full_and_long_outfits(model):
+    """Edge cases the collate can produce: outfits with 0 items (all slots masked), exactly full outfits, B = 1,
+    L = 31 (the kernel limit) and L = 0 (prefix token only)."""
+    CP, CIR = tasks()[0], tasks()[1]
+    W = synth.outfit_transformer_weights(W_SEED)
+    for B, L, n in ((1, 16, [0]), (3, 16, [0, 16, 1]), (5, 31, [31, 0, 17, 30, 2]), (2, 1, [1, 0])):
+        emb, mask = synth.outfit_batch(71 + B, B, L, np.asarray(n))
+        txt = synth.unit_rows(71, "t", B, 512)
+        with torch.no_grad():
+            cp = model(task=CP, outfit_embedding=cu(emb), outfit_mask=cu(mask)).cpu().numpy()
+            cir = model(task=CIR, outfit_embedding=cu(emb), outfit_mask=cu(mask), target_item_text_embedding=cu(txt)).cpu().numpy()
+        assert np.isfinite(cp).all() and np.isfinite(cir).all()
+        assert rel_err(cp, O.cp_forward(emb, mask, W)) < 1e-3
+        assert rel_err(cir, O.cir_forward(emb, mask, txt, W)) < 1e-3
+    with torch.no_grad():                                        # L = 0: nothing but the prefix token
+        cp0 = model(task=CP, outfit_embedding=torch.zeros(4, 0, 1024, device="cuda"), outfit_mask=torch.zeros(4, 0, dtype=torch.bool, device="cuda"))
+    want = O.cp_forward(np.zeros((4, 0, 1024), np.float32), np.zeros((4, 0), bool), W)
+    assert rel_err(cp0.cpu().numpy(), want) < 1e-3
+    with pytest.raises(Exception):                               # beyond the 31-item kernel limit: loud failure, not garbage
+        model(task=CP, outfit_embedding=torch.zeros(1, 40, 1024, device="cuda"), outfit_mask=torch.zeros(1, 40, dtype=torch.bool, device="cuda"))
+
+
+def test_c_abi_error_codes():
+    import ctypes as C
+    from outfitx_amd import _lib as L
+    lib = L.load()
+    d = L.default_desc()
+    h = lib.ofx_create(0, C.byref(d))
+    assert h
+    x = torch.zeros(2, 16, 1024, device="cuda"); m = torch.zeros(2, 16, dtype=torch.uint8, device="cuda"); o = torch.zeros(2, 1024, device="cuda")
+    ws = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    rc = lib.ofx_set_encoder_fwd(h, x.data_ptr(), m.data_ptr(), None, 0, 2, 16, o.data_ptr(), ws.data_ptr(), ws.numel(), s)
+    assert rc == -5 and b"not packed" in lib.ofx_last_error()                     # OFX_ESTATE
+    rc = lib.ofx_vit_b32_fwd(h, x.data_ptr(), 1, o.data_ptr(), 1024, 0, 1, ws.data_ptr(), ws.numel(), s)
+    assert rc == -5
+    bad = L.default_desc(); bad.d_model = 1000
+    assert not lib.ofx_create(0, C.byref(bad)) and b"d_model" in lib.ofx_last_error()
+    assert lib.ofx_tune(99, 0) == -1
+    lib.ofx_destroy(h)
+    # too-small workspace on a packed model
+    from outfitx_amd.engine import Engine
+    eng = Engine(torch.device("cuda", 0))
+    Wt = synth.outfit_transformer_weights(W_SEED)
+    order = ["outfit_token", "target_item_image_emb", "cp_ffn.1.weight", "cp_ffn.1.bias", "cir_ffn.0.weight"]
+    for i in range(6):
+        p = f"transformer_encoder.layers.{i}."
+        order += [p + k for k in ("self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight", "self_attn.out_proj.bias",
+                                  "linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias", "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")]
+    eng.pack_outfit([torch.from_numpy(Wt[k]).cuda() for k in order])
+    rc = lib.ofx_set_encoder_fwd(eng.h, x.data_ptr(), m.data_ptr(), None, 0, 2, 16, o.data_ptr(), ws.data_ptr(), 1024, s)
+    assert rc == -4 and b"workspace" in lib.ofx_last_error()                      # OFX_EWORKSPACE
+    torch.cuda.synchronize()
