@@ -73,12 +73,20 @@ def main():
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    # OFX_BENCH_REHEARSAL=1: every rank uses GPU 0 and the collectives go over gloo - a control-flow rehearsal of the
+    # N>1 path on a one-GPU box (its numbers mean nothing).  Normal runs: one rank per GPU over RCCL.
+    rehearsal = os.environ.get("OFX_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from src.models import OutfitX
     from src.models.configs import ItemEncoderConfig, OutfitXConfig
@@ -136,7 +144,7 @@ def main():
     L.check(lib.ofx_profile_read(bms, bfl, bcnt), "ofx_profile_read")
     lib.ofx_profile_enable(0)
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
