@@ -24,7 +24,8 @@ extern "C" {
 
 enum { OFX_OK = 0, OFX_EINVAL = -1, OFX_ESHAPE = -2, OFX_EHIP = -3, OFX_EWORKSPACE = -4, OFX_ESTATE = -5 };
 enum ofx_dtype { OFX_F32 = 0, OFX_BF16 = 1, OFX_F16 = 2 };
-enum ofx_act { OFX_ACT_NONE = 0, OFX_ACT_QUICK_GELU = 1, OFX_ACT_GELU = 2, OFX_ACT_MISH = 3 };
+/* OFX_ACT_MISH_GRAD (backward): out = acc * mish'(resid) - `resid` then carries the saved pre-activation, not an addend */
+enum ofx_act { OFX_ACT_NONE = 0, OFX_ACT_QUICK_GELU = 1, OFX_ACT_GELU = 2, OFX_ACT_MISH = 3, OFX_ACT_MISH_GRAD = 4 };
 /* MFMA operand precision of a sub-model.  BF16X3 = three bf16 products per term
  * (hi*hi + lo*hi + hi*lo, realised as one K-concatenated GEMM) ~ fp32-grade results. */
 enum ofx_precision { OFX_PREC_BF16 = 0, OFX_PREC_F16 = 1, OFX_PREC_BF16X3 = 2 };
@@ -121,6 +122,22 @@ int ofx_l2_topk(ofx_handle* h, const float* Q, const float* P, int nq, int np, i
                 int64_t* idx, float* dist, void* ws, size_t ws_bytes, ofx_stream stream);
 /* Merge `parts` candidate lists (after the RCCL all-gather of per-shard top-k): in [parts,nq,k]. */
 int ofx_topk_merge(const int64_t* idx_in, const float* dist_in, int parts, int nq, int k, int64_t* idx, float* dist,
+                   ofx_stream stream);
+
+/* ------------------------------------------------------------------ training step ("next" row N1) --- */
+/* CP path on precomputed embeddings with a tape, and its backward: what torch autograd computes for the reference's
+ * CP trainer step (compatibility_prediction_trainer.py:57-81) with dropout = 0.  Needs outfit_precision BF16 or F16.
+ * grads: one fp32 buffer, layout from ofx_cp_train_grad_floats (offsets per packed tensor, padded shapes:
+ * linear1 [ffn_pad, D], linear2 [D, ffn_pad], ffn_pad = d_ffn rounded up to 128). */
+size_t ofx_cp_train_tape_bytes(ofx_handle* h, int B, int L);
+size_t ofx_cp_train_ws_bytes(ofx_handle* h, int B, int L);
+size_t ofx_cp_train_grad_floats(ofx_handle* h, size_t* offsets, int n_offsets);
+int ofx_cp_train_fwd(ofx_handle* h, const float* x, const uint8_t* pad_mask, int B, int L, float* logits, void* tape, size_t tape_bytes,
+                     void* ws, size_t ws_bytes, ofx_stream stream);
+int ofx_cp_train_bwd(ofx_handle* h, void* tape, size_t tape_bytes, const float* dlogits, int B, int L, float* grads, size_t grad_floats,
+                     void* ws, size_t ws_bytes, ofx_stream stream);
+/* FocalLoss(alpha, gamma, mean) forward and d loss / d logits * upstream (src/losses/focal_loss.py:23-41). loss / dlogits may be NULL. */
+int ofx_focal_loss(const float* logits, const float* labels, int B, float alpha, float gamma, float upstream, float* loss, float* dlogits,
                    ofx_stream stream);
 
 /* ------------------------------------------------------------------ profiling --------------- */

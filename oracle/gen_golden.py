@@ -196,6 +196,48 @@ def main():
                         proc_mask=bd["input_dict"]["outfit_mask"].numpy(), proc_label=bd["label"].numpy(), meta=str(meta))
     print("focal", fl, "proc", tuple(bd["input_dict"]["outfit_embedding"].shape))
 
+    # ---- 8. one CP training step (next row N1): reference model in train() mode, dropout 0, fp32 --------
+    # cp_trainer:57-81 with accumulation 1 and no AMP: forward -> FocalLoss(.75, 2) -> backward -> clip_grad_norm_(1.0)
+    # -> AdamW(lr) step.  Saved: loss, logits, per-parameter gradient norms, full small gradients, a strided sample of
+    # the big ones, the clip norm and two post-step parameters.
+    torch.set_grad_enabled(True)
+    cfg0 = C.OutfitXConfig(item_encoder=C.ItemEncoderConfig(type="clip"))
+    cfg0.transformer.dropout = 0.0
+    m2 = M.OutfitX(cfg0)
+    m2.load_state_dict(sd, strict=True)
+    m2.train()
+    n_tr = np.array([1, 2, 3, 5, 8, 8, 11, 16, 4, 7, 8, 6])
+    emb, mask = synth.outfit_batch(1244, len(n_tr), 16, n_tr)
+    labels = (np.arange(len(n_tr)) % 2).astype(np.float32)
+    params = {k: v for k, v in m2.named_parameters() if not k.startswith("item_encoder.")}
+    lr = 1e-3
+    opt = torch.optim.AdamW(list(params.values()), lr=lr)
+    opt.zero_grad()
+    y_hat = m2(task=CP, outfit_embedding=t(emb), outfit_mask=t(mask)).squeeze(-1)
+    loss = FocalLoss(alpha=0.75, gamma=2, reduction="mean")(y_hat=y_hat, y_true=t(labels))
+    loss.backward()
+    out = dict(seed=1244, n_items=n_tr, labels=labels, emb_crc=synth.checksum(emb), logits=y_hat.detach().numpy(),
+               loss=float(loss), lr=lr, meta=str(meta))
+    names, norms = [], []
+    for k, v in params.items():
+        if v.grad is None:
+            continue
+        g_ = v.grad.detach().numpy()
+        names.append(k); norms.append(float(np.sqrt((g_.astype(np.float64) ** 2).sum())))
+        if g_.size <= 4096:
+            out["grad/" + k] = g_.copy()
+        else:
+            out["gsample/" + k] = g_.ravel()[::1009].copy()
+    out["grad_names"] = np.asarray(names); out["grad_norms"] = np.asarray(norms)
+    out["no_grad_names"] = np.asarray([k for k, v in params.items() if v.grad is None])
+    out["clip_norm"] = float(torch.nn.utils.clip_grad_norm_(list(params.values()), max_norm=1.0))
+    opt.step()
+    out["post/outfit_token"] = m2.outfit_token.detach().numpy()
+    out["post/cp_ffn.1.weight"] = m2.cp_ffn[1].weight.detach().numpy()
+    out["post/transformer_encoder.layers.0.norm1.weight"] = m2.transformer_encoder.layers[0].norm1.weight.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "train_step.npz"), **out)
+    print("train step: loss", float(loss), "clip norm", out["clip_norm"], "params with grad", len(names))
+
 
 if __name__ == "__main__":
     main()

@@ -55,6 +55,12 @@ SIGNATURES = {
     "ofx_fitb_argmin": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "ofx_l2_topk": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i64, _vp, _vp, _vp, _sz, _vp]),
     "ofx_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ofx_cp_train_tape_bytes": (_sz, [_vp, _i, _i]),
+    "ofx_cp_train_ws_bytes": (_sz, [_vp, _i, _i]),
+    "ofx_cp_train_grad_floats": (_sz, [_vp, C.POINTER(_sz), _i]),
+    "ofx_cp_train_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "ofx_cp_train_bwd": (_i, [_vp, _vp, _sz, _vp, _i, _i, _vp, _sz, _vp, _sz, _vp]),
+    "ofx_focal_loss": (_i, [_vp, _vp, _i, _f, _f, _f, _vp, _vp, _vp]),
     "ofx_profile_enable": (None, [_i]),
     "ofx_profile_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "ofx_tune": (_i, [_i, _i]),

@@ -67,6 +67,18 @@ extern "C" int ofx_profile_read(double* ms, double* flops, long long* launches) 
     return OFX_OK;
 }
 
+int ofx_launch_cast_transpose(const void* src, int src_is_f32, int ld_src, void* row_out, int ld_row, void* t_out, int Mpad, int C,
+                              const int* m_dev, int M, int op_dtype, hipStream_t s);
+int ofx_launch_colsum(const void* x, int x_is_f32, int ld, float* out, float* part, int C, const int* m_dev, int M, int accumulate, int op_dtype, hipStream_t s);
+int ofx_launch_ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* add, float* dx_out,
+                      float* dgamma, float* dbeta, float* part, int D, const int* m_dev, int M, int accumulate, hipStream_t s);
+size_t ofx_ln_bwd_part_floats(int D);
+int ofx_launch_set_attention_bwd(const float* qkv, const float* d_o, float* dqkv, const int* cu, int nseq, int n_head, int D, int max_len,
+                                 float scale, hipStream_t s);
+int ofx_launch_focal_loss(const float* logits, const float* labels, int B, float alpha, float gamma, float upstream, float* loss, float* dlogits, hipStream_t s);
+int ofx_launch_cp_head_bwd(const float* dlogits, const float* row0, const float* w, float* d_row0, float* dw, float* db, int B, int D, int accumulate, hipStream_t s);
+int ofx_launch_scatter_row0(const float* d_row0, const int* cu, float* dX, int B, int D, int M, const int* m_dev, hipStream_t s);
+int ofx_launch_prefix_grad(const float* dX, const int* cu, float* out, int B, int D, int c0, int n, int accumulate, hipStream_t s);
 int ofx_launch_fitb(const float* y, const float* cand, int B, int C, int D, int64_t* idx, float* dist, hipStream_t s);
 int ofx_launch_l2_topk(const float* Q, const float* P, int nq, int np, int D, int k, int64_t index_base, int64_t* idx,
                        float* dist, void* ws, size_t ws_bytes, hipStream_t s);
@@ -110,7 +122,8 @@ struct Arena {                                      // library-owned HBM for pac
     void release() { if (base) (void)hipFree(base); base = nullptr; cap = off = 0; }
 };
 
-struct OutfitLayer { void *w_in, *w_out, *w_1, *w_2; float *b_in, *b_out, *b_1, *b_2, *g1, *be1, *g2, *be2; };
+struct OutfitLayer { void *w_in, *w_out, *w_1, *w_2; float *b_in, *b_out, *b_1, *b_2, *g1, *be1, *g2, *be2;
+                     void *w_in_t, *w_out_t, *w_1_t, *w_2_t; };   // transposed operand copies (dgrad), single-product precisions only
 struct ClipLayer { void *w_qkv, *w_o, *w_fc1, *w_fc2; float *b_qkv, *b_o, *b_fc1, *b_fc2, *g1, *be1, *g2, *be2; };
 
 }  // namespace
@@ -187,7 +200,8 @@ extern "C" int ofx_pack_outfit_weights(ofx_handle* h, const void* const* P, int 
     hipStream_t s = (hipStream_t)stream;
     const size_t D = d.d_model, F = d.d_ffn, Fp = h->ot_ffn_pad, km = h->ot_kmul;
     const size_t per_layer = 2 * km * (3 * D * D + D * D + Fp * D + D * Fp) + 4 * (3 * D + D + Fp + D + 4 * D) + 16 * 256;
-    TRY(h->a_out.reserve(per_layer * d.n_layers + 2 * km * D * D + 4 * (3 * D + 8) + 16 * 256));
+    const size_t per_layer_t = km == 1 ? 2 * (3 * D * D + D * D + 2 * Fp * D) + 8 * 256 : 0;
+    TRY(h->a_out.reserve((per_layer + per_layer_t) * d.n_layers + 2 * km * D * D + 4 * (3 * D + 8) + 16 * 256));
     Arena& A = h->a_out;
     const int dt = h->ot_dtype, mode = km == 3 ? 2 : 0;
     h->outfit_token = A.take<float>(D); TRY(copy_f32(h->outfit_token, P[0], D, s));
@@ -211,6 +225,14 @@ extern "C" int ofx_pack_outfit_weights(ofx_handle* h, const void* const* P, int 
         L.be1 = A.take<float>(D); TRY(copy_f32(L.be1, q[9], D, s));
         L.g2 = A.take<float>(D); TRY(copy_f32(L.g2, q[10], D, s));
         L.be2 = A.take<float>(D); TRY(copy_f32(L.be2, q[11], D, s));
+        L.w_in_t = L.w_out_t = L.w_1_t = L.w_2_t = nullptr;
+        if (km == 1) {      // W^T copies for the backward dgrad GEMMs: [K_w, N_w] operand, zero padded
+            L.w_in_t = A.take<char>(2 * D * 3 * D); TRY(ofx_launch_cast_transpose(q[0], 1, (int)D, nullptr, 0, L.w_in_t, (int)(3 * D), (int)D, nullptr, (int)(3 * D), dt, s));
+            L.w_out_t = A.take<char>(2 * D * D); TRY(ofx_launch_cast_transpose(q[2], 1, (int)D, nullptr, 0, L.w_out_t, (int)D, (int)D, nullptr, (int)D, dt, s));
+            L.w_1_t = A.take<char>(2 * D * Fp); TRY(ofx_launch_cast_transpose(q[4], 1, (int)D, nullptr, 0, L.w_1_t, (int)Fp, (int)D, nullptr, (int)F, dt, s));
+            L.w_2_t = A.take<char>(2 * Fp * D); OFX_HIP(hipMemsetAsync(L.w_2_t, 0, 2 * Fp * D, s));
+            TRY(ofx_launch_cast_transpose(q[6], 1, (int)F, nullptr, 0, L.w_2_t, (int)D, (int)F, nullptr, (int)D, dt, s));
+        }
     }
     OFX_REQUIRE(A.off <= A.cap, OFX_ESTATE, "pack_outfit: arena overflow");
     h->out_ready = true;
@@ -559,6 +581,194 @@ extern "C" int ofx_l2_topk(ofx_handle*, const float* Q, const float* P, int nq, 
 }
 extern "C" int ofx_topk_merge(const int64_t* idx_in, const float* dist_in, int parts, int nq, int k, int64_t* idx, float* dist, ofx_stream stream) {
     return ofx_launch_topk_merge(idx_in, dist_in, parts, nq, k, idx, dist, (hipStream_t)stream);
+}
+
+
+static bool d_outfit_act_is_mish(const ofx_handle* h) { return h->d.outfit_act == OFX_ACT_MISH; }
+// ====================================================================================== training step (N1)
+// Forward with a tape + backward of the CP path on precomputed embeddings.  Single-product operand precisions only
+// (bf16 / f16, like the reference's AMP training); dropout is NOT applied (the caller must use dropout = 0).
+namespace {
+struct TapeLayer { float* Xin; float* st1; char* H1; float* QKV; char* O; float* Xmid; float* st2; char* H2; float* Upre; char* A; };
+struct Tape { int* cu; float* Xfinal; float* row0; std::vector<TapeLayer> L; size_t bytes; };
+size_t carve_tape(const ofx_handle* h, Bump& b, int B, int Lq, Tape* t) {
+    const size_t M = (size_t)B * (Lq + 1), D = h->d.d_model, Fp = h->ot_ffn_pad;
+    Tape tp;
+    tp.cu = b.take<int>(B + 1);
+    tp.row0 = b.take<float>((size_t)B * D);
+    tp.L.resize(h->d.n_layers);
+    for (TapeLayer& l : tp.L) {
+        l.Xin = b.take<float>(M * D); l.st1 = b.take<float>(M * 2); l.H1 = b.take<char>(M * D * 2); l.QKV = b.take<float>(M * 3 * D);
+        l.O = b.take<char>(M * D * 2); l.Xmid = b.take<float>(M * D); l.st2 = b.take<float>(M * 2); l.H2 = b.take<char>(M * D * 2);
+        l.Upre = b.take<float>(M * Fp); l.A = b.take<char>(M * Fp * 2);
+    }
+    tp.Xfinal = b.take<float>(M * D);
+    tp.bytes = align_up(b.off, 256);
+    if (t) *t = tp;
+    return tp.bytes;
+}
+struct BwdWs { float *dXa, *dXb_f, *dH, *dO, *dQKV, *d_row0, *part; char *gXb, *gXbT, *dU, *dUT, *gQb, *gQbT, *actT; char* slab; size_t slab_bytes; int Mpad; };
+size_t carve_bwd(const ofx_handle* h, Bump& b, int B, int Lq, BwdWs* w) {
+    const size_t M = (size_t)B * (Lq + 1), D = h->d.d_model, Fp = h->ot_ffn_pad, Mpad = align_up(M, 64);
+    BwdWs t;
+    t.Mpad = (int)Mpad;
+    t.dXa = b.take<float>(M * D); t.dXb_f = b.take<float>(M * D); t.dH = b.take<float>(M * D); t.dO = b.take<float>(M * D);
+    t.dQKV = b.take<float>(M * 3 * D); t.d_row0 = b.take<float>((size_t)B * D);
+    t.part = b.take<float>(std::max<size_t>(ofx_ln_bwd_part_floats((int)D), (size_t)32 * 3 * D + 32 * Fp));
+    t.gXb = b.take<char>(M * D * 2); t.gXbT = b.take<char>(D * Mpad * 2);
+    t.dU = b.take<char>(M * Fp * 2); t.dUT = b.take<char>(Fp * Mpad * 2);
+    t.gQb = b.take<char>(M * 3 * D * 2); t.gQbT = b.take<char>(3 * D * Mpad * 2);
+    t.actT = b.take<char>(Fp * Mpad * 2);
+    t.slab_bytes = 0;
+    const int mp = (int)Mpad, Di = (int)D, Fi = (int)Fp;
+    for (auto s : {ofx_gemm_splitk_bytes(Di, Fi, mp), ofx_gemm_splitk_bytes(Fi, Di, mp), ofx_gemm_splitk_bytes(Di, Di, mp), ofx_gemm_splitk_bytes(3 * Di, Di, mp),
+                   ofx_gemm_splitk_bytes((int)M, Fi, Di), ofx_gemm_splitk_bytes((int)M, Di, Fi), ofx_gemm_splitk_bytes((int)M, Di, Di), ofx_gemm_splitk_bytes((int)M, Di, 3 * Di)})
+        t.slab_bytes = std::max(t.slab_bytes, s);
+    t.slab = b.take<char>(t.slab_bytes);
+    if (w) *w = t;
+    return align_up(b.off, 256);
+}
+// gradient buffer layout (floats), pack order, padded shapes: [outfit_token D][tgt_img D/2][cp_w D][cp_b 1][cir_w D*D] then per layer
+// [Win 3D*D][bin 3D][Wo D*D][bo D][W1 Fp*D][b1 Fp][W2 D*Fp][b2 D][g1 D][be1 D][g2 D][be2 D]
+void grad_offsets(const ofx_handle* h, std::vector<size_t>& off, size_t* total) {
+    const size_t D = h->d.d_model, Fp = h->ot_ffn_pad;
+    size_t o = 0;
+    auto add = [&](size_t n) { off.push_back(o); o += (n + 63) / 64 * 64; };
+    add(D); add(D / 2); add(D); add(1); add(D * D);
+    for (int l = 0; l < h->d.n_layers; ++l) { add(3 * D * D); add(3 * D); add(D * D); add(D); add(Fp * D); add(Fp); add(D * Fp); add(D); add(D); add(D); add(D); add(D); }
+    *total = o;
+}
+}  // namespace
+
+extern "C" size_t ofx_cp_train_tape_bytes(ofx_handle* h, int B, int L) { Bump b(nullptr, ~(size_t)0); return h ? carve_tape(h, b, B, L, nullptr) : 0; }
+extern "C" size_t ofx_cp_train_ws_bytes(ofx_handle* h, int B, int L) {
+    if (!h) return 0;
+    Bump b(nullptr, ~(size_t)0);
+    const size_t bw = carve_bwd(h, b, B, L, nullptr);
+    Bump f(nullptr, ~(size_t)0);
+    return std::max(bw, align_up(carve_set(h, f, B, L, nullptr), 256));
+}
+extern "C" size_t ofx_cp_train_grad_floats(ofx_handle* h, size_t* offsets, int n) {
+    if (!h) return 0;
+    std::vector<size_t> off; size_t total;
+    grad_offsets(h, off, &total);
+    if (offsets) for (int i = 0; i < n && i < (int)off.size(); ++i) offsets[i] = off[i];
+    return total;
+}
+
+extern "C" int ofx_cp_train_fwd(ofx_handle* h, const float* x, const uint8_t* pad_mask, int B, int L, float* logits, void* tape_mem,
+                                size_t tape_bytes, void* ws, size_t ws_bytes, ofx_stream stream) {
+    OFX_REQUIRE(h && h->out_ready, OFX_ESTATE, "cp_train_fwd: outfit weights not packed");
+    OFX_REQUIRE(h->ot_kmul == 1, OFX_ESTATE, "cp_train_fwd: training uses a single-product precision (bf16 / f16), not bf16x3");
+    OFX_REQUIRE(B > 0 && L >= 0 && L <= 31 && (x || L == 0) && (pad_mask || L == 0) && logits && tape_mem, OFX_EINVAL, "cp_train_fwd: bad argument");
+    const ofx_model_desc& d = h->d;
+    hipStream_t s = (hipStream_t)stream;
+    Bump tb(tape_mem, tape_bytes);
+    Tape T;
+    carve_tape(h, tb, B, L, &T);
+    OFX_REQUIRE(tb.ok, OFX_EWORKSPACE, "cp_train_fwd: tape %zu < %zu bytes", tape_bytes, T.bytes);
+    Bump wb(ws, ws_bytes);
+    SetWs w;
+    carve_set(h, wb, B, L, &w);
+    OFX_REQUIRE(wb.ok, OFX_EWORKSPACE, "cp_train_fwd: workspace too small");
+    const int D = d.d_model, Fp = h->ot_ffn_pad, dt = h->ot_dtype, M = B * (L + 1);
+    TRY(ofx_launch_set_build(x, pad_mask, h->outfit_token, 0, T.cu, T.L[0].Xin, B, L, D, s));
+    const int* m_dev = T.cu + B;
+    for (int l = 0; l < d.n_layers; ++l) {
+        const OutfitLayer& Ly = h->ol[l];
+        TapeLayer& t = T.L[l];
+        float* Xnext = l + 1 < d.n_layers ? T.L[l + 1].Xin : T.Xfinal;
+        LnArgs ln{t.Xin, nullptr, Ly.g1, Ly.be1, t.H1, M, D, D, OFX_OUT_OP, d.ln_eps}; ln.stats = t.st1;
+        TRY(ofx_launch_layernorm_dev(ln, m_dev, dt, s));
+        GemmArgs g1{}; g1.A = t.H1; g1.W = Ly.w_in; g1.C = t.QKV; g1.bias = Ly.b_in; g1.m_dev = m_dev; g1.M = M; g1.N = 3 * D; g1.K = D; g1.lda = D;
+        g1.ldc = 3 * D; g1.out_kind = OFX_OUT_F32; g1.slab = w.slab; g1.slab_bytes = w.slab_bytes;
+        TRY(ofx_launch_gemm(g1, dt, s));
+        SetAttnArgs sa{t.QKV, t.O, T.cu, B, d.n_head, D, D, OFX_OUT_OP, L + 1, 0, 0.125f};
+        TRY(ofx_launch_set_attention(sa, dt, s));
+        GemmArgs g2{}; g2.A = t.O; g2.W = Ly.w_out; g2.C = t.Xmid; g2.bias = Ly.b_out; g2.resid = t.Xin; g2.m_dev = m_dev; g2.M = M; g2.N = D; g2.K = D;
+        g2.lda = D; g2.ldc = D; g2.ldr = D; g2.out_kind = OFX_OUT_F32; g2.slab = w.slab; g2.slab_bytes = w.slab_bytes;
+        TRY(ofx_launch_gemm(g2, dt, s));
+        LnArgs ln2{t.Xmid, nullptr, Ly.g2, Ly.be2, t.H2, M, D, D, OFX_OUT_OP, d.ln_eps}; ln2.stats = t.st2;
+        TRY(ofx_launch_layernorm_dev(ln2, m_dev, dt, s));
+        GemmArgs g3{}; g3.A = t.H2; g3.W = Ly.w_1; g3.C = t.A; g3.bias = Ly.b_1; g3.aux_out = t.Upre; g3.m_dev = m_dev; g3.M = M; g3.N = Fp; g3.K = D;
+        g3.lda = D; g3.ldc = Fp; g3.act = d.outfit_act; g3.out_kind = OFX_OUT_OP; g3.slab = w.slab; g3.slab_bytes = w.slab_bytes;
+        TRY(ofx_launch_gemm(g3, dt, s));
+        GemmArgs g4{}; g4.A = t.A; g4.W = Ly.w_2; g4.C = Xnext; g4.bias = Ly.b_2; g4.resid = t.Xmid; g4.m_dev = m_dev; g4.M = M; g4.N = D; g4.K = Fp;
+        g4.lda = Fp; g4.ldc = D; g4.ldr = D; g4.out_kind = OFX_OUT_F32; g4.slab = w.slab; g4.slab_bytes = w.slab_bytes;
+        TRY(ofx_launch_gemm(g4, dt, s));
+    }
+    TRY(ofx_launch_gather_row0(T.Xfinal, T.cu, T.row0, B, D, s));
+    return ofx_launch_cp_head(T.row0, h->cp_w, h->cp_b, logits, B, D, s);
+}
+
+extern "C" int ofx_cp_train_bwd(ofx_handle* h, void* tape_mem, size_t tape_bytes, const float* dlogits, int B, int L, float* grads,
+                                size_t grad_floats, void* ws, size_t ws_bytes, ofx_stream stream) {
+    OFX_REQUIRE(h && h->out_ready && h->ot_kmul == 1, OFX_ESTATE, "cp_train_bwd: needs packed single-product weights");
+    OFX_REQUIRE(tape_mem && dlogits && grads && ws && B > 0, OFX_EINVAL, "cp_train_bwd: bad argument");
+    OFX_REQUIRE(d_outfit_act_is_mish(h), OFX_ESTATE, "cp_train_bwd: only the Mish activation has a backward epilogue");
+    const ofx_model_desc& d = h->d;
+    hipStream_t s = (hipStream_t)stream;
+    Bump tb(tape_mem, tape_bytes);
+    Tape T;
+    carve_tape(h, tb, B, L, &T);
+    OFX_REQUIRE(tb.ok, OFX_EWORKSPACE, "cp_train_bwd: tape too small");
+    Bump wb(ws, ws_bytes);
+    BwdWs w;
+    carve_bwd(h, wb, B, L, &w);
+    OFX_REQUIRE(wb.ok, OFX_EWORKSPACE, "cp_train_bwd: workspace %zu < %zu bytes", ws_bytes, wb.off);
+    std::vector<size_t> off; size_t total;
+    grad_offsets(h, off, &total);
+    OFX_REQUIRE(grad_floats >= total, OFX_EWORKSPACE, "cp_train_bwd: gradient buffer %zu < %zu floats", grad_floats, total);
+    const int D = d.d_model, Fp = h->ot_ffn_pad, dt = h->ot_dtype, M = B * (L + 1), Mpad = w.Mpad;
+    const int* m_dev = T.cu + B;
+    auto G = [&](int i) { return grads + off[i]; };
+    auto gemm = [&](const void* A, int lda, const void* W, void* C, int ldc, int m, int n, int k, int out_kind, int act, const float* resid, int ldr, const int* md) {
+        GemmArgs g{}; g.A = A; g.W = W; g.C = C; g.M = m; g.N = n; g.K = k; g.lda = lda; g.ldc = ldc; g.out_kind = out_kind; g.act = act; g.resid = resid; g.ldr = ldr;
+        g.m_dev = md; g.slab = w.slab; g.slab_bytes = w.slab_bytes;
+        return ofx_launch_gemm(g, dt, s);
+    };
+    // head: logits = row0 . w + b
+    TRY(ofx_launch_cp_head_bwd(dlogits, T.row0, h->cp_w, w.d_row0, G(2), G(3), B, D, 0, s));
+    float* dX = w.dXa; float* dX2 = w.dXb_f;
+    TRY(ofx_launch_scatter_row0(w.d_row0, T.cu, dX, B, D, M, m_dev, s));
+    for (int l = d.n_layers - 1; l >= 0; --l) {
+        const OutfitLayer& Ly = h->ol[l];
+        const TapeLayer& t = T.L[l];
+        const int g0 = 5 + 12 * l;                    // Win, bin, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2
+        // ---- FFN branch: Xout = Xmid + mish(H2 W1^T + b1) W2^T + b2
+        TRY(ofx_launch_cast_transpose(dX, 1, D, w.gXb, D, w.gXbT, Mpad, D, m_dev, M, dt, s));
+        TRY(ofx_launch_colsum(dX, 1, D, G(g0 + 7), w.part, D, m_dev, M, 0, dt, s));
+        TRY(ofx_launch_cast_transpose(t.A, 0, Fp, nullptr, 0, w.actT, Mpad, Fp, m_dev, M, dt, s));
+        TRY(gemm(w.gXbT, Mpad, w.actT, G(g0 + 6), Fp, D, Fp, Mpad, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nullptr));             // dW2 [D, Fp]
+        TRY(gemm(w.gXb, D, Ly.w_2_t, w.dU, Fp, M, Fp, D, OFX_OUT_OP, OFX_ACT_MISH_GRAD, t.Upre, Fp, m_dev));                      // dU = (dX W2) * mish'(Upre)
+        TRY(ofx_launch_cast_transpose(w.dU, 0, Fp, nullptr, 0, w.dUT, Mpad, Fp, m_dev, M, dt, s));
+        TRY(ofx_launch_colsum(w.dU, 0, Fp, G(g0 + 5), w.part, Fp, m_dev, M, 0, dt, s));
+        TRY(ofx_launch_cast_transpose(t.H2, 0, D, nullptr, 0, w.actT, Mpad, D, m_dev, M, dt, s));
+        TRY(gemm(w.dUT, Mpad, w.actT, G(g0 + 4), D, Fp, D, Mpad, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nullptr));                // dW1 [Fp, D]
+        TRY(gemm(w.dU, Fp, Ly.w_1_t, w.dH, D, M, D, Fp, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, m_dev));                           // dH2
+        TRY(ofx_launch_ln_bwd(w.dH, t.Xmid, t.st2, Ly.g2, dX, dX2, G(g0 + 10), G(g0 + 11), w.part, D, m_dev, M, 0, s));         // dXmid
+        // ---- attention branch: Xmid = Xin + O Wo^T + bo
+        TRY(ofx_launch_cast_transpose(dX2, 1, D, w.gXb, D, w.gXbT, Mpad, D, m_dev, M, dt, s));
+        TRY(ofx_launch_colsum(dX2, 1, D, G(g0 + 3), w.part, D, m_dev, M, 0, dt, s));
+        TRY(ofx_launch_cast_transpose(t.O, 0, D, nullptr, 0, w.actT, Mpad, D, m_dev, M, dt, s));
+        TRY(gemm(w.gXbT, Mpad, w.actT, G(g0 + 2), D, D, D, Mpad, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nullptr));                // dWo [D, D]
+        TRY(gemm(w.gXb, D, Ly.w_out_t, w.dO, D, M, D, D, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, m_dev));                          // dO
+        TRY(ofx_launch_set_attention_bwd(t.QKV, w.dO, w.dQKV, T.cu, B, d.n_head, D, L + 1, 0.125f, s));
+        TRY(ofx_launch_cast_transpose(w.dQKV, 1, 3 * D, w.gQb, 3 * D, w.gQbT, Mpad, 3 * D, m_dev, M, dt, s));
+        TRY(ofx_launch_colsum(w.dQKV, 1, 3 * D, G(g0 + 1), w.part, 3 * D, m_dev, M, 0, dt, s));
+        TRY(ofx_launch_cast_transpose(t.H1, 0, D, nullptr, 0, w.actT, Mpad, D, m_dev, M, dt, s));
+        TRY(gemm(w.gQbT, Mpad, w.actT, G(g0 + 0), D, 3 * D, D, Mpad, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nullptr));            // dWin [3D, D]
+        TRY(gemm(w.gQb, 3 * D, Ly.w_in_t, w.dH, D, M, D, 3 * D, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, m_dev));                   // dH1
+        TRY(ofx_launch_ln_bwd(w.dH, t.Xin, t.st1, Ly.g1, dX2, dX, G(g0 + 8), G(g0 + 9), w.part, D, m_dev, M, 0, s));            // dXin
+    }
+    // shared prefix token: d outfit_token = sum_b dX0[cu[b]]
+    return ofx_launch_prefix_grad(dX, T.cu, G(0), B, D, 0, D, 0, s);
+}
+
+extern "C" int ofx_focal_loss(const float* logits, const float* labels, int B, float alpha, float gamma, float upstream, float* loss, float* dlogits,
+                              ofx_stream stream) {
+    OFX_REQUIRE(logits && labels && B > 0, OFX_EINVAL, "focal_loss: bad argument");
+    return ofx_launch_focal_loss(logits, labels, B, alpha, gamma, upstream, loss, dlogits, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------- tuning

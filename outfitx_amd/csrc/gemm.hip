@@ -35,6 +35,7 @@ struct KArgs {
     char* C;
     const float* bias;
     const float* resid;
+    float* aux_out;     // optional fp32 [M, N] pre-activation copy
     const int* m_dev;   // optional device-side row count (pad-free varlen sets); M is then the upper bound
     unsigned long long* dbg;   // diagnostics only (tools/gemm_bench.py --clock): per block {shader cycles, 100 MHz ticks} of the main loop
     int M, N, K, lda, ldc, ldr, act, out_kind, tiles_n, tiles_m, nwg, group_m, skew;
@@ -63,13 +64,20 @@ __device__ __forceinline__ void epilogue(const KArgs& p, OFX_LDS float* ep, int 
         f32x4 v = *(OFX_LDS f32x4*)(ep + row * EPI_STRIDE + col);
         if (gm < p.M) {
             v += bias4;
+            if (p.aux_out) *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn) = v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (ACT == OFX_ACT_QUICK_GELU) v[e] = act_quick_gelu(v[e]);
                 else if (ACT == OFX_ACT_GELU) v[e] = act_gelu(v[e]);
                 else if (ACT == OFX_ACT_MISH) v[e] = act_mish(v[e]);
             }
-            if (p.resid) v += *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn);
+            if (p.resid) {
+                const f32x4 rr = *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn);
+                if (ACT == OFX_ACT_MISH_GRAD) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= act_mish_grad(rr[e]);
+                } else v += rr;
+            }
             if (p.out_kind == 0) {
                 *(f32x4*)(p.C + ((size_t)gm * p.ldc + gn) * 4) = v;
             } else {
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (p.splits > 1) {                                  // raw partial sums; bias / activation / residual happen in splitk_reduce
         KArgs q = p;
-        q.C = (char*)(p.slab + (size_t)blockIdx.y * p.m_slab * p.N); q.ldc = p.N; q.out_kind = 0; q.bias = nullptr; q.resid = nullptr;
+        q.C = (char*)(p.slab + (size_t)blockIdx.y * p.m_slab * p.N); q.ldc = p.N; q.out_kind = 0; q.bias = nullptr; q.resid = nullptr; q.aux_out = nullptr;
         epilogue<T, OFX_ACT_NONE>(q, ep, m0 + wm * 64, n0 + wn * 64, lane);
         return;
     }
@@ -217,6 +225,7 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
         case OFX_ACT_QUICK_GELU: epilogue<T, OFX_ACT_QUICK_GELU>(p, ep, m0 + wm * 64, n0 + wn * 64, lane); break;
         case OFX_ACT_GELU: epilogue<T, OFX_ACT_GELU>(p, ep, m0 + wm * 64, n0 + wn * 64, lane); break;
         case OFX_ACT_MISH: epilogue<T, OFX_ACT_MISH>(p, ep, m0 + wm * 64, n0 + wn * 64, lane); break;
+        case OFX_ACT_MISH_GRAD: epilogue<T, OFX_ACT_MISH_GRAD>(p, ep, m0 + wm * 64, n0 + wn * 64, lane); break;
         default: epilogue<T, OFX_ACT_NONE>(p, ep, m0 + wm * 64, n0 + wn * 64, lane); break;
     }
 }
@@ -277,9 +286,13 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
                 f32x4 v = *(OFX_LDS f32x4*)(ep + row * 256 + ((chunk ^ (row & 7)) << 4));
                 if (gm < p.M) {
                     v += bias4;
+                    if (p.aux_out) *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn) = v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = act_apply<T, ACT>(v[e]);
-                    v += res[i % (DEPTH + 1)][it];
+                    if (ACT == OFX_ACT_MISH_GRAD) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= act_mish_grad(res[i % (DEPTH + 1)][it][e]);
+                    } else v += res[i % (DEPTH + 1)][it];
                     *(f32x4*)(p.C + ((size_t)gm * p.ldc + gn) * 4) = v;
                 }
             }
@@ -301,11 +314,15 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
                 f32x4 v1 = *(OFX_LDS f32x4*)(ep + row * 256 + (((2 * c8 + 1) ^ (row & 7)) << 4));
                 if (gm < p.M) {
                     v0 += b0; v1 += b1;
+                    if (p.aux_out) { *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn) = v0; *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn + 4) = v1; }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v0[e] = act_apply<T, ACT>(v0[e]); v1[e] = act_apply<T, ACT>(v1[e]); }
                     if (p.resid) {
-                        v0 += *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn);
-                        v1 += *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn + 4);
+                        const f32x4 r0 = *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn), r1 = *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn + 4);
+                        if (ACT == OFX_ACT_MISH_GRAD) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { v0[e] *= act_mish_grad(r0[e]); v1[e] *= act_mish_grad(r1[e]); }
+                        } else { v0 += r0; v1 += r1; }
                     }
                     v8 hi;
 #pragma unroll
@@ -338,9 +355,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(KArgs p) {
         f32x4 v = *(const f32x4*)sp;
         for (int s = 1; s < p.splits; ++s) v += *(const f32x4*)(sp + s * plane);
         if (p.bias) v += *(const f32x4*)(p.bias + gn);
+        if (p.aux_out) *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn) = v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
-        if (p.resid) v += *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn);
+        if (p.resid) {
+            const f32x4 rr = *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn);
+            if (p.act == OFX_ACT_MISH_GRAD) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= act_mish_grad(rr[e]);
+            } else v += rr;
+        }
         if (p.out_kind == 0) {
             *(f32x4*)(p.C + ((size_t)gm * p.ldc + gn) * 4) = v;
         } else {
@@ -507,6 +531,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_big_kernel(KArgs p) {
         case OFX_ACT_QUICK_GELU: epilogue2<T, OFX_ACT_QUICK_GELU>(p, ep, acc, gm0, gn0, lane); break;
         case OFX_ACT_GELU: epilogue2<T, OFX_ACT_GELU>(p, ep, acc, gm0, gn0, lane); break;
         case OFX_ACT_MISH: epilogue2<T, OFX_ACT_MISH>(p, ep, acc, gm0, gn0, lane); break;
+        case OFX_ACT_MISH_GRAD: epilogue2<T, OFX_ACT_MISH_GRAD>(p, ep, acc, gm0, gn0, lane); break;
         default: epilogue2<T, OFX_ACT_NONE>(p, ep, acc, gm0, gn0, lane); break;
     }
     if (p.dbg) {
@@ -660,6 +685,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(KArgs p) {
         case OFX_ACT_QUICK_GELU: epilogue2<T, OFX_ACT_QUICK_GELU>(p, ep, acc, gm0, gn0, lane); break;
         case OFX_ACT_GELU: epilogue2<T, OFX_ACT_GELU>(p, ep, acc, gm0, gn0, lane); break;
         case OFX_ACT_MISH: epilogue2<T, OFX_ACT_MISH>(p, ep, acc, gm0, gn0, lane); break;
+        case OFX_ACT_MISH_GRAD: epilogue2<T, OFX_ACT_MISH_GRAD>(p, ep, acc, gm0, gn0, lane); break;
         default: epilogue2<T, OFX_ACT_NONE>(p, ep, acc, gm0, gn0, lane); break;
     }
 }
@@ -730,7 +756,7 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
                 "gemm: operands must be 16-byte aligned");
     OFX_REQUIRE(op_dtype == OFX_BF16 || op_dtype == OFX_F16, OFX_EINVAL, "gemm: operand dtype must be bf16 or f16");
     KArgs k;
-    k.A = (const char*)g.A; k.W = (const char*)g.W; k.C = (char*)g.C; k.bias = g.bias; k.resid = g.resid; k.m_dev = g.m_dev; k.dbg = g_gemm_dbg; k.skew = g_gemm_skew; k.splits = 1; k.slab = nullptr; k.m_slab = g.M; k.kt_per_split = 0;
+    k.A = (const char*)g.A; k.W = (const char*)g.W; k.C = (char*)g.C; k.bias = g.bias; k.resid = g.resid; k.aux_out = g.aux_out; k.m_dev = g.m_dev; k.dbg = g_gemm_dbg; k.skew = g_gemm_skew; k.splits = 1; k.slab = nullptr; k.m_slab = g.M; k.kt_per_split = 0;
     k.M = g.M; k.N = g.N; k.K = g.K; k.lda = g.lda; k.ldc = g.ldc; k.ldr = g.ldr; k.act = g.act; k.out_kind = g.out_kind;
     static bool attr_set = false;
     if (!attr_set) {

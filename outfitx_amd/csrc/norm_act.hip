@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a, const int* row
             q += v[c][0] * v[c][0] + v[c][1] * v[c][1] + v[c][2] * v[c][2] + v[c][3] * v[c][3];
         }
         const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + a.eps);
+        if (a.stats && lane == 0) { a.stats[2 * (size_t)r] = mu; a.stats[2 * (size_t)r + 1] = rstd; }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int col = (lane + 64 * c) * 4;

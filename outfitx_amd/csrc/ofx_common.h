@@ -77,6 +77,14 @@ __device__ __forceinline__ float act_mish(float u) {
     float n = e * (e + 2.0f);
     return u * (n * __builtin_amdgcn_rcpf(n + 2.0f));
 }
+// d/du [u * tanh(softplus(u))] = tanh(sp) + u * sigmoid(u) * (1 - tanh(sp)^2)
+__device__ __forceinline__ float act_mish_grad(float u) {
+    if (u > 20.0f) return 1.0f;
+    const float e = __expf(u), n = e * (e + 2.0f);
+    const float t = n * __builtin_amdgcn_rcpf(n + 2.0f);               // tanh(softplus(u))
+    const float sg = e * __builtin_amdgcn_rcpf(1.0f + e);              // sigmoid(u)
+    return t + u * sg * (1.0f - t * t);
+}
 __device__ __forceinline__ float apply_act(float u, int act) {
     switch (act) {
         case OFX_ACT_QUICK_GELU: return act_quick_gelu(u);
@@ -117,6 +125,7 @@ struct GemmArgs {
     const float* bias;  // [N] or null
     const float* resid; // fp32 [M, ldr] or null; may alias C when out_kind == F32
     const int* m_dev = nullptr; // optional device-side live row count (<= M)
+    float* aux_out = nullptr;   // optional fp32 [M, N] copy of (acc + bias) BEFORE the activation (training tape)
     void* slab = nullptr;       // optional split-K scratch (fp32 [splits, M, N]); see ofx_gemm_splitk_bytes
     size_t slab_bytes = 0;
     int M, N, K, lda, ldc, ldr;
@@ -136,6 +145,7 @@ struct LnArgs {
     int rows, D, ldy;
     int out_kind;          // 0 fp32 | 1 operand type | 2 split3
     float eps;
+    float* stats = nullptr;  // optional [rows, 2] (mean, rstd) for the backward pass
 };
 int ofx_launch_layernorm(const LnArgs& a, int op_dtype, hipStream_t s);
 int ofx_launch_layernorm_dev(const LnArgs& a, const int* rows_dev, int op_dtype, hipStream_t s);

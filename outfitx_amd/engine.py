@@ -123,6 +123,38 @@ class Engine:
             L.check(self.lib.ofx_cir_prefix(self.h, _ptr(t), B, _ptr(out), _stream(self.device)), "ofx_cir_prefix")
         return out
 
+    # ---------------------------------------------------------------- training step (CP path, next row N1)
+    def grad_layout(self):
+        n = 5 + 12 * self.desc.n_layers
+        offs = (C.c_size_t * n)()
+        total = int(self.lib.ofx_cp_train_grad_floats(self.h, offs, n))
+        return total, list(offs)
+
+    def cp_train_fwd(self, x: torch.Tensor, mask: torch.Tensor):
+        """Tape-saving CP forward: x [B,L,D], mask [B,L] (True = pad) -> (logits [B,1] fp32, tape uint8 tensor)."""
+        B, Lq, D = x.shape
+        x = _f32c(x, self.device)
+        m = mask.to(device=self.device)
+        m = (m if m.dtype == torch.bool else m != 0).contiguous().view(torch.uint8)
+        tape = torch.empty(int(self.lib.ofx_cp_train_tape_bytes(self.h, B, Lq)), dtype=torch.uint8, device=self.device)
+        ws = self.workspace(int(self.lib.ofx_cp_train_ws_bytes(self.h, B, Lq)))
+        logits = torch.empty(B, 1, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ofx_cp_train_fwd(self.h, _ptr(x), _ptr(m), B, Lq, _ptr(logits), _ptr(tape), tape.numel(),
+                                              _ptr(ws), ws.numel(), _stream(self.device)), "ofx_cp_train_fwd")
+        return logits, tape
+
+    def cp_train_bwd(self, tape: torch.Tensor, dlogits: torch.Tensor, B: int, Lq: int) -> torch.Tensor:
+        """d loss / d logits [B,1] -> flat fp32 gradient buffer (layout: grad_layout())."""
+        total, _ = self.grad_layout()
+        g = torch.empty(total, dtype=torch.float32, device=self.device)
+        dl = _f32c(dlogits, self.device)
+        ws = self.workspace(int(self.lib.ofx_cp_train_ws_bytes(self.h, B, Lq)))
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ofx_cp_train_bwd(self.h, _ptr(tape), tape.numel(), _ptr(dl), B, Lq, _ptr(g), total,
+                                              _ptr(ws), ws.numel(), _stream(self.device)), "ofx_cp_train_bwd")
+        return g
+
     # ---------------------------------------------------------------- towers
     def vit(self, pixels: torch.Tensor, out: torch.Tensor, col: int, normalize: bool) -> None:
         """pixels [N,3,H,W] fp32 pixel_values -> out[:, col:col+512] (out is [N, ld] fp32 contiguous)."""
@@ -186,6 +218,21 @@ def fitb_argmin(y_hat: torch.Tensor, cand: torch.Tensor, return_dist: bool = Fal
     with torch.cuda.device(dev):
         L.check(lib.ofx_fitb_argmin(_ptr(y), _ptr(c), B, Cn, D, _ptr(idx), _ptr(dist), _stream(dev)), "ofx_fitb_argmin")
     return (idx, dist) if return_dist else idx
+
+
+def focal_loss(logits: torch.Tensor, labels: torch.Tensor, alpha: float, gamma: float, upstream: float = 1.0, need_grad: bool = True):
+    """FocalLoss(alpha, gamma, 'mean') (src/losses/focal_loss.py:23-41) and upstream * d loss / d logits, one kernel."""
+    lib = L.load()
+    dev = logits.device
+    if dev.type != "cuda":
+        raise L.OfxError("focal_loss needs HIP tensors; there is no CPU path")
+    y = _f32c(logits.reshape(-1), dev); t = _f32c(labels.reshape(-1), dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    dl = torch.empty_like(y) if need_grad else None
+    with torch.cuda.device(dev):
+        L.check(lib.ofx_focal_loss(_ptr(y), _ptr(t), y.numel(), float(alpha), float(gamma), float(upstream), _ptr(loss), _ptr(dl),
+                                   _stream(dev)), "ofx_focal_loss")
+    return loss, dl
 
 
 def topk_merge(idx_parts: torch.Tensor, dist_parts: torch.Tensor):

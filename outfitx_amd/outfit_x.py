@@ -39,11 +39,52 @@ def _activation_id(act) -> int:
     raise NotImplementedError(f"transformer activation {act!r} has no fused epilogue (mish / gelu are built)")
 
 
+class _CPTrainFn(torch.autograd.Function):
+    """CP path with a hand-written backward (libofx_hip.so: ofx_cp_train_fwd / ofx_cp_train_bwd).  Gradients flow to
+    the outfit transformer, outfit_token and cp_ffn; the embeddings are data (cp_trainer feeds precomputed ones)."""
+
+    @staticmethod
+    def forward(ctx, eng, x, mask, F, *params):
+        logits, tape = eng.cp_train_fwd(x, mask)
+        ctx.eng, ctx.tape, ctx.bl, ctx.F = eng, tape, (x.shape[0], x.shape[1]), F
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        eng = ctx.eng
+        B, Lq = ctx.bl
+        g = eng.cp_train_bwd(ctx.tape, dlogits.contiguous(), B, Lq)
+        ctx.tape = None
+        _, offs = eng.grad_layout()
+        D, F = eng.desc.d_model, ctx.F
+        Fp = (F + 127) // 128 * 128
+        out = []
+        for i, shp in enumerate(ctx.shapes):
+            if i in (1, 4):                       # target_item_image_emb, cir_ffn: not on the CP path
+                out.append(None)
+                continue
+            k = (i - 5) % 12 if i >= 5 else -1
+            if k == 4:
+                out.append(g[offs[i]:offs[i] + Fp * D].view(Fp, D)[:F])
+            elif k == 5:
+                out.append(g[offs[i]:offs[i] + F])
+            elif k == 6:
+                out.append(g[offs[i]:offs[i] + D * Fp].view(D, Fp)[:, :F])
+            else:
+                n = 1
+                for v in shp:
+                    n *= v
+                out.append(g[offs[i]:offs[i] + n].view(shp))
+        return (None, None, None, None, *out)
+
+
 class OutfitX(nn.Module):
     Tasks = TypeVar("Tasks", OutfitComplementaryItemRetrievalTask, OutfitCompatibilityPredictionTask,
                     OutfitFillInTheBlankTask, OutfitPrecomputeEmbeddingTask)
 
-    def __init__(self, cfg: Optional[OutfitXConfig] = None, precision: str = "bf16x3", tower_precision: str = "bf16"):
+    def __init__(self, cfg: Optional[OutfitXConfig] = None, precision: str = "bf16x3", tower_precision: str = "bf16",
+                 train_precision: str = "bf16"):
         super().__init__()
         self.cfg = cfg if cfg is not None else OutfitXConfig()
         t = self.cfg.transformer
@@ -66,6 +107,7 @@ class OutfitX(nn.Module):
         if not t.norm_first:
             raise NotImplementedError("post-norm encoder layers are outside the scoring path (reference uses norm_first)")
         self.precision = precision
+        self.train_precision = train_precision      # operand format of the training step (the reference trains under bf16 autocast)
         self.item_encoder.set_precision(tower_precision)
         self._engines: Dict[Any, Engine] = {}
 
@@ -87,12 +129,10 @@ class OutfitX(nn.Module):
                     l.norm1.weight, l.norm1.bias, l.norm2.weight, l.norm2.bias]
         return out
 
-    def _engine(self) -> Engine:
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("outfitx_amd builds the forward (scoring) path; the training step / backward is a "
-                                      "'next' row (SURVEY.md §8f N1).  Call under torch.no_grad() or model.eval().")
+    def _engine(self, precision: Optional[str] = None) -> Engine:
         dev = self.device
-        key = (dev, self.precision)
+        precision = precision or self.precision
+        key = (dev, precision)
         eng = self._engines.get(key)
         if eng is None:
             desc = L.default_desc()
@@ -101,7 +141,7 @@ class OutfitX(nn.Module):
             desc.max_items = min(self.cfg.max_length, 31)
             desc.outfit_act = _activation_id(t.activation)
             desc.ln_eps = self.transformer_encoder.layers[0].norm1.eps
-            eng = Engine(dev, desc, precision=self.precision)
+            eng = Engine(dev, desc, precision=precision)
             self._engines[key] = eng
         ts = self._outfit_tensors()
         sig = tuple((p.data_ptr(), p._version) for p in ts)
@@ -132,12 +172,30 @@ class OutfitX(nn.Module):
         """outfit_x.py:120-144 -> raw compatibility logits [B,1]."""
         if encoder_input_dict is not None:
             outfit_embedding = self.item_encoder(**encoder_input_dict)
+        if self.training and torch.is_grad_enabled():
+            return self._cp_train_forward(outfit_embedding, outfit_mask)
         eng, row0 = self._run_encoder(outfit_embedding, outfit_mask)
         return eng.cp_head(row0)
+
+    def _cp_train_forward(self, outfit_embedding, outfit_mask):
+        """CP trainer step (compatibility_prediction_trainer.py:57-81): forward with a tape, backward in libofx_hip.so."""
+        t = self.cfg.transformer
+        if t.dropout != 0.0:
+            raise NotImplementedError("the HIP training step is deterministic (dropout = 0); set cfg.transformer.dropout = 0 "
+                                      "(dropout masks are the next increment of SURVEY.md §8f N1)")
+        if self.train_precision not in ("bf16", "f16"):
+            raise ValueError("train_precision must be 'bf16' or 'f16'")
+        if outfit_embedding.requires_grad:
+            raise NotImplementedError("gradients w.r.t. the item embeddings (encoder fine-tuning) are not built")
+        eng = self._engine(self.train_precision)
+        return _CPTrainFn.apply(eng, outfit_embedding, outfit_mask, t.d_ffn, *self._outfit_tensors())
 
     def _cir_forward(self, outfit_embedding: torch.Tensor, outfit_mask: torch.Tensor,
                      target_item_text_embedding: torch.Tensor) -> torch.Tensor:
         """outfit_x.py:147-172 -> target-item embedding [B, d_embed]."""
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("the CIR / FITB training step (backward of the retrieval path) is not built; "
+                                      "call under torch.no_grad() or model.eval()")
         eng = self._engine()
         prefix = eng.cir_prefix(target_item_text_embedding)
         row0 = eng.set_encoder(outfit_embedding, outfit_mask, prefix)
