@@ -155,6 +155,13 @@ void ofx_debug_gemm_clock(void* buf);
 /* ------------------------------------------------------------------ op level (tests) ------- */
 int ofx_gemm(const void* A, const void* W, void* C, const float* bias, const float* resid, int M, int N, int K,
              int lda, int ldc, int ldr, int act, int out_kind, int op_dtype, ofx_stream stream);
+/* Weight-gradient GEMM of the training step: C[M,N] fp32 = sum_k A[k, m] * B[k, n]; A [K, lda] and B [K, ldb] row-major
+ * operand-type matrices whose ROW index is contracted (dW = dY^T X without transposed copies).  M, N multiples of 256.
+ * k_dev: optional device-side live row count (<= K).  Both operands must be readable up to round_up(K, 64) rows.
+ * slab: ofx_gemm_tn_ws(M,N,K) bytes of scratch for the deterministic split-K (NULL = no split). */
+size_t ofx_gemm_tn_ws(int M, int N, int K);
+int ofx_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K, const int* k_dev,
+                void* slab, size_t slab_bytes, int op_dtype, ofx_stream stream);
 /* ofx_gemm with split-K scratch: slab of ofx_gemm_splitk_ws(M,N,K) bytes (0 = the shape is not split) */
 size_t ofx_gemm_splitk_ws(int M, int N, int K);
 int ofx_gemm_splitk(const void* A, const void* W, void* C, const float* bias, const float* resid, int M, int N, int K,

@@ -66,6 +66,8 @@ SIGNATURES = {
     "ofx_tune": (_i, [_i, _i]),
     "ofx_debug_gemm_clock": (None, [_vp]),
     "ofx_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ofx_gemm_tn_ws": (_sz, [_i, _i, _i]),
+    "ofx_gemm_tn": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp]),
     "ofx_gemm_splitk_ws": (_sz, [_i, _i, _i]),
     "ofx_gemm_splitk": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ofx_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),

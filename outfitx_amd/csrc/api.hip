@@ -67,18 +67,17 @@ extern "C" int ofx_profile_read(double* ms, double* flops, long long* launches) 
     return OFX_OK;
 }
 
-int ofx_launch_cast_transpose(const void* src, int src_is_f32, int ld_src, void* row_out, int ld_row, void* t_out, int Mpad, int C,
-                              const int* m_dev, int M, int op_dtype, hipStream_t s);
-int ofx_launch_colsum(const void* x, int x_is_f32, int ld, float* out, float* part, int C, const int* m_dev, int M, int accumulate, int op_dtype, hipStream_t s);
-int ofx_launch_ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* add, float* dx_out,
-                      float* dgamma, float* dbeta, float* part, int D, const int* m_dev, int M, int accumulate, hipStream_t s);
+int ofx_launch_transpose_cast(const float* src, void* dst, int R, int C, int ldd, int op_dtype, hipStream_t s);
+size_t ofx_colsum_part_floats(int C);
+int ofx_launch_colsum(const void* x, int x_kind, int ld, const int* gather, const float* row_scale, float* out0, float* out1, float* out2, int seg,
+                      float* part, int C, const int* m_dev, int M, int op_dtype, hipStream_t s);
 size_t ofx_ln_bwd_part_floats(int D);
-int ofx_launch_set_attention_bwd(const float* qkv, const float* d_o, float* dqkv, const int* cu, int nseq, int n_head, int D, int max_len,
-                                 float scale, hipStream_t s);
+int ofx_launch_ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* add, float* dx_out, void* dx_op,
+                      float* dgamma, float* dbeta, float* dcols, float* part, int D, const int* m_dev, int M, int op_dtype, hipStream_t s);
+int ofx_launch_set_attention_bwd(const float* qkv, const float* d_o, void* dqkv, const int* cu, int nseq, int n_head, int D, int max_len,
+                                 float scale, int op_dtype, hipStream_t s);
 int ofx_launch_focal_loss(const float* logits, const float* labels, int B, float alpha, float gamma, float upstream, float* loss, float* dlogits, hipStream_t s);
-int ofx_launch_cp_head_bwd(const float* dlogits, const float* row0, const float* w, float* d_row0, float* dw, float* db, int B, int D, int accumulate, hipStream_t s);
-int ofx_launch_scatter_row0(const float* d_row0, const int* cu, float* dX, int B, int D, int M, const int* m_dev, hipStream_t s);
-int ofx_launch_prefix_grad(const float* dX, const int* cu, float* out, int B, int D, int c0, int n, int accumulate, hipStream_t s);
+int ofx_launch_cp_head_bwd(const float* dlogits, const float* w, const int* cu, float* dX, void* dXb, float* db, int B, int D, int op_dtype, hipStream_t s);
 int ofx_launch_fitb(const float* y, const float* cand, int B, int C, int D, int64_t* idx, float* dist, hipStream_t s);
 int ofx_launch_l2_topk(const float* Q, const float* P, int nq, int np, int D, int k, int64_t index_base, int64_t* idx,
                        float* dist, void* ws, size_t ws_bytes, hipStream_t s);
@@ -227,11 +226,12 @@ extern "C" int ofx_pack_outfit_weights(ofx_handle* h, const void* const* P, int 
         L.be2 = A.take<float>(D); TRY(copy_f32(L.be2, q[11], D, s));
         L.w_in_t = L.w_out_t = L.w_1_t = L.w_2_t = nullptr;
         if (km == 1) {      // W^T copies for the backward dgrad GEMMs: [K_w, N_w] operand, zero padded
-            L.w_in_t = A.take<char>(2 * D * 3 * D); TRY(ofx_launch_cast_transpose(q[0], 1, (int)D, nullptr, 0, L.w_in_t, (int)(3 * D), (int)D, nullptr, (int)(3 * D), dt, s));
-            L.w_out_t = A.take<char>(2 * D * D); TRY(ofx_launch_cast_transpose(q[2], 1, (int)D, nullptr, 0, L.w_out_t, (int)D, (int)D, nullptr, (int)D, dt, s));
-            L.w_1_t = A.take<char>(2 * D * Fp); TRY(ofx_launch_cast_transpose(q[4], 1, (int)D, nullptr, 0, L.w_1_t, (int)Fp, (int)D, nullptr, (int)F, dt, s));
-            L.w_2_t = A.take<char>(2 * Fp * D); OFX_HIP(hipMemsetAsync(L.w_2_t, 0, 2 * Fp * D, s));
-            TRY(ofx_launch_cast_transpose(q[6], 1, (int)F, nullptr, 0, L.w_2_t, (int)D, (int)F, nullptr, (int)D, dt, s));
+            L.w_in_t = A.take<char>(2 * D * 3 * D); TRY(ofx_launch_transpose_cast((const float*)q[0], L.w_in_t, (int)(3 * D), (int)D, (int)(3 * D), dt, s));
+            L.w_out_t = A.take<char>(2 * D * D); TRY(ofx_launch_transpose_cast((const float*)q[2], L.w_out_t, (int)D, (int)D, (int)D, dt, s));
+            L.w_1_t = A.take<char>(2 * D * Fp); OFX_HIP(hipMemsetAsync(L.w_1_t, 0, 2 * D * Fp, s));      // [D, Fp], columns F.. stay zero
+            TRY(ofx_launch_transpose_cast((const float*)q[4], L.w_1_t, (int)F, (int)D, (int)Fp, dt, s));
+            L.w_2_t = A.take<char>(2 * Fp * D); OFX_HIP(hipMemsetAsync(L.w_2_t, 0, 2 * Fp * D, s));      // [Fp, D], rows F.. stay zero
+            TRY(ofx_launch_transpose_cast((const float*)q[6], L.w_2_t, (int)D, (int)F, (int)D, dt, s));
         }
     }
     OFX_REQUIRE(A.off <= A.cap, OFX_ESTATE, "pack_outfit: arena overflow");
@@ -592,37 +592,32 @@ namespace {
 struct TapeLayer { float* Xin; float* st1; char* H1; float* QKV; char* O; float* Xmid; float* st2; char* H2; float* Upre; char* A; };
 struct Tape { int* cu; float* Xfinal; float* row0; std::vector<TapeLayer> L; size_t bytes; };
 size_t carve_tape(const ofx_handle* h, Bump& b, int B, int Lq, Tape* t) {
-    const size_t M = (size_t)B * (Lq + 1), D = h->d.d_model, Fp = h->ot_ffn_pad;
+    const size_t M = (size_t)B * (Lq + 1), D = h->d.d_model, Fp = h->ot_ffn_pad, Mp = align_up(M, 64);   // operand copies: rows readable up to Mp (TN GEMM)
     Tape tp;
     tp.cu = b.take<int>(B + 1);
     tp.row0 = b.take<float>((size_t)B * D);
     tp.L.resize(h->d.n_layers);
     for (TapeLayer& l : tp.L) {
-        l.Xin = b.take<float>(M * D); l.st1 = b.take<float>(M * 2); l.H1 = b.take<char>(M * D * 2); l.QKV = b.take<float>(M * 3 * D);
-        l.O = b.take<char>(M * D * 2); l.Xmid = b.take<float>(M * D); l.st2 = b.take<float>(M * 2); l.H2 = b.take<char>(M * D * 2);
-        l.Upre = b.take<float>(M * Fp); l.A = b.take<char>(M * Fp * 2);
+        l.Xin = b.take<float>(M * D); l.st1 = b.take<float>(M * 2); l.H1 = b.take<char>(Mp * D * 2); l.QKV = b.take<float>(M * 3 * D);
+        l.O = b.take<char>(Mp * D * 2); l.Xmid = b.take<float>(M * D); l.st2 = b.take<float>(M * 2); l.H2 = b.take<char>(Mp * D * 2);
+        l.Upre = b.take<float>(M * Fp); l.A = b.take<char>(Mp * Fp * 2);
     }
     tp.Xfinal = b.take<float>(M * D);
     tp.bytes = align_up(b.off, 256);
     if (t) *t = tp;
     return tp.bytes;
 }
-struct BwdWs { float *dXa, *dXb_f, *dH, *dO, *dQKV, *d_row0, *part; char *gXb, *gXbT, *dU, *dUT, *gQb, *gQbT, *actT; char* slab; size_t slab_bytes; int Mpad; };
+struct BwdWs { float *dXa, *dXb_f, *dH, *dO, *part; char *gXb, *dU, *gQb; char* slab; size_t slab_bytes; };
 size_t carve_bwd(const ofx_handle* h, Bump& b, int B, int Lq, BwdWs* w) {
-    const size_t M = (size_t)B * (Lq + 1), D = h->d.d_model, Fp = h->ot_ffn_pad, Mpad = align_up(M, 64);
+    const size_t M = (size_t)B * (Lq + 1), D = h->d.d_model, Fp = h->ot_ffn_pad, Mp = align_up(M, 64);
     BwdWs t;
-    t.Mpad = (int)Mpad;
     t.dXa = b.take<float>(M * D); t.dXb_f = b.take<float>(M * D); t.dH = b.take<float>(M * D); t.dO = b.take<float>(M * D);
-    t.dQKV = b.take<float>(M * 3 * D); t.d_row0 = b.take<float>((size_t)B * D);
-    t.part = b.take<float>(std::max<size_t>(ofx_ln_bwd_part_floats((int)D), (size_t)32 * 3 * D + 32 * Fp));
-    t.gXb = b.take<char>(M * D * 2); t.gXbT = b.take<char>(D * Mpad * 2);
-    t.dU = b.take<char>(M * Fp * 2); t.dUT = b.take<char>(Fp * Mpad * 2);
-    t.gQb = b.take<char>(M * 3 * D * 2); t.gQbT = b.take<char>(3 * D * Mpad * 2);
-    t.actT = b.take<char>(Fp * Mpad * 2);
+    t.part = b.take<float>(std::max(ofx_ln_bwd_part_floats((int)D), ofx_colsum_part_floats((int)(3 * D))));
+    t.gXb = b.take<char>(Mp * D * 2); t.dU = b.take<char>(Mp * Fp * 2); t.gQb = b.take<char>(Mp * 3 * D * 2);
     t.slab_bytes = 0;
-    const int mp = (int)Mpad, Di = (int)D, Fi = (int)Fp;
-    for (auto s : {ofx_gemm_splitk_bytes(Di, Fi, mp), ofx_gemm_splitk_bytes(Fi, Di, mp), ofx_gemm_splitk_bytes(Di, Di, mp), ofx_gemm_splitk_bytes(3 * Di, Di, mp),
-                   ofx_gemm_splitk_bytes((int)M, Fi, Di), ofx_gemm_splitk_bytes((int)M, Di, Fi), ofx_gemm_splitk_bytes((int)M, Di, Di), ofx_gemm_splitk_bytes((int)M, Di, 3 * Di)})
+    const int m = (int)M, Di = (int)D, Fi = (int)Fp;
+    for (auto s : {ofx_gemm_tn_slab_bytes(Di, Fi, m), ofx_gemm_tn_slab_bytes(Fi, Di, m), ofx_gemm_tn_slab_bytes(Di, Di, m), ofx_gemm_tn_slab_bytes(3 * Di, Di, m),
+                   ofx_gemm_splitk_bytes(m, Fi, Di), ofx_gemm_splitk_bytes(m, Di, Fi), ofx_gemm_splitk_bytes(m, Di, Di), ofx_gemm_splitk_bytes(m, Di, 3 * Di)})
         t.slab_bytes = std::max(t.slab_bytes, s);
     t.slab = b.take<char>(t.slab_bytes);
     if (w) *w = t;
@@ -719,50 +714,49 @@ extern "C" int ofx_cp_train_bwd(ofx_handle* h, void* tape_mem, size_t tape_bytes
     std::vector<size_t> off; size_t total;
     grad_offsets(h, off, &total);
     OFX_REQUIRE(grad_floats >= total, OFX_EWORKSPACE, "cp_train_bwd: gradient buffer %zu < %zu floats", grad_floats, total);
-    const int D = d.d_model, Fp = h->ot_ffn_pad, dt = h->ot_dtype, M = B * (L + 1), Mpad = w.Mpad;
+    const int D = d.d_model, Fp = h->ot_ffn_pad, dt = h->ot_dtype, M = B * (L + 1);
     const int* m_dev = T.cu + B;
     auto G = [&](int i) { return grads + off[i]; };
-    auto gemm = [&](const void* A, int lda, const void* W, void* C, int ldc, int m, int n, int k, int out_kind, int act, const float* resid, int ldr, const int* md) {
-        GemmArgs g{}; g.A = A; g.W = W; g.C = C; g.M = m; g.N = n; g.K = k; g.lda = lda; g.ldc = ldc; g.out_kind = out_kind; g.act = act; g.resid = resid; g.ldr = ldr;
-        g.m_dev = md; g.slab = w.slab; g.slab_bytes = w.slab_bytes;
+    auto dgrad = [&](const void* A, int lda, const void* W, void* C, int ldc, int n, int k, int out_kind, int act, const float* resid, int ldr) {
+        GemmArgs g{}; g.A = A; g.W = W; g.C = C; g.M = M; g.N = n; g.K = k; g.lda = lda; g.ldc = ldc; g.out_kind = out_kind; g.act = act; g.resid = resid; g.ldr = ldr;
+        g.m_dev = m_dev; g.slab = w.slab; g.slab_bytes = w.slab_bytes;
         return ofx_launch_gemm(g, dt, s);
     };
-    // head: logits = row0 . w + b
-    TRY(ofx_launch_cp_head_bwd(dlogits, T.row0, h->cp_w, w.d_row0, G(2), G(3), B, D, 0, s));
+    // dW[n_w, k_w] = dY[rows, n_w]^T X[rows, k_w], contraction over the live rows
+    auto wgrad = [&](const void* dY, int n_w, const void* X, int k_w, float* out) {
+        return ofx_launch_gemm_tn(dY, n_w, X, k_w, out, k_w, n_w, k_w, M, m_dev, w.slab, w.slab_bytes, dt, s);
+    };
+    // head: logits = X[cu[b]] . w + b.  dX is zero except the prefix rows.
     float* dX = w.dXa; float* dX2 = w.dXb_f;
-    TRY(ofx_launch_scatter_row0(w.d_row0, T.cu, dX, B, D, M, m_dev, s));
+    OFX_HIP(hipMemsetAsync(dX, 0, (size_t)M * D * 4, s));
+    OFX_HIP(hipMemsetAsync(w.gXb, 0, (size_t)M * D * 2, s));
+    TRY(ofx_launch_cp_head_bwd(dlogits, h->cp_w, T.cu, dX, w.gXb, G(3), B, D, dt, s));
+    TRY(ofx_launch_colsum(T.row0, 0, D, nullptr, dlogits, G(2), nullptr, nullptr, D, w.part, D, nullptr, B, dt, s));                 // d cp_w = sum_b dlogit_b row0_b
+    // bias gradient of the last layer's linear2 = column sums of dX = (sum_b dlogit_b) w
+    TRY(ofx_launch_colsum(h->cp_w, 0, 0, nullptr, dlogits, G(5 + 12 * (d.n_layers - 1) + 7), nullptr, nullptr, D, w.part, D, nullptr, B, dt, s));
     for (int l = d.n_layers - 1; l >= 0; --l) {
         const OutfitLayer& Ly = h->ol[l];
         const TapeLayer& t = T.L[l];
         const int g0 = 5 + 12 * l;                    // Win, bin, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2
-        // ---- FFN branch: Xout = Xmid + mish(H2 W1^T + b1) W2^T + b2
-        TRY(ofx_launch_cast_transpose(dX, 1, D, w.gXb, D, w.gXbT, Mpad, D, m_dev, M, dt, s));
-        TRY(ofx_launch_colsum(dX, 1, D, G(g0 + 7), w.part, D, m_dev, M, 0, dt, s));
-        TRY(ofx_launch_cast_transpose(t.A, 0, Fp, nullptr, 0, w.actT, Mpad, Fp, m_dev, M, dt, s));
-        TRY(gemm(w.gXbT, Mpad, w.actT, G(g0 + 6), Fp, D, Fp, Mpad, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nullptr));             // dW2 [D, Fp]
-        TRY(gemm(w.gXb, D, Ly.w_2_t, w.dU, Fp, M, Fp, D, OFX_OUT_OP, OFX_ACT_MISH_GRAD, t.Upre, Fp, m_dev));                      // dU = (dX W2) * mish'(Upre)
-        TRY(ofx_launch_cast_transpose(w.dU, 0, Fp, nullptr, 0, w.dUT, Mpad, Fp, m_dev, M, dt, s));
-        TRY(ofx_launch_colsum(w.dU, 0, Fp, G(g0 + 5), w.part, Fp, m_dev, M, 0, dt, s));
-        TRY(ofx_launch_cast_transpose(t.H2, 0, D, nullptr, 0, w.actT, Mpad, D, m_dev, M, dt, s));
-        TRY(gemm(w.dUT, Mpad, w.actT, G(g0 + 4), D, Fp, D, Mpad, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nullptr));                // dW1 [Fp, D]
-        TRY(gemm(w.dU, Fp, Ly.w_1_t, w.dH, D, M, D, Fp, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, m_dev));                           // dH2
-        TRY(ofx_launch_ln_bwd(w.dH, t.Xmid, t.st2, Ly.g2, dX, dX2, G(g0 + 10), G(g0 + 11), w.part, D, m_dev, M, 0, s));         // dXmid
+        // ---- FFN branch: Xout = Xmid + mish(H2 W1^T + b1) W2^T + b2        (gXb = operand copy of dX)
+        TRY(wgrad(w.gXb, D, t.A, Fp, G(g0 + 6)));                                                                   // dW2 [D, Fp]
+        TRY(dgrad(w.gXb, D, Ly.w_2_t, w.dU, Fp, Fp, D, OFX_OUT_OP, OFX_ACT_MISH_GRAD, t.Upre, Fp));                 // dU = (dX W2) * mish'(Upre)
+        TRY(ofx_launch_colsum(w.dU, 1, Fp, nullptr, nullptr, G(g0 + 5), nullptr, nullptr, Fp, w.part, Fp, m_dev, M, dt, s));   // db1
+        TRY(wgrad(w.dU, Fp, t.H2, D, G(g0 + 4)));                                                                   // dW1 [Fp, D]
+        TRY(dgrad(w.dU, Fp, Ly.w_1_t, w.dH, D, D, Fp, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0));                      // dH2
+        TRY(ofx_launch_ln_bwd(w.dH, t.Xmid, t.st2, Ly.g2, dX, dX2, w.gXb, G(g0 + 10), G(g0 + 11), G(g0 + 3), w.part, D, m_dev, M, dt, s));   // dXmid (+ dbo)
         // ---- attention branch: Xmid = Xin + O Wo^T + bo
-        TRY(ofx_launch_cast_transpose(dX2, 1, D, w.gXb, D, w.gXbT, Mpad, D, m_dev, M, dt, s));
-        TRY(ofx_launch_colsum(dX2, 1, D, G(g0 + 3), w.part, D, m_dev, M, 0, dt, s));
-        TRY(ofx_launch_cast_transpose(t.O, 0, D, nullptr, 0, w.actT, Mpad, D, m_dev, M, dt, s));
-        TRY(gemm(w.gXbT, Mpad, w.actT, G(g0 + 2), D, D, D, Mpad, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nullptr));                // dWo [D, D]
-        TRY(gemm(w.gXb, D, Ly.w_out_t, w.dO, D, M, D, D, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, m_dev));                          // dO
-        TRY(ofx_launch_set_attention_bwd(t.QKV, w.dO, w.dQKV, T.cu, B, d.n_head, D, L + 1, 0.125f, s));
-        TRY(ofx_launch_cast_transpose(w.dQKV, 1, 3 * D, w.gQb, 3 * D, w.gQbT, Mpad, 3 * D, m_dev, M, dt, s));
-        TRY(ofx_launch_colsum(w.dQKV, 1, 3 * D, G(g0 + 1), w.part, 3 * D, m_dev, M, 0, dt, s));
-        TRY(ofx_launch_cast_transpose(t.H1, 0, D, nullptr, 0, w.actT, Mpad, D, m_dev, M, dt, s));
-        TRY(gemm(w.gQbT, Mpad, w.actT, G(g0 + 0), D, 3 * D, D, Mpad, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nullptr));            // dWin [3D, D]
-        TRY(gemm(w.gQb, 3 * D, Ly.w_in_t, w.dH, D, M, D, 3 * D, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, m_dev));                   // dH1
-        TRY(ofx_launch_ln_bwd(w.dH, t.Xin, t.st1, Ly.g1, dX2, dX, G(g0 + 8), G(g0 + 9), w.part, D, m_dev, M, 0, s));            // dXin
+        TRY(wgrad(w.gXb, D, t.O, D, G(g0 + 2)));                                                                    // dWo [D, D]
+        TRY(dgrad(w.gXb, D, Ly.w_out_t, w.dO, D, D, D, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0));                     // dO
+        TRY(ofx_launch_set_attention_bwd(t.QKV, w.dO, w.gQb, T.cu, B, d.n_head, D, L + 1, 0.125f, dt, s));
+        TRY(ofx_launch_colsum(w.gQb, 1, 3 * D, nullptr, nullptr, G(g0 + 1), nullptr, nullptr, 3 * D, w.part, 3 * D, m_dev, M, dt, s));   // dbin
+        TRY(wgrad(w.gQb, 3 * D, t.H1, D, G(g0 + 0)));                                                               // dWin [3D, D]
+        TRY(dgrad(w.gQb, 3 * D, Ly.w_in_t, w.dH, D, D, 3 * D, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0));              // dH1
+        // dXin; its column sums are the bias gradient of the layer below's linear2
+        TRY(ofx_launch_ln_bwd(w.dH, t.Xin, t.st1, Ly.g1, dX2, dX, w.gXb, G(g0 + 8), G(g0 + 9), l > 0 ? G(g0 - 12 + 7) : nullptr, w.part, D, m_dev, M, dt, s));
     }
     // shared prefix token: d outfit_token = sum_b dX0[cu[b]]
-    return ofx_launch_prefix_grad(dX, T.cu, G(0), B, D, 0, D, 0, s);
+    return ofx_launch_colsum(dX, 0, D, T.cu, nullptr, G(0), nullptr, nullptr, D, w.part, D, nullptr, B, dt, s);
 }
 
 extern "C" int ofx_focal_loss(const float* logits, const float* labels, int B, float alpha, float gamma, float upstream, float* loss, float* dlogits,
@@ -801,6 +795,11 @@ extern "C" int ofx_gemm_splitk(const void* A, const void* W, void* C, const floa
     GemmArgs g{}; g.A = A; g.W = W; g.C = C; g.bias = bias; g.resid = resid; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc;
     g.ldr = ldr; g.act = act; g.out_kind = out_kind; g.slab = slab; g.slab_bytes = slab_bytes;
     return ofx_launch_gemm(g, op_dtype, (hipStream_t)stream);
+}
+extern "C" size_t ofx_gemm_tn_ws(int M, int N, int K) { return ofx_gemm_tn_slab_bytes(M, N, K); }
+extern "C" int ofx_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K, const int* k_dev,
+                           void* slab, size_t slab_bytes, int op_dtype, ofx_stream stream) {
+    return ofx_launch_gemm_tn(A, lda, B, ldb, C, ldc, M, N, K, k_dev, slab, slab_bytes, op_dtype, (hipStream_t)stream);
 }
 extern "C" int ofx_layernorm(const float* x, const int* row_idx, const float* gamma, const float* beta, void* y, int rows,
                              int D, int ldy, int out_kind, int op_dtype, float eps, ofx_stream stream) {

@@ -2,68 +2,92 @@
 // Transformer on precomputed embeddings, i.e. what torch autograd computes for
 // nn.TransformerEncoderLayer(norm_first, mish) x 6 + Linear(1024,1) in the reference's CP trainer
 // (src/trains/trainers/compatibility_prediction_trainer.py:57-81) under FocalLoss (src/losses/focal_loss.py:23-41).
-// Dense contractions (dgrad / wgrad) reuse the forward MFMA GEMM with transposed operands; this file holds the rest:
-// cast+transpose, column sums (bias grads), LayerNorm backward, fp32 set-attention backward, head and loss kernels.
+// Dense contractions run on the MFMA GEMMs (dgrad: the forward kernel on W^T; wgrad: the TN kernel of gemm.hip straight
+// from row-major copies).  This file holds the rest: column sums (bias grads), LayerNorm backward (which also emits the
+// operand-type copy of its output and that output's column sums), fp32 set-attention backward, head and loss kernels.
 #include "ofx_common.h"
 
 namespace {
 
-// ---- src [M_live, C] (fp32 or operand type) -> optional row-major operand copy [M, ldr] and transposed operand copy
-// [C, Mpad] with zero columns for rows >= M_live (the wgrad GEMM contracts over Mpad).  64 x 64 tiles through LDS.
-template <typename TI, typename T>
-__global__ __launch_bounds__(256) void cast_transpose_kernel(const TI* src, int ld_src, T* row_out, int ld_row, T* t_out, int Mpad,
-                                                           int C, const int* m_dev, int M_static) {
+template <typename TI> struct Ld4;
+template <> struct Ld4<float> { static __device__ __forceinline__ f32x4 ld(const float* p) { return *(const f32x4*)p; } };
+template <> struct Ld4<bf16_t> { static __device__ __forceinline__ f32x4 ld(const bf16_t* p) { const bf16x4 v = *(const bf16x4*)p; return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; } };
+template <> struct Ld4<f16_t> { static __device__ __forceinline__ f32x4 ld(const f16_t* p) { const f16x4 v = *(const f16x4*)p; return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; } };
+
+// ---- fp32 [R, C] -> operand-type transpose [C, ldd] (64 x 64 tiles through LDS).  Pack time only: the W^T copies the
+// dgrad GEMMs contract against.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* src, T* dst, int R, int C, int ldd) {
     __shared__ T tile[64][66];
-    const int M = m_dev ? min(*m_dev, M_static) : M_static;
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int r = r0 + ty * 16 + i, c = c0 + tx;
-        T v = (T)0.0f;
-        if (r < M && c < C) v = (T)(float)src[(size_t)r * ld_src + c];
-        tile[ty * 16 + i][tx] = v;
-        if (row_out && r < M && c < C) row_out[(size_t)r * ld_row + c] = v;
+        tile[ty * 16 + i][tx] = (r < R && c < C) ? (T)src[(size_t)r * C + c] : (T)0.0f;
     }
     __syncthreads();
-    if (t_out) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int c = c0 + ty * 16 + i, r = r0 + tx;
-            if (c < C && r < Mpad) t_out[(size_t)c * Mpad + r] = tile[tx][ty * 16 + i];
-        }
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty * 16 + i, r = r0 + tx;
+        if (c < C && r < R) dst[(size_t)c * ldd + r] = tile[tx][ty * 16 + i];
     }
 }
 
-// ---- column sums, two deterministic stages: part[chunk][C] then out[C] (+= when accumulate)
+// ---- column sums, two deterministic stages.  Stage 1: block (x, y) sums rows [y*per, (y+1)*per) of columns 1024x .. +1023
+// (4 per thread, 16-byte loads for fp32), optional row gather and per-row scale -> part[y][C].  Stage 2: out[c] = sum_y.
 template <typename TI>
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const TI* x, int ld, float* part, int C, const int* m_dev, int M_static, int nchunk) {
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const TI* x, int ld, const int* gather, const float* row_scale, float* part, int C,
+                                                           const int* m_dev, int M_static, int nchunk) {
     const int M = m_dev ? min(*m_dev, M_static) : M_static;
-    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int col = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (col >= C) return;
     const int per = (M + nchunk - 1) / nchunk, r0 = blockIdx.y * per, r1 = min(M, r0 + per);
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += (float)x[(size_t)r * ld + col];
-    part[(size_t)blockIdx.y * C + col] = s;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = Ld4<TI>::ld(x + (size_t)(gather ? gather[r + u] : r + u) * ld + col);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += row_scale ? v[u] * row_scale[r + u] : v[u];
+    }
+    for (; r < r1; ++r) {
+        const f32x4 v = Ld4<TI>::ld(x + (size_t)(gather ? gather[r] : r) * ld + col);
+        s += row_scale ? v * row_scale[r] : v;
+    }
+    *(f32x4*)(part + (size_t)blockIdx.y * C + col) = s;
 }
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* part, float* out, int C, int nchunk, int accumulate) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= C) return;
+// out_k[c % seg] for c in segment k = c / seg (up to three destinations: LayerNorm's dgamma | dbeta | column sums)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* part, int C, int nchunk, float* out0, float* out1, float* out2, int seg) {
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cx;
     float s = 0.f;
-    for (int k = 0; k < nchunk; ++k) s += part[(size_t)k * C + col];
-    out[col] = accumulate ? out[col] + s : s;
+    if (col < C) for (int k = ry; k < nchunk; k += 4) s += part[(size_t)k * C + col];
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && col < C) {
+        s = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+        float* o = col < seg ? out0 : (col < 2 * seg ? out1 : out2);
+        if (o) o[col % seg] = s;
+    }
 }
 
 // ---- LayerNorm backward.  One wave per row (grid-stride): dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;
-// dx_out[r] = dx (+ add[r] when given).  Per-wave partial sums of dgamma = dy * xhat and dbeta = dy go to part[wave][2D].
-template <int NCH>
+// out[r] = dx + add[r]; also stored as operand type (the next GEMMs' A operand).  Per-block partial sums of
+// dgamma = dy * xhat, dbeta = dy and of the OUTPUT's columns (= bias gradient of the linear layer below) -> part[block][3D].
+template <int NCH, typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const float* x, const float* stats, const float* gamma, const float* add,
-                                                     float* dx_out, float* part, const int* m_dev, int M_static) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, D = NCH * 256;
+                                                     float* dx_out, T* dx_op, float* part, const int* m_dev, int M_static) {
+    typedef typename OpT<T>::v4 v4;
+    constexpr int D = NCH * 256;
+    __shared__ __attribute__((aligned(16))) float red[3 * D];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int M = m_dev ? min(*m_dev, M_static) : M_static;
-    f32x4 dg[NCH], db[NCH];
+    f32x4 dg[NCH], db[NCH], dc[NCH];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) { dg[c] = f32x4{0.f, 0.f, 0.f, 0.f}; db[c] = dg[c]; }
+    for (int c = 0; c < NCH; ++c) { dg[c] = f32x4{0.f, 0.f, 0.f, 0.f}; db[c] = dg[c]; dc[c] = dg[c]; }
     for (int r = blockIdx.x * 4 + w; r < M; r += gridDim.x * 4) {
         const float mu = stats[2 * (size_t)r], rstd = stats[2 * (size_t)r + 1];
         f32x4 xh[NCH], g[NCH];
@@ -86,15 +110,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const floa
             f32x4 o = (g[c] - m1 - xh[c] * m2) * rstd;
             if (add) o += *(const f32x4*)(add + (size_t)r * D + col);
             *(f32x4*)(dx_out + (size_t)r * D + col) = o;
+            dc[c] += o;
+            v4 ob;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ob[e] = (T)o[e];
+            *(v4*)(dx_op + (size_t)r * D + col) = ob;
         }
     }
-    float* pw = part + (size_t)(blockIdx.x * 4 + w) * 2 * D;
+    // block reduction in a fixed order (wave 0, 1, 2, 3) through LDS, then one partial row per block
+    for (int k = 0; k < 4; ++k) {
+        if (w == k) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int col = (lane + 64 * c) * 4;
-        *(f32x4*)(pw + col) = dg[c];
-        *(f32x4*)(pw + D + col) = db[c];
+            for (int c = 0; c < NCH; ++c) {
+                const int col = (lane + 64 * c) * 4;
+                OFX_LDS f32x4* a0 = (OFX_LDS f32x4*)(red + col);
+                OFX_LDS f32x4* a1 = (OFX_LDS f32x4*)(red + D + col);
+                OFX_LDS f32x4* a2 = (OFX_LDS f32x4*)(red + 2 * D + col);
+                if (k == 0) { *a0 = dg[c]; *a1 = db[c]; *a2 = dc[c]; }
+                else { *a0 += dg[c]; *a1 += db[c]; *a2 += dc[c]; }
+            }
+        }
+        __syncthreads();
     }
+    float* pw = part + (size_t)blockIdx.x * 3 * D;
+    for (int i = threadIdx.x; i < 3 * D / 4; i += 256) *(f32x4*)(pw + 4 * i) = *(OFX_LDS f32x4*)(red + 4 * i);
 }
 
 // ---- fp32 set-attention backward, one wave per (outfit, head): recompute P = softmax(q k^T * scale), then
@@ -102,12 +141,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const floa
 struct SetBwdK {
     const float* qkv;   // [rows, 3D]
     const float* d_o;   // [rows, D]
-    float* dqkv;        // [rows, 3D]
+    void* dqkv;         // [rows, 3D] operand type (feeds the dgrad / wgrad GEMMs directly)
     const int* cu;
     int n_head, D;
     float scale;
 };
-template <int SMAX>
+template <typename T, int SMAX>
 __global__ __launch_bounds__(64) void set_attention_bwd_kernel(SetBwdK a) {
     constexpr int STR = 68, PS = SMAX + 4;
     __shared__ __attribute__((aligned(16))) float qs[SMAX * STR], ks[SMAX * STR], vs[SMAX * STR], gs[SMAX * STR];
@@ -161,8 +200,8 @@ __global__ __launch_bounds__(64) void set_attention_bwd_kernel(SetBwdK a) {
             dk += dS[i * PS + j] * qs[i * STR + lane];
             dv += P[i * PS + j] * gs[i * STR + lane];
         }
-        float* op = a.dqkv + (size_t)(r0 + j) * 3 * D + h * 64 + lane;
-        op[0] = dq; op[D] = dk; op[2 * D] = dv;
+        T* op = (T*)a.dqkv + (size_t)(r0 + j) * 3 * D + h * 64 + lane;
+        op[0] = (T)dq; op[D] = (T)dk; op[2 * D] = (T)dv;
     }
 }
 
@@ -193,102 +232,89 @@ __global__ __launch_bounds__(256) void focal_loss_kernel(const float* logits, co
     if (threadIdx.x == 0 && loss) *loss = red[0] / B;
 }
 
-// CP head backward: d_row0[b] = dlogit[b] * w ; dw = sum_b dlogit[b] * row0[b] ; db = sum_b dlogit[b]
-__global__ __launch_bounds__(256) void cp_head_bwd_kernel(const float* dlogits, const float* row0, const float* w, float* d_row0, float* dw, float* db,
-                                                         int B, int D, int accumulate) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col < D) {
-        float s = 0.f;
-        const float wc = w[col];
-        for (int b = 0; b < B; ++b) {
-            const float g = dlogits[b];
-            s += g * row0[(size_t)b * D + col];
-            d_row0[(size_t)b * D + col] = g * wc;
-        }
-        dw[col] = accumulate ? dw[col] + s : s;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) s += dlogits[b];
-        db[0] = accumulate ? db[0] + s : s;
-    }
-}
 
-// dX[cu[b]] = d_row0[b], everything else zero (gradient of "take row 0")
-__global__ __launch_bounds__(256) void scatter_row0_kernel(const float* d_row0, const int* cu, float* dX, int B, int D, size_t total4, const int* m_dev) {
-    const size_t live = m_dev ? (size_t)*m_dev * D / 4 : total4;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < live; i += (size_t)gridDim.x * blockDim.x) ((f32x4*)dX)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-}
-__global__ __launch_bounds__(256) void scatter_row0_write_kernel(const float* d_row0, const int* cu, float* dX, int B, int D) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int b = blockIdx.x * 4 + w; b < B; b += gridDim.x * 4)
-        for (int c = lane; c < D / 4; c += 64) *(f32x4*)(dX + (size_t)cu[b] * D + c * 4) = *(const f32x4*)(d_row0 + (size_t)b * D + c * 4);
-}
-// out[col] (+)= sum_b dX[cu[b]][col]  (gradient of the shared prefix token), cols [c0, c0+n)
-__global__ __launch_bounds__(256) void prefix_grad_kernel(const float* dX, const int* cu, float* out, int B, int D, int c0, int n, int accumulate) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= n) return;
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dX[(size_t)cu[b] * D + c0 + col];
-    out[col] = accumulate ? out[col] + s : s;
+// CP head backward, row part: dX[cu[b]] = dlogit[b] * w (fp32 + operand copy; the rest of dX was zeroed: gradient of
+// "take row 0" then Linear(D, 1)); block 0 also writes db = sum_b dlogit[b].
+template <typename T>
+__global__ __launch_bounds__(256) void cp_head_bwd_kernel(const float* dlogits, const float* w, const int* cu, float* dX, T* dXb, float* db, int B, int D) {
+    typedef typename OpT<T>::v4 v4;
+    const int b = blockIdx.x;
+    const float g = dlogits[b];
+    const size_t row = (size_t)cu[b] * D;
+    for (int c = threadIdx.x * 4; c < D; c += 1024) {
+        const f32x4 v = *(const f32x4*)(w + c) * g;
+        *(f32x4*)(dX + row + c) = v;
+        v4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
+        *(v4*)(dXb + row + c) = o;
+    }
+    if (b == 0) {
+        __shared__ float red[256];
+        float s = 0.f;
+        for (int i = threadIdx.x; i < B; i += 256) s += dlogits[i];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+        if (threadIdx.x == 0) db[0] = red[0];
+    }
 }
 
 }  // namespace
 
 #define BWD_CHECK() OFX_LAUNCH_CHECK()
 
-int ofx_launch_cast_transpose(const void* src, int src_is_f32, int ld_src, void* row_out, int ld_row, void* t_out, int Mpad, int C,
-                              const int* m_dev, int M, int op_dtype, hipStream_t s) {
-    OFX_REQUIRE(Mpad % 64 == 0 && Mpad >= M, OFX_ESHAPE, "cast_transpose: Mpad=%d must be a multiple of 64 and >= M=%d", Mpad, M);
-    ProfScope prof(PROF_OTHER, s);
-    const dim3 grid((C + 63) / 64, Mpad / 64);
-#define CT(TI, T) hipLaunchKernelGGL((cast_transpose_kernel<TI, T>), grid, dim3(256), 0, s, (const TI*)src, ld_src, (T*)row_out, ld_row, (T*)t_out, Mpad, C, m_dev, M)
-    if (op_dtype == OFX_F16) { if (src_is_f32) CT(float, f16_t); else CT(f16_t, f16_t); }
-    else { if (src_is_f32) CT(float, bf16_t); else CT(bf16_t, bf16_t); }
-#undef CT
+int ofx_launch_transpose_cast(const float* src, void* dst, int R, int C, int ldd, int op_dtype, hipStream_t s) {
+    OFX_REQUIRE(ldd >= R, OFX_ESHAPE, "transpose_cast: ldd=%d < R=%d", ldd, R);
+    const dim3 grid((C + 63) / 64, (R + 63) / 64);
+    if (op_dtype == OFX_F16) hipLaunchKernelGGL(transpose_cast_kernel<f16_t>, grid, dim3(256), 0, s, src, (f16_t*)dst, R, C, ldd);
+    else hipLaunchKernelGGL(transpose_cast_kernel<bf16_t>, grid, dim3(256), 0, s, src, (bf16_t*)dst, R, C, ldd);
     BWD_CHECK();
     return OFX_OK;
 }
 
-int ofx_launch_colsum(const void* x, int x_is_f32, int ld, float* out, float* part, int C, const int* m_dev, int M, int accumulate, int op_dtype, hipStream_t s) {
-    const int nchunk = 32;
+// out[c] = sum_r scale[r] * x[gather ? gather[r] : r][c]; C a multiple of 4; part: ofx_colsum_part_floats(C) floats.
+// Up to three outputs: column c goes to out_k[c % seg], k = c / seg (seg = C for a single output).
+constexpr int COLSUM_MAX_CHUNKS = 256;
+size_t ofx_colsum_part_floats(int C) { return (size_t)COLSUM_MAX_CHUNKS * C; }
+int ofx_launch_colsum(const void* x, int x_kind /*0 fp32 | 1 operand type*/, int ld, const int* gather, const float* row_scale, float* out0, float* out1,
+                      float* out2, int seg, float* part, int C, const int* m_dev, int M, int op_dtype, hipStream_t s) {
+    OFX_REQUIRE(C % 4 == 0 && M > 0 && (ld % 4 == 0), OFX_ESHAPE, "colsum: C=%d ld=%d", C, ld);
+    int nchunk = M / 16; nchunk = nchunk < 1 ? 1 : (nchunk > COLSUM_MAX_CHUNKS ? COLSUM_MAX_CHUNKS : nchunk);
     ProfScope prof(PROF_OTHER, s);
-    const dim3 grid((C + 255) / 256, nchunk);
-    if (x_is_f32) hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ld, part, C, m_dev, M, nchunk);
-    else if (op_dtype == OFX_F16) hipLaunchKernelGGL(colsum_partial_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)x, ld, part, C, m_dev, M, nchunk);
-    else hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, part, C, m_dev, M, nchunk);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, part, out, C, nchunk, accumulate);
+    const dim3 grid((C + 1023) / 1024, nchunk);
+    if (x_kind == 0) hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ld, gather, row_scale, part, C, m_dev, M, nchunk);
+    else if (op_dtype == OFX_F16) hipLaunchKernelGGL(colsum_partial_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)x, ld, gather, row_scale, part, C, m_dev, M, nchunk);
+    else hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, gather, row_scale, part, C, m_dev, M, nchunk);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s, part, C, nchunk, out0, out1, out2, seg);
     BWD_CHECK();
     return OFX_OK;
 }
 
 constexpr int LN_BWD_BLOCKS = 256;
-int ofx_launch_ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* add, float* dx_out,
-                      float* dgamma, float* dbeta, float* part /*[LN_BWD_BLOCKS*4, 2D] + [32, 2D]*/, int D, const int* m_dev, int M, int accumulate, hipStream_t s) {
+size_t ofx_ln_bwd_part_floats(int D) { return (size_t)LN_BWD_BLOCKS * 3 * D; }
+int ofx_launch_ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* add, float* dx_out, void* dx_op,
+                      float* dgamma, float* dbeta, float* dcols, float* part, int D, const int* m_dev, int M, int op_dtype, hipStream_t s) {
     OFX_REQUIRE(D == 512 || D == 768 || D == 1024, OFX_ESHAPE, "ln_bwd: D=%d", D);
     ProfScope prof(PROF_NORM, s);
-    if (D == 1024) hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(LN_BWD_BLOCKS), dim3(256), 0, s, dy, x, stats, gamma, add, dx_out, part, m_dev, M);
-    else if (D == 768) hipLaunchKernelGGL(ln_bwd_kernel<3>, dim3(LN_BWD_BLOCKS), dim3(256), 0, s, dy, x, stats, gamma, add, dx_out, part, m_dev, M);
-    else hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(LN_BWD_BLOCKS), dim3(256), 0, s, dy, x, stats, gamma, add, dx_out, part, m_dev, M);
-    // reduce the per-wave partials [LN_BWD_BLOCKS*4, 2D]: column sums of a fp32 matrix with 2D columns
-    float* part2 = part + (size_t)LN_BWD_BLOCKS * 4 * 2 * D;
-    const int nchunk = 32, C = 2 * D, rows = LN_BWD_BLOCKS * 4;
-    hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3((C + 255) / 256, nchunk), dim3(256), 0, s, part, C, part2, C, nullptr, rows, nchunk);
-    // dgamma = first D columns, dbeta = last D
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((D + 255) / 256), dim3(256), 0, s, part2, dgamma, C, nchunk, accumulate);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((D + 255) / 256), dim3(256), 0, s, part2 + D, dbeta, C, nchunk, accumulate);
+#define LNB(NCH, T) hipLaunchKernelGGL((ln_bwd_kernel<NCH, T>), dim3(LN_BWD_BLOCKS), dim3(256), 0, s, dy, x, stats, gamma, add, dx_out, (T*)dx_op, part, m_dev, M)
+    if (op_dtype == OFX_F16) { if (D == 1024) LNB(4, f16_t); else if (D == 768) LNB(3, f16_t); else LNB(2, f16_t); }
+    else { if (D == 1024) LNB(4, bf16_t); else if (D == 768) LNB(3, bf16_t); else LNB(2, bf16_t); }
+#undef LNB
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((3 * D + 63) / 64), dim3(256), 0, s, part, 3 * D, LN_BWD_BLOCKS, dgamma, dbeta, dcols, D);
     BWD_CHECK();
     return OFX_OK;
 }
-size_t ofx_ln_bwd_part_floats(int D) { return (size_t)LN_BWD_BLOCKS * 4 * 2 * D + (size_t)32 * 2 * D; }
 
-int ofx_launch_set_attention_bwd(const float* qkv, const float* d_o, float* dqkv, const int* cu, int nseq, int n_head, int D, int max_len,
-                                 float scale, hipStream_t s) {
+int ofx_launch_set_attention_bwd(const float* qkv, const float* d_o, void* dqkv, const int* cu, int nseq, int n_head, int D, int max_len,
+                                 float scale, int op_dtype, hipStream_t s) {
     OFX_REQUIRE(D == n_head * 64 && max_len >= 1 && max_len <= 32, OFX_ESHAPE, "set_attention_bwd: bad shape");
     SetBwdK k{qkv, d_o, dqkv, cu, n_head, D, scale};
     ProfScope prof(PROF_ATTN, s);
-    if (max_len <= 20) hipLaunchKernelGGL(set_attention_bwd_kernel<20>, dim3(nseq * n_head), dim3(64), 0, s, k);
-    else hipLaunchKernelGGL(set_attention_bwd_kernel<32>, dim3(nseq * n_head), dim3(64), 0, s, k);
+#define SAB(T, S) hipLaunchKernelGGL((set_attention_bwd_kernel<T, S>), dim3(nseq * n_head), dim3(64), 0, s, k)
+    if (op_dtype == OFX_F16) { if (max_len <= 20) SAB(f16_t, 20); else SAB(f16_t, 32); }
+    else { if (max_len <= 20) SAB(bf16_t, 20); else SAB(bf16_t, 32); }
+#undef SAB
     BWD_CHECK();
     return OFX_OK;
 }
@@ -298,21 +324,10 @@ int ofx_launch_focal_loss(const float* logits, const float* labels, int B, float
     BWD_CHECK();
     return OFX_OK;
 }
-int ofx_launch_cp_head_bwd(const float* dlogits, const float* row0, const float* w, float* d_row0, float* dw, float* db, int B, int D, int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(cp_head_bwd_kernel, dim3((D + 255) / 256), dim3(256), 0, s, dlogits, row0, w, d_row0, dw, db, B, D, accumulate);
-    BWD_CHECK();
-    return OFX_OK;
-}
-int ofx_launch_scatter_row0(const float* d_row0, const int* cu, float* dX, int B, int D, int M, const int* m_dev, hipStream_t s) {
-    const size_t total4 = (size_t)M * D / 4;
-    int grid = (int)((total4 + 255) / 256); if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(scatter_row0_kernel, dim3(grid), dim3(256), 0, s, d_row0, cu, dX, B, D, total4, m_dev);
-    hipLaunchKernelGGL(scatter_row0_write_kernel, dim3((B + 3) / 4 > 4096 ? 4096 : (B + 3) / 4), dim3(256), 0, s, d_row0, cu, dX, B, D);
-    BWD_CHECK();
-    return OFX_OK;
-}
-int ofx_launch_prefix_grad(const float* dX, const int* cu, float* out, int B, int D, int c0, int n, int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(prefix_grad_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dX, cu, out, B, D, c0, n, accumulate);
+int ofx_launch_cp_head_bwd(const float* dlogits, const float* w, const int* cu, float* dX, void* dXb, float* db, int B, int D, int op_dtype, hipStream_t s) {
+    OFX_REQUIRE(D % 4 == 0, OFX_ESHAPE, "cp_head_bwd: D=%d", D);
+    if (op_dtype == OFX_F16) hipLaunchKernelGGL(cp_head_bwd_kernel<f16_t>, dim3(B), dim3(256), 0, s, dlogits, w, cu, dX, (f16_t*)dXb, db, B, D);
+    else hipLaunchKernelGGL(cp_head_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, s, dlogits, w, cu, dX, (bf16_t*)dXb, db, B, D);
     BWD_CHECK();
     return OFX_OK;
 }

@@ -109,6 +109,38 @@ def test_gemm_split_k_is_deterministic_and_exact(M, N, K, kind):
         assert rel_err(outs[0][:, :N] + outs[0][:, N:2 * N], z) < 3e-5
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K,kdev,split", [(256, 256, 64, None, False), (512, 256, 200, None, False), (1024, 512, 2304, 2000, True),
+                                              (256, 768, 1, None, True), (768, 256, 4352, 2305, True), (256, 256, 640, 0, True)])
+def test_gemm_tn_weight_gradient_kernel(dt, M, N, K, kdev, split):
+    """C = A^T B with the contraction over ROWS (transposed LDS reads): asymmetric operands, K not a multiple of 64,
+    device-side live row count (rows past it are garbage / NaN and must not contribute), with and without split-K."""
+    lib = L.load()
+    g = np.random.default_rng(M + N + K)
+    Kp = (K + 63) // 64 * 64
+    lda, ldb = M + 8, N + 16
+    a = g.standard_normal((Kp, lda), dtype=np.float32)
+    b = g.standard_normal((Kp, ldb), dtype=np.float32) / np.sqrt(max(K, 1))
+    live = K if kdev is None else kdev
+    a[live:] = np.nan; b[live:] = np.nan
+    A, B = to_op(a, dt), to_op(b, dt)
+    kd = None if kdev is None else torch.tensor([kdev], dtype=torch.int32, device="cuda")
+    nb = lib.ofx_gemm_tn_ws(M, N, K) if split else 0
+    slab = torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
+    outs = []
+    for rep in range(2):
+        out = torch.full((M, N + 4), float("nan"), device="cuda")
+        L.check(lib.ofx_gemm_tn(A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), N + 4, M, N, K, None if kd is None else kd.data_ptr(),
+                                slab.data_ptr() if nb else None, nb, DT[dt], stream()))
+        outs.append(out.cpu().numpy())
+    assert np.array_equal(outs[0][:, :N], outs[1][:, :N]) and np.isnan(outs[0][:, N:]).all()
+    want = A[:live, :M].double().cpu().numpy().T @ B[:live, :N].double().cpu().numpy()
+    if live == 0:
+        assert not outs[0][:, :N].any()
+    else:
+        assert rel_err(outs[0][:, :N], want) < 2e-5
+
+
 @pytest.mark.parametrize("act", [0, 1, 2, 3])
 def test_gemm_epilogue_bias_act_residual(act):
     M, N, K = 333, 256, 512
