@@ -60,15 +60,21 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const TI* x, int ld
 }
 // out_k[c % seg] for c in segment k = c / seg (up to three destinations: LayerNorm's dgamma | dbeta | column sums)
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* part, int C, int nchunk, float* out0, float* out1, float* out2, int seg) {
-    __shared__ float red[4][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + cx;
-    float s = 0.f;
-    if (col < C) for (int k = ry; k < nchunk; k += 4) s += part[(size_t)k * C + col];
-    red[ry][cx] = s;
+    __shared__ float red[16][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;          // 16 columns x 16 row groups per block
+    const int col = blockIdx.x * 16 + cx;
+    float s0 = 0.f, s1 = 0.f;
+    if (col < C) {
+        int k = ry;
+        for (; k + 16 < nchunk; k += 32) { s0 += part[(size_t)k * C + col]; s1 += part[(size_t)(k + 16) * C + col]; }
+        if (k < nchunk) s0 += part[(size_t)k * C + col];
+    }
+    red[ry][cx] = s0 + s1;
     __syncthreads();
     if (ry == 0 && col < C) {
-        s = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][cx];
         float* o = col < seg ? out0 : (col < 2 * seg ? out1 : out2);
         if (o) o[col % seg] = s;
     }
@@ -286,7 +292,7 @@ int ofx_launch_colsum(const void* x, int x_kind /*0 fp32 | 1 operand type*/, int
     if (x_kind == 0) hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ld, gather, row_scale, part, C, m_dev, M, nchunk);
     else if (op_dtype == OFX_F16) hipLaunchKernelGGL(colsum_partial_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)x, ld, gather, row_scale, part, C, m_dev, M, nchunk);
     else hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, gather, row_scale, part, C, m_dev, M, nchunk);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s, part, C, nchunk, out0, out1, out2, seg);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, C, nchunk, out0, out1, out2, seg);
     BWD_CHECK();
     return OFX_OK;
 }
@@ -301,7 +307,7 @@ int ofx_launch_ln_bwd(const float* dy, const float* x, const float* stats, const
     if (op_dtype == OFX_F16) { if (D == 1024) LNB(4, f16_t); else if (D == 768) LNB(3, f16_t); else LNB(2, f16_t); }
     else { if (D == 1024) LNB(4, bf16_t); else if (D == 768) LNB(3, bf16_t); else LNB(2, bf16_t); }
 #undef LNB
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((3 * D + 63) / 64), dim3(256), 0, s, part, 3 * D, LN_BWD_BLOCKS, dgamma, dbeta, dcols, D);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((3 * D + 15) / 16), dim3(256), 0, s, part, 3 * D, LN_BWD_BLOCKS, dgamma, dbeta, dcols, D);
     BWD_CHECK();
     return OFX_OK;
 }

@@ -4,6 +4,11 @@ forward -> FocalLoss(.75, 2) -> backward -> clip_grad_norm_(1.0) -> AdamW step â
 (HIP tape forward + hand-written backward).  Per-GPU batch 256 (= 2048 / 8 ranks) by default.
 
     python tools/bench_train.py [--batch 256] [--items 8] [--steps 20] [--precision bf16] [--eager]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_train.py   (DP, RCCL)
+
+ms_step is the reference-shaped step (torch clip_grad_norm_ + default AdamW on per-tensor grads); ms_step_dp is the
+outfitx_amd.trainer.CPTrainer step (flat gradient arena, one all-reduce, fused AdamW), accumulation 1 = an optimizer step
+and an all-reduce on EVERY micro-batch (the worst case; the reference default accumulates 4).
 
 --eager also times the same step written with plain torch modules (nn.TransformerEncoder under bf16 autocast, what the
 reference's trainer executes) on the same GPU, for a like-for-like ratio.  Prints one JSON line.
@@ -51,6 +56,7 @@ def main():
     m = OutfitX(cfg, train_precision=a.precision)
     sd = synth.outfit_transformer_weights(7)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     m = m.cuda().train()
     params = [v for k, v in m.named_parameters() if not k.startswith("item_encoder.")]
     opt = torch.optim.AdamW(params, lr=2e-5)
@@ -81,6 +87,22 @@ def main():
     res["ms_fwd_bwd"] = timed(lambda: (opt.zero_grad(set_to_none=True), fwd_bwd()), a.steps, a.warmup)
     res["ms_tape_fwd"] = timed(fwd_only, a.steps, a.warmup)
     res["outfits_per_s"] = a.batch / res["ms_step"] * 1e3
+    # the DP trainer's step (world size from the launcher; 1 = no collective)
+    import torch.distributed as dist
+    from outfitx_amd.trainer import CPTrainConfig, CPTrainer
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl")
+    opt.zero_grad(set_to_none=True)
+    batch = {"input_dict": {"task": CP, "outfit_embedding": emb, "outfit_mask": mask}, "label": labels}
+    for acc in (1, 4):
+        tr = CPTrainer(m, steps_per_epoch=10 ** 9, cfg=CPTrainConfig(accumulation_steps=acc), params=params)
+        k = [0]
+        def dp_step():
+            tr.micro_step(batch, k[0]); k[0] += 1
+        res["ms_step_dp" if acc == 1 else "ms_step_dp_accum4"] = timed(dp_step, a.steps if acc == 1 else 4 * max(a.steps // 4, 1), a.warmup if acc == 1 else 4)
+    res["world"] = world
+    res["outfits_per_s_dp"] = world * a.batch / res["ms_step_dp"] * 1e3
     rows = a.batch * (a.items + 1)
     D, Fp = 1024, 2048
     res["gemm_tflop_per_step"] = 3 * 2 * rows * (4 * D * D + 2 * Fp * D) * 6 / 1e12
@@ -111,7 +133,10 @@ def main():
 
         res["ms_step_torch_eager_bf16"] = timed(eager_step, a.steps, a.warmup)
         res["speedup_vs_torch_eager"] = res["ms_step_torch_eager_bf16"] / res["ms_step"]
-    print(json.dumps(res))
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
