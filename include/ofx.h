@@ -132,10 +132,16 @@ int ofx_topk_merge(const int64_t* idx_in, const float* dist_in, int parts, int n
 size_t ofx_cp_train_tape_bytes(ofx_handle* h, int B, int L);
 size_t ofx_cp_train_ws_bytes(ofx_handle* h, int B, int L);
 size_t ofx_cp_train_grad_floats(ofx_handle* h, size_t* offsets, int n_offsets);
+/* dropout_p / seed: torch's train-mode dropout (attention probabilities, dropout1, FFN dropout, dropout2 of every layer and
+ * the head's nn.Dropout) with stateless masks = hash(seed, site, row, col); the backward call must repeat both values.
+ * Same distribution as torch's, not the same random stream. */
 int ofx_cp_train_fwd(ofx_handle* h, const float* x, const uint8_t* pad_mask, int B, int L, float* logits, void* tape, size_t tape_bytes,
-                     void* ws, size_t ws_bytes, ofx_stream stream);
+                     void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream);
 int ofx_cp_train_bwd(ofx_handle* h, void* tape, size_t tape_bytes, const float* dlogits, int B, int L, float* grads, size_t grad_floats,
-                     void* ws, size_t ws_bytes, ofx_stream stream);
+                     void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream);
+/* out[rows, cols] fp32 = keep-mask / (1 - p) of dropout site `site` (layer l: 4l + {0 attention [B*heads, 32*i + j], 1 dropout1,
+ * 2 FFN, 3 dropout2}; 4 * n_layers = head), exactly as the kernels compute it.  Test / debugging aid. */
+int ofx_dropout_mask(float dropout_p, unsigned seed, int site, int rows, int cols, float* out, ofx_stream stream);
 /* FocalLoss(alpha, gamma, mean) forward and d loss / d logits * upstream (src/losses/focal_loss.py:23-41). loss / dlogits may be NULL. */
 int ofx_focal_loss(const float* logits, const float* labels, int B, float alpha, float gamma, float upstream, float* loss, float* dlogits,
                    ofx_stream stream);

@@ -58,8 +58,9 @@ SIGNATURES = {
     "ofx_cp_train_tape_bytes": (_sz, [_vp, _i, _i]),
     "ofx_cp_train_ws_bytes": (_sz, [_vp, _i, _i]),
     "ofx_cp_train_grad_floats": (_sz, [_vp, C.POINTER(_sz), _i]),
-    "ofx_cp_train_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp, _sz, _vp]),
-    "ofx_cp_train_bwd": (_i, [_vp, _vp, _sz, _vp, _i, _i, _vp, _sz, _vp, _sz, _vp]),
+    "ofx_cp_train_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp, _sz, _f, C.c_uint, _vp]),
+    "ofx_cp_train_bwd": (_i, [_vp, _vp, _sz, _vp, _i, _i, _vp, _sz, _vp, _sz, _f, C.c_uint, _vp]),
+    "ofx_dropout_mask": (_i, [_f, C.c_uint, _i, _i, _i, _vp, _vp]),
     "ofx_focal_loss": (_i, [_vp, _vp, _i, _f, _f, _f, _vp, _vp, _vp]),
     "ofx_profile_enable": (None, [_i]),
     "ofx_profile_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),

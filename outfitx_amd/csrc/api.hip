@@ -73,11 +73,13 @@ int ofx_launch_colsum(const void* x, int x_kind, int ld, const int* gather, cons
                       float* part, int C, const int* m_dev, int M, int op_dtype, hipStream_t s);
 size_t ofx_ln_bwd_part_floats(int D);
 int ofx_launch_ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* add, float* dx_out, void* dx_op,
-                      float* dgamma, float* dbeta, float* dcols, float* part, int D, const int* m_dev, int M, int op_dtype, hipStream_t s);
+                      float* dgamma, float* dbeta, float* dcols, float* part, int D, const int* m_dev, int M, int op_dtype, const DropArgs& drop, hipStream_t s);
 int ofx_launch_set_attention_bwd(const float* qkv, const float* d_o, void* dqkv, const int* cu, int nseq, int n_head, int D, int max_len,
-                                 float scale, int op_dtype, hipStream_t s);
+                                 float scale, int op_dtype, const DropArgs& drop, hipStream_t s);
+int ofx_launch_drop_rows(float* x, int rows, int cols, const DropArgs& d, hipStream_t s);
 int ofx_launch_focal_loss(const float* logits, const float* labels, int B, float alpha, float gamma, float upstream, float* loss, float* dlogits, hipStream_t s);
-int ofx_launch_cp_head_bwd(const float* dlogits, const float* w, const int* cu, float* dX, void* dXb, float* db, int B, int D, int op_dtype, hipStream_t s);
+int ofx_launch_cp_head_bwd(const float* dlogits, const float* w, const int* cu, float* dX, void* dXb, float* db, int B, int D, int op_dtype,
+                           const DropArgs& head, const DropArgs& below, hipStream_t s);
 int ofx_launch_fitb(const float* y, const float* cand, int B, int C, int D, int64_t* idx, float* dist, hipStream_t s);
 int ofx_launch_l2_topk(const float* Q, const float* P, int nq, int np, int D, int k, int64_t index_base, int64_t* idx,
                        float* dist, void* ws, size_t ws_bytes, hipStream_t s);
@@ -651,8 +653,11 @@ extern "C" size_t ofx_cp_train_grad_floats(ofx_handle* h, size_t* offsets, int n
     return total;
 }
 
+// dropout sites: layer l -> 4l + {0 attention probabilities, 1 dropout1 (out_proj output), 2 FFN inner, 3 dropout2 (linear2 output)};
+// 4 * n_layers = the head's Dropout (cp_ffn[0]).  torch: nn.TransformerEncoderLayer._sa_block / _ff_block, MultiheadAttention dropout.
 extern "C" int ofx_cp_train_fwd(ofx_handle* h, const float* x, const uint8_t* pad_mask, int B, int L, float* logits, void* tape_mem,
-                                size_t tape_bytes, void* ws, size_t ws_bytes, ofx_stream stream) {
+                                size_t tape_bytes, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream) {
+    OFX_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, OFX_EINVAL, "cp_train_fwd: dropout_p=%g", dropout_p);
     OFX_REQUIRE(h && h->out_ready, OFX_ESTATE, "cp_train_fwd: outfit weights not packed");
     OFX_REQUIRE(h->ot_kmul == 1, OFX_ESTATE, "cp_train_fwd: training uses a single-product precision (bf16 / f16), not bf16x3");
     OFX_REQUIRE(B > 0 && L >= 0 && L <= 31 && (x || L == 0) && (pad_mask || L == 0) && logits && tape_mem, OFX_EINVAL, "cp_train_fwd: bad argument");
@@ -679,25 +684,30 @@ extern "C" int ofx_cp_train_fwd(ofx_handle* h, const float* x, const uint8_t* pa
         g1.ldc = 3 * D; g1.out_kind = OFX_OUT_F32; g1.slab = w.slab; g1.slab_bytes = w.slab_bytes;
         TRY(ofx_launch_gemm(g1, dt, s));
         SetAttnArgs sa{t.QKV, t.O, T.cu, B, d.n_head, D, D, OFX_OUT_OP, L + 1, 0, 0.125f};
+        sa.drop = make_drop(dropout_p, seed, 4 * l + 0);
         TRY(ofx_launch_set_attention(sa, dt, s));
         GemmArgs g2{}; g2.A = t.O; g2.W = Ly.w_out; g2.C = t.Xmid; g2.bias = Ly.b_out; g2.resid = t.Xin; g2.m_dev = m_dev; g2.M = M; g2.N = D; g2.K = D;
         g2.lda = D; g2.ldc = D; g2.ldr = D; g2.out_kind = OFX_OUT_F32; g2.slab = w.slab; g2.slab_bytes = w.slab_bytes;
+        g2.drop = make_drop(dropout_p, seed, 4 * l + 1);
         TRY(ofx_launch_gemm(g2, dt, s));
         LnArgs ln2{t.Xmid, nullptr, Ly.g2, Ly.be2, t.H2, M, D, D, OFX_OUT_OP, d.ln_eps}; ln2.stats = t.st2;
         TRY(ofx_launch_layernorm_dev(ln2, m_dev, dt, s));
         GemmArgs g3{}; g3.A = t.H2; g3.W = Ly.w_1; g3.C = t.A; g3.bias = Ly.b_1; g3.aux_out = t.Upre; g3.m_dev = m_dev; g3.M = M; g3.N = Fp; g3.K = D;
         g3.lda = D; g3.ldc = Fp; g3.act = d.outfit_act; g3.out_kind = OFX_OUT_OP; g3.slab = w.slab; g3.slab_bytes = w.slab_bytes;
+        g3.drop = make_drop(dropout_p, seed, 4 * l + 2);
         TRY(ofx_launch_gemm(g3, dt, s));
         GemmArgs g4{}; g4.A = t.A; g4.W = Ly.w_2; g4.C = Xnext; g4.bias = Ly.b_2; g4.resid = t.Xmid; g4.m_dev = m_dev; g4.M = M; g4.N = D; g4.K = Fp;
         g4.lda = Fp; g4.ldc = D; g4.ldr = D; g4.out_kind = OFX_OUT_F32; g4.slab = w.slab; g4.slab_bytes = w.slab_bytes;
+        g4.drop = make_drop(dropout_p, seed, 4 * l + 3);
         TRY(ofx_launch_gemm(g4, dt, s));
     }
     TRY(ofx_launch_gather_row0(T.Xfinal, T.cu, T.row0, B, D, s));
+    TRY(ofx_launch_drop_rows(T.row0, B, D, make_drop(dropout_p, seed, 4 * d.n_layers), s));     // the tape keeps the dropped-out rows
     return ofx_launch_cp_head(T.row0, h->cp_w, h->cp_b, logits, B, D, s);
 }
 
 extern "C" int ofx_cp_train_bwd(ofx_handle* h, void* tape_mem, size_t tape_bytes, const float* dlogits, int B, int L, float* grads,
-                                size_t grad_floats, void* ws, size_t ws_bytes, ofx_stream stream) {
+                                size_t grad_floats, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream) {
     OFX_REQUIRE(h && h->out_ready && h->ot_kmul == 1, OFX_ESTATE, "cp_train_bwd: needs packed single-product weights");
     OFX_REQUIRE(tape_mem && dlogits && grads && ws && B > 0, OFX_EINVAL, "cp_train_bwd: bad argument");
     OFX_REQUIRE(d_outfit_act_is_mish(h), OFX_ESTATE, "cp_train_bwd: only the Mish activation has a backward epilogue");
@@ -717,11 +727,13 @@ extern "C" int ofx_cp_train_bwd(ofx_handle* h, void* tape_mem, size_t tape_bytes
     const int D = d.d_model, Fp = h->ot_ffn_pad, dt = h->ot_dtype, M = B * (L + 1);
     const int* m_dev = T.cu + B;
     auto G = [&](int i) { return grads + off[i]; };
-    auto dgrad = [&](const void* A, int lda, const void* W, void* C, int ldc, int n, int k, int out_kind, int act, const float* resid, int ldr) {
+    auto dgrad = [&](const void* A, int lda, const void* W, void* C, int ldc, int n, int k, int out_kind, int act, const float* resid, int ldr, const DropArgs& drop) {
         GemmArgs g{}; g.A = A; g.W = W; g.C = C; g.M = M; g.N = n; g.K = k; g.lda = lda; g.ldc = ldc; g.out_kind = out_kind; g.act = act; g.resid = resid; g.ldr = ldr;
-        g.m_dev = m_dev; g.slab = w.slab; g.slab_bytes = w.slab_bytes;
+        g.m_dev = m_dev; g.slab = w.slab; g.slab_bytes = w.slab_bytes; g.drop = drop;
         return ofx_launch_gemm(g, dt, s);
     };
+    auto site = [&](int l, int k) { return make_drop(dropout_p, seed, 4 * l + k); };
+    const DropArgs nodrop;
     // dW[n_w, k_w] = dY[rows, n_w]^T X[rows, k_w], contraction over the live rows
     auto wgrad = [&](const void* dY, int n_w, const void* X, int k_w, float* out) {
         return ofx_launch_gemm_tn(dY, n_w, X, k_w, out, k_w, n_w, k_w, M, m_dev, w.slab, w.slab_bytes, dt, s);
@@ -730,33 +742,44 @@ extern "C" int ofx_cp_train_bwd(ofx_handle* h, void* tape_mem, size_t tape_bytes
     float* dX = w.dXa; float* dX2 = w.dXb_f;
     OFX_HIP(hipMemsetAsync(dX, 0, (size_t)M * D * 4, s));
     OFX_HIP(hipMemsetAsync(w.gXb, 0, (size_t)M * D * 2, s));
-    TRY(ofx_launch_cp_head_bwd(dlogits, h->cp_w, T.cu, dX, w.gXb, G(3), B, D, dt, s));
-    TRY(ofx_launch_colsum(T.row0, 0, D, nullptr, dlogits, G(2), nullptr, nullptr, D, w.part, D, nullptr, B, dt, s));                 // d cp_w = sum_b dlogit_b row0_b
-    // bias gradient of the last layer's linear2 = column sums of dX = (sum_b dlogit_b) w
-    TRY(ofx_launch_colsum(h->cp_w, 0, 0, nullptr, dlogits, G(5 + 12 * (d.n_layers - 1) + 7), nullptr, nullptr, D, w.part, D, nullptr, B, dt, s));
+    TRY(ofx_launch_cp_head_bwd(dlogits, h->cp_w, T.cu, dX, w.gXb, G(3), B, D, dt, site(d.n_layers, 0), site(d.n_layers - 1, 3), s));
+    TRY(ofx_launch_colsum(T.row0, 0, D, nullptr, dlogits, G(2), nullptr, nullptr, D, w.part, D, nullptr, B, dt, s));                 // d cp_w = sum_b dlogit_b (row0_b . m_head)
+    // bias gradient of the last layer's linear2 = column sums of (dX . m_dropout2): only the prefix rows are non-zero
+    TRY(ofx_launch_colsum(w.gXb, 1, D, T.cu, nullptr, G(5 + 12 * (d.n_layers - 1) + 7), nullptr, nullptr, D, w.part, D, nullptr, B, dt, s));
     for (int l = d.n_layers - 1; l >= 0; --l) {
         const OutfitLayer& Ly = h->ol[l];
         const TapeLayer& t = T.L[l];
         const int g0 = 5 + 12 * l;                    // Win, bin, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2
         // ---- FFN branch: Xout = Xmid + mish(H2 W1^T + b1) W2^T + b2        (gXb = operand copy of dX)
         TRY(wgrad(w.gXb, D, t.A, Fp, G(g0 + 6)));                                                                   // dW2 [D, Fp]
-        TRY(dgrad(w.gXb, D, Ly.w_2_t, w.dU, Fp, Fp, D, OFX_OUT_OP, OFX_ACT_MISH_GRAD, t.Upre, Fp));                 // dU = (dX W2) * mish'(Upre)
+        TRY(dgrad(w.gXb, D, Ly.w_2_t, w.dU, Fp, Fp, D, OFX_OUT_OP, OFX_ACT_MISH_GRAD, t.Upre, Fp, site(l, 2)));                 // dU = (dX W2) * mish'(Upre)
         TRY(ofx_launch_colsum(w.dU, 1, Fp, nullptr, nullptr, G(g0 + 5), nullptr, nullptr, Fp, w.part, Fp, m_dev, M, dt, s));   // db1
         TRY(wgrad(w.dU, Fp, t.H2, D, G(g0 + 4)));                                                                   // dW1 [Fp, D]
-        TRY(dgrad(w.dU, Fp, Ly.w_1_t, w.dH, D, D, Fp, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0));                      // dH2
-        TRY(ofx_launch_ln_bwd(w.dH, t.Xmid, t.st2, Ly.g2, dX, dX2, w.gXb, G(g0 + 10), G(g0 + 11), G(g0 + 3), w.part, D, m_dev, M, dt, s));   // dXmid (+ dbo)
+        TRY(dgrad(w.dU, Fp, Ly.w_1_t, w.dH, D, D, Fp, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nodrop));                      // dH2
+        TRY(ofx_launch_ln_bwd(w.dH, t.Xmid, t.st2, Ly.g2, dX, dX2, w.gXb, G(g0 + 10), G(g0 + 11), G(g0 + 3), w.part, D, m_dev, M, dt, site(l, 1), s));   // dXmid (+ dbo)
         // ---- attention branch: Xmid = Xin + O Wo^T + bo
         TRY(wgrad(w.gXb, D, t.O, D, G(g0 + 2)));                                                                    // dWo [D, D]
-        TRY(dgrad(w.gXb, D, Ly.w_out_t, w.dO, D, D, D, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0));                     // dO
-        TRY(ofx_launch_set_attention_bwd(t.QKV, w.dO, w.gQb, T.cu, B, d.n_head, D, L + 1, 0.125f, dt, s));
+        TRY(dgrad(w.gXb, D, Ly.w_out_t, w.dO, D, D, D, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nodrop));                     // dO
+        TRY(ofx_launch_set_attention_bwd(t.QKV, w.dO, w.gQb, T.cu, B, d.n_head, D, L + 1, 0.125f, dt, site(l, 0), s));
         TRY(ofx_launch_colsum(w.gQb, 1, 3 * D, nullptr, nullptr, G(g0 + 1), nullptr, nullptr, 3 * D, w.part, 3 * D, m_dev, M, dt, s));   // dbin
         TRY(wgrad(w.gQb, 3 * D, t.H1, D, G(g0 + 0)));                                                               // dWin [3D, D]
-        TRY(dgrad(w.gQb, 3 * D, Ly.w_in_t, w.dH, D, D, 3 * D, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0));              // dH1
+        TRY(dgrad(w.gQb, 3 * D, Ly.w_in_t, w.dH, D, D, 3 * D, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nodrop));              // dH1
         // dXin; its column sums are the bias gradient of the layer below's linear2
-        TRY(ofx_launch_ln_bwd(w.dH, t.Xin, t.st1, Ly.g1, dX2, dX, w.gXb, G(g0 + 8), G(g0 + 9), l > 0 ? G(g0 - 12 + 7) : nullptr, w.part, D, m_dev, M, dt, s));
+        TRY(ofx_launch_ln_bwd(w.dH, t.Xin, t.st1, Ly.g1, dX2, dX, w.gXb, G(g0 + 8), G(g0 + 9), l > 0 ? G(g0 - 12 + 7) : nullptr, w.part, D, m_dev, M, dt,
+                              l > 0 ? site(l - 1, 3) : nodrop, s));
     }
     // shared prefix token: d outfit_token = sum_b dX0[cu[b]]
     return ofx_launch_colsum(dX, 0, D, T.cu, nullptr, G(0), nullptr, nullptr, D, w.part, D, nullptr, B, dt, s);
+}
+
+// mask * 1/(1-p) of a dropout site as the kernels compute it (tests build a torch reference with the same masks)
+extern "C" int ofx_dropout_mask(float dropout_p, unsigned seed, int site, int rows, int cols, float* out, ofx_stream stream) {
+    OFX_REQUIRE(out && rows > 0 && cols > 0 && dropout_p >= 0.f && dropout_p < 1.f, OFX_EINVAL, "dropout_mask: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<float> ones((size_t)rows * cols, 1.0f);
+    OFX_HIP(hipMemcpyAsync(out, ones.data(), ones.size() * 4, hipMemcpyHostToDevice, s));
+    OFX_HIP(hipStreamSynchronize(s));
+    return ofx_launch_drop_rows(out, rows, cols, make_drop(dropout_p, seed, (unsigned)site), s);
 }
 
 extern "C" int ofx_focal_loss(const float* logits, const float* labels, int B, float alpha, float gamma, float upstream, float* loss, float* dlogits,

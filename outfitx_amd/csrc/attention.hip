@@ -180,6 +180,7 @@ struct SetK {
     const int* cu;
     int nseq, n_head, D, ldo, out_kind, only_row0;
     float scale;
+    DropArgs drop;
 };
 
 template <typename T, int SMAX>
@@ -227,7 +228,8 @@ __global__ __launch_bounds__(64) void set_attention_kernel(SetK a) {
         float sum = 0.f;
         for (int j = 0; j < S; ++j) { const float e = expf(row[j] - m); row[j] = e; sum += e; }
         const float inv = 1.0f / sum;
-        for (int j = 0; j < S; ++j) row[j] *= inv;
+        if (a.drop.thresh) for (int j = 0; j < S; ++j) row[j] *= inv * drop_mul(a.drop, blockIdx.x, lane * 32 + j);
+        else for (int j = 0; j < S; ++j) row[j] *= inv;
     }
     __syncthreads();
     for (int i = 0; i < nq; ++i) {
@@ -275,7 +277,7 @@ int ofx_launch_set_attention(const SetAttnArgs& g, int op_dtype, hipStream_t s) 
     OFX_REQUIRE(g.ldo >= (g.out_kind == 2 ? 3 * g.D : g.D), OFX_ESHAPE, "set_attention: bad ldo=%d", g.ldo);
     SetK k;
     k.qkv = g.qkv; k.out = (char*)g.out; k.cu = g.cu_seqlens; k.nseq = g.nseq; k.n_head = g.n_head; k.D = g.D; k.ldo = g.ldo;
-    k.out_kind = g.out_kind; k.only_row0 = g.only_row0; k.scale = g.scale;
+    k.out_kind = g.out_kind; k.only_row0 = g.only_row0; k.scale = g.scale; k.drop = g.drop;
     const int grid = g.nseq * g.n_head;
     ProfScope prof(PROF_ATTN, s);
 #define SA(T, N) hipLaunchKernelGGL((set_attention_kernel<T, N>), dim3(grid), dim3(64), 0, s, k)

@@ -81,11 +81,12 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* part, in
 }
 
 // ---- LayerNorm backward.  One wave per row (grid-stride): dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;
-// out[r] = dx + add[r]; also stored as operand type (the next GEMMs' A operand).  Per-block partial sums of
+// out[r] = dx + add[r]; also stored as operand type (the next GEMMs' A operand; times the dropout mask of the
+// linear layer below's output when training with dropout).  Per-block partial sums of
 // dgamma = dy * xhat, dbeta = dy and of the OUTPUT's columns (= bias gradient of the linear layer below) -> part[block][3D].
 template <int NCH, typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const float* x, const float* stats, const float* gamma, const float* add,
-                                                     float* dx_out, T* dx_op, float* part, const int* m_dev, int M_static) {
+                                                     float* dx_out, T* dx_op, float* part, const int* m_dev, int M_static, DropArgs drop) {
     typedef typename OpT<T>::v4 v4;
     constexpr int D = NCH * 256;
     __shared__ __attribute__((aligned(16))) float red[3 * D];
@@ -116,6 +117,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const floa
             f32x4 o = (g[c] - m1 - xh[c] * m2) * rstd;
             if (add) o += *(const f32x4*)(add + (size_t)r * D + col);
             *(f32x4*)(dx_out + (size_t)r * D + col) = o;
+            if (drop.thresh) {           // the copy that feeds the linear layer below is the gradient of ITS (dropped-out) output
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] *= drop_mul(drop, r, col + e);
+            }
             dc[c] += o;
             v4 ob;
 #pragma unroll
@@ -151,6 +156,7 @@ struct SetBwdK {
     const int* cu;
     int n_head, D;
     float scale;
+    DropArgs drop;
 };
 template <typename T, int SMAX>
 __global__ __launch_bounds__(64) void set_attention_bwd_kernel(SetBwdK a) {
@@ -194,8 +200,19 @@ __global__ __launch_bounds__(64) void set_attention_bwd_kernel(SetBwdK a) {
         for (int j = 0; j < S; ++j) { const float e = expf(pr[j] - m); pr[j] = e; sum += e; }
         const float inv = 1.0f / sum;
         float dot = 0.f;
-        for (int j = 0; j < S; ++j) { pr[j] *= inv; dot += pr[j] * dr[j]; }
-        for (int j = 0; j < S; ++j) dr[j] = pr[j] * (dr[j] - dot) * a.scale;
+        if (a.drop.thresh) {          // O = (P . m) V:  dP = (dO V^T) . m, dV uses P . m; softmax backward uses the undropped P
+            for (int j = 0; j < S; ++j) {
+                const float mk = drop_mul(a.drop, blockIdx.x, lane * 32 + j);
+                pr[j] *= inv; dr[j] *= mk; dot += pr[j] * dr[j];
+            }
+            for (int j = 0; j < S; ++j) {
+                dr[j] = pr[j] * (dr[j] - dot) * a.scale;
+                pr[j] *= drop_mul(a.drop, blockIdx.x, lane * 32 + j);
+            }
+        } else {
+            for (int j = 0; j < S; ++j) { pr[j] *= inv; dot += pr[j] * dr[j]; }
+            for (int j = 0; j < S; ++j) dr[j] = pr[j] * (dr[j] - dot) * a.scale;
+        }
     }
     __syncthreads();
     // per row j (lane = feature): dQ[j] = sum_i dS[j][i] K[i]; dK[j] = sum_i dS[i][j] Q[i]; dV[j] = sum_i P[i][j] dO[i]
@@ -241,18 +258,26 @@ __global__ __launch_bounds__(256) void focal_loss_kernel(const float* logits, co
 
 // CP head backward, row part: dX[cu[b]] = dlogit[b] * w (fp32 + operand copy; the rest of dX was zeroed: gradient of
 // "take row 0" then Linear(D, 1)); block 0 also writes db = sum_b dlogit[b].
+// With dropout: the head sees row0 . m_head (mask row = outfit), and the operand copy carries the mask of the last
+// layer's dropout2 (mask row = global row), like the copies LayerNorm backward emits.
 template <typename T>
-__global__ __launch_bounds__(256) void cp_head_bwd_kernel(const float* dlogits, const float* w, const int* cu, float* dX, T* dXb, float* db, int B, int D) {
+__global__ __launch_bounds__(256) void cp_head_bwd_kernel(const float* dlogits, const float* w, const int* cu, float* dX, T* dXb, float* db, int B, int D,
+                                                         DropArgs head, DropArgs below) {
     typedef typename OpT<T>::v4 v4;
     const int b = blockIdx.x;
     const float g = dlogits[b];
-    const size_t row = (size_t)cu[b] * D;
+    const int r = cu[b];
+    const size_t row = (size_t)r * D;
     for (int c = threadIdx.x * 4; c < D; c += 1024) {
-        const f32x4 v = *(const f32x4*)(w + c) * g;
+        f32x4 v = *(const f32x4*)(w + c) * g;
+        if (head.thresh) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= drop_mul(head, b, c + e);
+        }
         *(f32x4*)(dX + row + c) = v;
         v4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
+        for (int e = 0; e < 4; ++e) o[e] = (T)(below.thresh ? v[e] * drop_mul(below, r, c + e) : v[e]);
         *(v4*)(dXb + row + c) = o;
     }
     if (b == 0) {
@@ -266,9 +291,25 @@ __global__ __launch_bounds__(256) void cp_head_bwd_kernel(const float* dlogits, 
     }
 }
 
+// x[r][c] *= mask(r, c)   (head dropout on the pooled rows; also exports a mask for the tests when x is all ones)
+__global__ __launch_bounds__(256) void drop_rows_kernel(float* x, int rows, int cols, DropArgs d) {
+    const size_t total = (size_t)rows * cols;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        x[i] *= drop_mul(d, (unsigned)(i / cols), (unsigned)(i % cols));
+}
+
 }  // namespace
 
 #define BWD_CHECK() OFX_LAUNCH_CHECK()
+
+int ofx_launch_drop_rows(float* x, int rows, int cols, const DropArgs& d, hipStream_t s) {
+    if (!d.thresh) return OFX_OK;
+    size_t total = (size_t)rows * cols;
+    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(drop_rows_kernel, dim3(grid), dim3(256), 0, s, x, rows, cols, d);
+    BWD_CHECK();
+    return OFX_OK;
+}
 
 int ofx_launch_transpose_cast(const float* src, void* dst, int R, int C, int ldd, int op_dtype, hipStream_t s) {
     OFX_REQUIRE(ldd >= R, OFX_ESHAPE, "transpose_cast: ldd=%d < R=%d", ldd, R);
@@ -300,10 +341,10 @@ int ofx_launch_colsum(const void* x, int x_kind /*0 fp32 | 1 operand type*/, int
 constexpr int LN_BWD_BLOCKS = 256;
 size_t ofx_ln_bwd_part_floats(int D) { return (size_t)LN_BWD_BLOCKS * 3 * D; }
 int ofx_launch_ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* add, float* dx_out, void* dx_op,
-                      float* dgamma, float* dbeta, float* dcols, float* part, int D, const int* m_dev, int M, int op_dtype, hipStream_t s) {
+                      float* dgamma, float* dbeta, float* dcols, float* part, int D, const int* m_dev, int M, int op_dtype, const DropArgs& drop, hipStream_t s) {
     OFX_REQUIRE(D == 512 || D == 768 || D == 1024, OFX_ESHAPE, "ln_bwd: D=%d", D);
     ProfScope prof(PROF_NORM, s);
-#define LNB(NCH, T) hipLaunchKernelGGL((ln_bwd_kernel<NCH, T>), dim3(LN_BWD_BLOCKS), dim3(256), 0, s, dy, x, stats, gamma, add, dx_out, (T*)dx_op, part, m_dev, M)
+#define LNB(NCH, T) hipLaunchKernelGGL((ln_bwd_kernel<NCH, T>), dim3(LN_BWD_BLOCKS), dim3(256), 0, s, dy, x, stats, gamma, add, dx_out, (T*)dx_op, part, m_dev, M, drop)
     if (op_dtype == OFX_F16) { if (D == 1024) LNB(4, f16_t); else if (D == 768) LNB(3, f16_t); else LNB(2, f16_t); }
     else { if (D == 1024) LNB(4, bf16_t); else if (D == 768) LNB(3, bf16_t); else LNB(2, bf16_t); }
 #undef LNB
@@ -313,9 +354,9 @@ int ofx_launch_ln_bwd(const float* dy, const float* x, const float* stats, const
 }
 
 int ofx_launch_set_attention_bwd(const float* qkv, const float* d_o, void* dqkv, const int* cu, int nseq, int n_head, int D, int max_len,
-                                 float scale, int op_dtype, hipStream_t s) {
+                                 float scale, int op_dtype, const DropArgs& drop, hipStream_t s) {
     OFX_REQUIRE(D == n_head * 64 && max_len >= 1 && max_len <= 32, OFX_ESHAPE, "set_attention_bwd: bad shape");
-    SetBwdK k{qkv, d_o, dqkv, cu, n_head, D, scale};
+    SetBwdK k{qkv, d_o, dqkv, cu, n_head, D, scale, drop};
     ProfScope prof(PROF_ATTN, s);
 #define SAB(T, S) hipLaunchKernelGGL((set_attention_bwd_kernel<T, S>), dim3(nseq * n_head), dim3(64), 0, s, k)
     if (op_dtype == OFX_F16) { if (max_len <= 20) SAB(f16_t, 20); else SAB(f16_t, 32); }
@@ -330,10 +371,11 @@ int ofx_launch_focal_loss(const float* logits, const float* labels, int B, float
     BWD_CHECK();
     return OFX_OK;
 }
-int ofx_launch_cp_head_bwd(const float* dlogits, const float* w, const int* cu, float* dX, void* dXb, float* db, int B, int D, int op_dtype, hipStream_t s) {
+int ofx_launch_cp_head_bwd(const float* dlogits, const float* w, const int* cu, float* dX, void* dXb, float* db, int B, int D, int op_dtype,
+                           const DropArgs& head, const DropArgs& below, hipStream_t s) {
     OFX_REQUIRE(D % 4 == 0, OFX_ESHAPE, "cp_head_bwd: D=%d", D);
-    if (op_dtype == OFX_F16) hipLaunchKernelGGL(cp_head_bwd_kernel<f16_t>, dim3(B), dim3(256), 0, s, dlogits, w, cu, dX, (f16_t*)dXb, db, B, D);
-    else hipLaunchKernelGGL(cp_head_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, s, dlogits, w, cu, dX, (bf16_t*)dXb, db, B, D);
+    if (op_dtype == OFX_F16) hipLaunchKernelGGL(cp_head_bwd_kernel<f16_t>, dim3(B), dim3(256), 0, s, dlogits, w, cu, dX, (f16_t*)dXb, db, B, D, head, below);
+    else hipLaunchKernelGGL(cp_head_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, s, dlogits, w, cu, dX, (bf16_t*)dXb, db, B, D, head, below);
     BWD_CHECK();
     return OFX_OK;
 }

@@ -42,6 +42,7 @@ struct KArgs {
     int m_slab;                 // rows per slab plane (the host-side M, never the clamped live count)
     int splits, kt_per_split;   // 128x128 kernel only: blockIdx.y owns k-tiles [y*kt_per_split, ...) and writes a raw fp32 slab
     float* slab;                // [splits, M, N] partial sums when splits > 1
+    DropArgs drop;
 };
 
 __device__ __forceinline__ void glds16(const char* g, OFX_LDS char* l) {
@@ -70,6 +71,10 @@ __device__ __forceinline__ void epilogue(const KArgs& p, OFX_LDS float* ep, int 
                 if (ACT == OFX_ACT_QUICK_GELU) v[e] = act_quick_gelu(v[e]);
                 else if (ACT == OFX_ACT_GELU) v[e] = act_gelu(v[e]);
                 else if (ACT == OFX_ACT_MISH) v[e] = act_mish(v[e]);
+            }
+            if (p.drop.thresh) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= drop_mul(p.drop, gm, gn + e);
             }
             if (p.resid) {
                 const f32x4 rr = *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn);
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (p.splits > 1) {                                  // raw partial sums; bias / activation / residual happen in splitk_reduce
         KArgs q = p;
-        q.C = (char*)(p.slab + (size_t)blockIdx.y * p.m_slab * p.N); q.ldc = p.N; q.out_kind = 0; q.bias = nullptr; q.resid = nullptr; q.aux_out = nullptr;
+        q.C = (char*)(p.slab + (size_t)blockIdx.y * p.m_slab * p.N); q.ldc = p.N; q.out_kind = 0; q.bias = nullptr; q.resid = nullptr; q.aux_out = nullptr; q.drop.thresh = 0;
         epilogue<T, OFX_ACT_NONE>(q, ep, m0 + wm * 64, n0 + wn * 64, lane);
         return;
     }
@@ -289,6 +294,10 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
                     if (p.aux_out) *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn) = v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = act_apply<T, ACT>(v[e]);
+                    if (p.drop.thresh) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= drop_mul(p.drop, gm, gn + e);
+                    }
                     if (ACT == OFX_ACT_MISH_GRAD) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] *= act_mish_grad(res[i % (DEPTH + 1)][it][e]);
@@ -317,6 +326,10 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
                     if (p.aux_out) { *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn) = v0; *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn + 4) = v1; }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v0[e] = act_apply<T, ACT>(v0[e]); v1[e] = act_apply<T, ACT>(v1[e]); }
+                    if (p.drop.thresh) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v0[e] *= drop_mul(p.drop, gm, gn + e); v1[e] *= drop_mul(p.drop, gm, gn + 4 + e); }
+                    }
                     if (p.resid) {
                         const f32x4 r0 = *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn), r1 = *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn + 4);
                         if (ACT == OFX_ACT_MISH_GRAD) {
@@ -358,6 +371,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(KArgs p) {
         if (p.aux_out) *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn) = v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+        if (p.drop.thresh) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= drop_mul(p.drop, gm, gn + e);
+        }
         if (p.resid) {
             const f32x4 rr = *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn);
             if (p.act == OFX_ACT_MISH_GRAD) {
@@ -976,7 +993,7 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
     OFX_REQUIRE(op_dtype == OFX_BF16 || op_dtype == OFX_F16, OFX_EINVAL, "gemm: operand dtype must be bf16 or f16");
     KArgs k;
     k.A = (const char*)g.A; k.W = (const char*)g.W; k.C = (char*)g.C; k.bias = g.bias; k.resid = g.resid; k.aux_out = g.aux_out; k.m_dev = g.m_dev; k.dbg = g_gemm_dbg; k.skew = g_gemm_skew; k.splits = 1; k.slab = nullptr; k.m_slab = g.M; k.kt_per_split = 0;
-    k.M = g.M; k.N = g.N; k.K = g.K; k.lda = g.lda; k.ldc = g.ldc; k.ldr = g.ldr; k.act = g.act; k.out_kind = g.out_kind;
+    k.M = g.M; k.N = g.N; k.K = g.K; k.lda = g.lda; k.ldc = g.ldc; k.ldr = g.ldr; k.act = g.act; k.out_kind = g.out_kind; k.drop = g.drop;
     static bool attr_set = false;
     if (!attr_set) {
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<bf16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));

@@ -118,6 +118,28 @@ struct ProfScope {
 };
 
 // ---- internal launchers (defined in the .hip files, used by api.hip) ----
+// ---- dropout (training step): stateless masks.  Element (row, col) of dropout site `site` is kept iff
+// hash(seed, site, row, col) >= thresh, thresh = p * 2^32; kept values are scaled by 1 / (1 - p).  Forward and backward
+// recompute the same mask from the same counters, so no mask is ever stored.  thresh == 0 means "no dropout".
+struct DropArgs {
+    unsigned seed = 0, site = 0, thresh = 0;
+    float scale = 1.0f;
+};
+__host__ __device__ __forceinline__ unsigned ofx_fmix32(unsigned h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__host__ __device__ __forceinline__ float drop_mul(const DropArgs& d, unsigned row, unsigned col) {
+    unsigned h = ofx_fmix32(d.seed + d.site * 0x9E3779B9u + row * 0x632BE5ABu);
+    h = ofx_fmix32(h ^ (col * 0x9E3779B1u + 0x7F4A7C15u));
+    return h >= d.thresh ? d.scale : 0.0f;
+}
+inline DropArgs make_drop(float p, unsigned seed, unsigned site) {
+    DropArgs d;
+    if (p > 0.f) { d.seed = seed; d.site = site; d.thresh = (unsigned)((double)p * 4294967296.0); d.scale = 1.0f / (1.0f - p); }
+    return d;
+}
+
 struct GemmArgs {
     const void* A;      // [M, lda] operand type, K-contiguous
     const void* W;      // [N, K] operand type, K-contiguous (torch Linear layout)
@@ -131,6 +153,7 @@ struct GemmArgs {
     int M, N, K, lda, ldc, ldr;
     int act;            // ofx_act
     int out_kind;       // 0 fp32 | 1 operand type | 2 split3 (hi|lo|hi at column blocks of width N, ldc >= 3N; bf16 only)
+    DropArgs drop;      // applied to act(acc + bias) BEFORE the residual add (MISH_GRAD: to acc before the mish' factor)
 };
 int ofx_launch_gemm(const GemmArgs& g, int op_dtype /*OFX_BF16|OFX_F16*/, hipStream_t s);
 int ofx_gemm_splitk_plan(int M, int N, int K);
@@ -188,5 +211,6 @@ struct SetAttnArgs {
     int max_len;           // upper bound of 1 + items (<= 32)
     int only_row0;         // compute query row 0 of every set only (last layer)
     float scale;
+    DropArgs drop;         // attention-probability dropout (row = set * n_head + head, col = query * 32 + key)
 };
 int ofx_launch_set_attention(const SetAttnArgs& a, int op_dtype, hipStream_t s);

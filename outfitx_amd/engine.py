@@ -130,7 +130,7 @@ class Engine:
         total = int(self.lib.ofx_cp_train_grad_floats(self.h, offs, n))
         return total, list(offs)
 
-    def cp_train_fwd(self, x: torch.Tensor, mask: torch.Tensor):
+    def cp_train_fwd(self, x: torch.Tensor, mask: torch.Tensor, dropout_p: float = 0.0, seed: int = 0):
         """Tape-saving CP forward: x [B,L,D], mask [B,L] (True = pad) -> (logits [B,1] fp32, tape uint8 tensor)."""
         B, Lq, D = x.shape
         x = _f32c(x, self.device)
@@ -141,10 +141,10 @@ class Engine:
         logits = torch.empty(B, 1, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             L.check(self.lib.ofx_cp_train_fwd(self.h, _ptr(x), _ptr(m), B, Lq, _ptr(logits), _ptr(tape), tape.numel(),
-                                              _ptr(ws), ws.numel(), _stream(self.device)), "ofx_cp_train_fwd")
+                                              _ptr(ws), ws.numel(), float(dropout_p), int(seed) & 0xFFFFFFFF, _stream(self.device)), "ofx_cp_train_fwd")
         return logits, tape
 
-    def cp_train_bwd(self, tape: torch.Tensor, dlogits: torch.Tensor, B: int, Lq: int) -> torch.Tensor:
+    def cp_train_bwd(self, tape: torch.Tensor, dlogits: torch.Tensor, B: int, Lq: int, dropout_p: float = 0.0, seed: int = 0) -> torch.Tensor:
         """d loss / d logits [B,1] -> flat fp32 gradient buffer (layout: grad_layout())."""
         total, _ = self.grad_layout()
         g = torch.empty(total, dtype=torch.float32, device=self.device)
@@ -152,7 +152,7 @@ class Engine:
         ws = self.workspace(int(self.lib.ofx_cp_train_ws_bytes(self.h, B, Lq)))
         with torch.cuda.device(self.device):
             L.check(self.lib.ofx_cp_train_bwd(self.h, _ptr(tape), tape.numel(), _ptr(dl), B, Lq, _ptr(g), total,
-                                              _ptr(ws), ws.numel(), _stream(self.device)), "ofx_cp_train_bwd")
+                                              _ptr(ws), ws.numel(), float(dropout_p), int(seed) & 0xFFFFFFFF, _stream(self.device)), "ofx_cp_train_bwd")
         return g
 
     # ---------------------------------------------------------------- towers
@@ -218,6 +218,15 @@ def fitb_argmin(y_hat: torch.Tensor, cand: torch.Tensor, return_dist: bool = Fal
     with torch.cuda.device(dev):
         L.check(lib.ofx_fitb_argmin(_ptr(y), _ptr(c), B, Cn, D, _ptr(idx), _ptr(dist), _stream(dev)), "ofx_fitb_argmin")
     return (idx, dist) if return_dist else idx
+
+
+def dropout_mask(p: float, seed: int, site: int, rows: int, cols: int, device) -> torch.Tensor:
+    """keep-mask / (1 - p) of one dropout site exactly as the training kernels compute it (test aid)."""
+    lib = L.load()
+    out = torch.empty(rows, cols, dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        L.check(lib.ofx_dropout_mask(float(p), int(seed) & 0xFFFFFFFF, site, rows, cols, _ptr(out), _stream(out.device)), "ofx_dropout_mask")
+    return out
 
 
 def focal_loss(logits: torch.Tensor, labels: torch.Tensor, alpha: float, gamma: float, upstream: float = 1.0, need_grad: bool = True):

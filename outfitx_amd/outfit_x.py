@@ -44,9 +44,9 @@ class _CPTrainFn(torch.autograd.Function):
     the outfit transformer, outfit_token and cp_ffn; the embeddings are data (cp_trainer feeds precomputed ones)."""
 
     @staticmethod
-    def forward(ctx, eng, x, mask, F, *params):
-        logits, tape = eng.cp_train_fwd(x, mask)
-        ctx.eng, ctx.tape, ctx.bl, ctx.F = eng, tape, (x.shape[0], x.shape[1]), F
+    def forward(ctx, eng, x, mask, F, drop, *params):
+        logits, tape = eng.cp_train_fwd(x, mask, *drop)
+        ctx.eng, ctx.tape, ctx.bl, ctx.F, ctx.drop = eng, tape, (x.shape[0], x.shape[1]), F, drop
         ctx.shapes = [tuple(p.shape) for p in params]
         return logits
 
@@ -54,7 +54,7 @@ class _CPTrainFn(torch.autograd.Function):
     def backward(ctx, dlogits):
         eng = ctx.eng
         B, Lq = ctx.bl
-        g = eng.cp_train_bwd(ctx.tape, dlogits.contiguous(), B, Lq)
+        g = eng.cp_train_bwd(ctx.tape, dlogits.contiguous(), B, Lq, *ctx.drop)
         ctx.tape = None
         _, offs = eng.grad_layout()
         D, F = eng.desc.d_model, ctx.F
@@ -76,7 +76,7 @@ class _CPTrainFn(torch.autograd.Function):
                 for v in shp:
                     n *= v
                 out.append(g[offs[i]:offs[i] + n].view(shp))
-        return (None, None, None, None, *out)
+        return (None, None, None, None, None, *out)
 
 
 class OutfitX(nn.Module):
@@ -180,15 +180,17 @@ class OutfitX(nn.Module):
     def _cp_train_forward(self, outfit_embedding, outfit_mask):
         """CP trainer step (compatibility_prediction_trainer.py:57-81): forward with a tape, backward in libofx_hip.so."""
         t = self.cfg.transformer
-        if t.dropout != 0.0:
-            raise NotImplementedError("the HIP training step is deterministic (dropout = 0); set cfg.transformer.dropout = 0 "
-                                      "(dropout masks are the next increment of SURVEY.md §8f N1)")
         if self.train_precision not in ("bf16", "f16"):
             raise ValueError("train_precision must be 'bf16' or 'f16'")
         if outfit_embedding.requires_grad:
             raise NotImplementedError("gradients w.r.t. the item embeddings (encoder fine-tuning) are not built")
         eng = self._engine(self.train_precision)
-        return _CPTrainFn.apply(eng, outfit_embedding, outfit_mask, t.d_ffn, *self._outfit_tensors())
+        # dropout masks are hash(seed, site, element); the seed is drawn from torch's global generator, so
+        # torch.manual_seed() makes a run reproducible (same distribution as torch's dropout, not the same stream)
+        p = float(t.dropout)
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0.0 else 0
+        self.last_dropout = (p, seed)
+        return _CPTrainFn.apply(eng, outfit_embedding, outfit_mask, t.d_ffn, (p, seed), *self._outfit_tensors())
 
     def _cir_forward(self, outfit_embedding: torch.Tensor, outfit_mask: torch.Tensor,
                      target_item_text_embedding: torch.Tensor) -> torch.Tensor:

@@ -153,14 +153,95 @@ def test_fused_focal_loss_and_gradient_vs_golden_and_torch():
     assert np.abs(x.grad.cpu().numpy() - xr.grad.numpy()).max() <= 1e-6 * np.abs(xr.grad.numpy()).max() + 1e-9
 
 
+def test_dropout_masks_are_stateless_and_have_the_right_rate():
+    from outfitx_amd.engine import dropout_mask
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    a = dropout_mask(0.3, 1234, 5, 1000, 2048, torch.device("cuda"))
+    b = dropout_mask(0.3, 1234, 5, 1000, 2048, torch.device("cuda"))
+    c = dropout_mask(0.3, 1234, 6, 1000, 2048, torch.device("cuda"))
+    d = dropout_mask(0.3, 1235, 5, 1000, 2048, torch.device("cuda"))
+    assert torch.equal(a, b) and not torch.equal(a, c) and not torch.equal(a, d)
+    vals = torch.unique(a).cpu().numpy()
+    assert np.allclose(vals, [0.0, 1.0 / 0.7], rtol=1e-6)
+    for t in (a, c, d):
+        keep = float((t > 0).float().mean())
+        assert abs(keep - 0.7) < 3e-3                                   # 2M samples: sigma = 3.2e-4
+    # rows and columns are decorrelated: per-row and per-column keep rates scatter like a binomial
+    rows = (a > 0).float().mean(1).cpu().numpy(); cols = (a > 0).float().mean(0).cpu().numpy()
+    assert abs(rows.std() - np.sqrt(0.21 / 2048)) < 2e-3 and abs(cols.std() - np.sqrt(0.21 / 1000)) < 3e-3
+    assert abs(float(((a > 0) & (c > 0)).float().mean()) - 0.49) < 3e-3    # sites are independent
+    assert torch.equal(dropout_mask(0.0, 1, 0, 4, 8, torch.device("cuda")), torch.ones(4, 8, device="cuda"))
+
+
+def test_dropout_training_step_matches_torch_autograd_with_the_same_masks():
+    """Train-mode dropout 0.3 (the reference default, transformer_config.py:16) at all five kinds of site.  The masks are
+    exported from the library and replayed in a float64 torch re-statement of the same network; logits and every
+    parameter gradient must agree (f16 operands: 5e-3)."""
+    from outfitx_amd.engine import dropout_mask
+    from src.models.datatypes import OutfitCompatibilityPredictionTask as CP
+    p = 0.3
+    n = np.array([3, 8, 1, 5, 6])
+    B, Lp = len(n), 8
+    emb, mask = synth.outfit_batch(777, B, Lp, n)
+    m = make_model("f16", dropout=p)
+    torch.manual_seed(99)
+    up = torch.linspace(-1.0, 2.0, B)
+    y = m(task=CP, outfit_embedding=cu(emb), outfit_mask=cu(mask))
+    (y.squeeze(-1) * up.cuda()).sum().backward()
+    pp, seed = m.last_dropout
+    assert pp == p
+    torch.manual_seed(99)
+    y2 = m(task=CP, outfit_embedding=cu(emb), outfit_mask=cu(mask))
+    assert torch.equal(y, y2), "same torch seed -> same masks"
+    ours = {k: v.grad.detach().cpu().double() for k, v in trainable(m).items() if v.grad is not None}
+    dev = torch.device("cuda")
+    S = n + 1
+    cu_rows = np.concatenate([[0], np.cumsum(S)])
+    M = int(cu_rows[-1])
+    P = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in trainable(m).items()}
+    nl, H, D, F = m.cfg.transformer.n_layers, 16, 1024, m.cfg.transformer.d_ffn
+    mk = lambda site, r, c: dropout_mask(p, seed, site, r, c, dev).cpu().double()
+    logits = []
+    masks = {l: (mk(4 * l, B * H, 32 * 32).view(B, H, 32, 32), mk(4 * l + 1, M, D), mk(4 * l + 2, M, 2048)[:, :F], mk(4 * l + 3, M, D)) for l in range(nl)}
+    mh = mk(4 * nl, B, D)
+    ln = torch.nn.functional.layer_norm
+    for b in range(B):
+        r0, s = int(cu_rows[b]), int(S[b])
+        X = torch.cat([P["outfit_token"].view(1, D), torch.from_numpy(emb[b, :n[b]]).double()], 0)
+        for l in range(nl):
+            q = lambda name: P[f"transformer_encoder.layers.{l}.{name}"]
+            m0, m1, m2, m3 = masks[l]
+            h1 = ln(X, (D,), q("norm1.weight"), q("norm1.bias"), 1e-5)
+            qkv = h1 @ q("self_attn.in_proj_weight").t() + q("self_attn.in_proj_bias")
+            qh, kh, vh = [t.view(s, H, 64).transpose(0, 1) for t in qkv.split(D, dim=1)]
+            pr = torch.softmax(qh @ kh.transpose(1, 2) / 8.0, -1) * m0[b, :, :s, :s]
+            o = (pr @ vh).transpose(0, 1).reshape(s, D)
+            X = X + (o @ q("self_attn.out_proj.weight").t() + q("self_attn.out_proj.bias")) * m1[r0:r0 + s]
+            h2 = ln(X, (D,), q("norm2.weight"), q("norm2.bias"), 1e-5)
+            a = torch.nn.functional.mish(h2 @ q("linear1.weight").t() + q("linear1.bias")) * m2[r0:r0 + s]
+            X = X + (a @ q("linear2.weight").t() + q("linear2.bias")) * m3[r0:r0 + s]
+        logits.append((X[0] * mh[b]) @ P["cp_ffn.1.weight"].view(-1) + P["cp_ffn.1.bias"].view(()))
+    ref_logits = torch.stack(logits)
+    (ref_logits * up.double()).sum().backward()
+    assert np.abs(y.detach().cpu().numpy().ravel() - ref_logits.detach().numpy()).max() <= 3e-3 * max(1.0, float(ref_logits.abs().max()))
+    bad = {}
+    for k, g in ours.items():
+        e = nrm((g - P[k].grad).numpy()) / max(nrm(P[k].grad.numpy()), 1e-30)
+        if not e <= 5e-3:
+            bad[k] = e
+    assert not bad, bad
+    assert set(ours) == {k for k, v in P.items() if v.grad is not None}
+
+
 def test_training_guards():
     from src.models.datatypes import (OutfitCompatibilityPredictionTask as CP, OutfitComplementaryItemRetrievalTask as CIR)
     emb, mask = synth.outfit_batch(5, 2, 4, 3)
     m = make_model("bf16", dropout=0.3)
-    with pytest.raises(NotImplementedError):
-        m(task=CP, outfit_embedding=cu(emb), outfit_mask=cu(mask))
-    with torch.no_grad():                      # scoring in train() mode under no_grad stays available
-        m(task=CP, outfit_embedding=cu(emb), outfit_mask=cu(mask))
+    with torch.no_grad():                      # scoring in train() mode under no_grad stays available (and has no dropout)
+        a = m(task=CP, outfit_embedding=cu(emb), outfit_mask=cu(mask))
+        b = m(task=CP, outfit_embedding=cu(emb), outfit_mask=cu(mask))
+    assert torch.equal(a, b)
     m.cfg.transformer.dropout = 0.0
     with pytest.raises(NotImplementedError):
         m(task=CIR, outfit_embedding=cu(emb), outfit_mask=cu(mask), target_item_text_embedding=cu(synth.unit_rows(5, "t", 2, 512)))
