@@ -124,6 +124,17 @@ int ofx_l2_topk(ofx_handle* h, const float* Q, const float* P, int nq, int np, i
 int ofx_topk_merge(const int64_t* idx_in, const float* dist_in, int parts, int nq, int k, int64_t* idx, float* dist,
                    ofx_stream stream);
 
+/* ------------------------------------------------------------------ indexed (varlen) set input ("next" row N3) --- */
+/* The same encoder with the outfits given as ROW INDICES into a device-resident embedding table [n_table, ld] fp32
+ * (the precomputed-embedding store kept in HBM) instead of a padded [B, L, D] tensor + mask: outfit b holds items
+ * item_index[cu_items[b] .. cu_items[b+1]); cu_items[0] = 0; at most max_len (<= 31) items per outfit.  Replaces the
+ * reference's collate (outfit_x_base_processor.py:20-81: per-item torch.tensor + cat + stack, then a 12.6 MB/256-outfit
+ * H2D copy) by a few KB of indices.  Bit-identical to the dense call on the same items.  Workspace: ofx_workspace_bytes
+ * (OFX_OP_SET_ENCODER, B, max_len). */
+int ofx_set_encoder_fwd_indexed(ofx_handle* h, const float* table, int ld, long long n_table, const int* item_index, const int* cu_items,
+                                const float* prefix, int prefix_stride, int B, int max_len, float* out_row0, void* ws, size_t ws_bytes,
+                                ofx_stream stream);
+
 /* ------------------------------------------------------------------ training step ("next" row N1) --- */
 /* CP path on precomputed embeddings with a tape, and its backward: what torch autograd computes for the reference's
  * CP trainer step (compatibility_prediction_trainer.py:57-81) with dropout = 0.  Needs outfit_precision BF16 or F16.
@@ -139,6 +150,9 @@ int ofx_cp_train_fwd(ofx_handle* h, const float* x, const uint8_t* pad_mask, int
                      void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream);
 int ofx_cp_train_bwd(ofx_handle* h, void* tape, size_t tape_bytes, const float* dlogits, int B, int L, float* grads, size_t grad_floats,
                      void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream);
+int ofx_cp_train_fwd_indexed(ofx_handle* h, const float* table, int ld, long long n_table, const int* item_index, const int* cu_items,
+                             int B, int max_len, float* logits, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes,
+                             float dropout_p, unsigned seed, ofx_stream stream);
 /* out[rows, cols] fp32 = keep-mask / (1 - p) of dropout site `site` (layer l: 4l + {0 attention [B*heads, 32*i + j], 1 dropout1,
  * 2 FFN, 3 dropout2}; 4 * n_layers = head), exactly as the kernels compute it.  Test / debugging aid. */
 int ofx_dropout_mask(float dropout_p, unsigned seed, int site, int rows, int cols, float* out, ofx_stream stream);

@@ -387,14 +387,40 @@ extern "C" size_t ofx_workspace_bytes(ofx_handle* h, int op, int n, int len) {
 }
 
 // --------------------------------------------------------------------------- outfit transformer
+// The set input in either form: a padded [B, L, D] tensor + mask, or (indexed / varlen) item rows of a device-resident table.
+struct SetInput {
+    const float* x = nullptr; const uint8_t* pad_mask = nullptr;                                   // dense
+    const float* table = nullptr; int ld = 0; long long n_table = 0; const int* item_index = nullptr; const int* cu_items = nullptr;   // indexed
+};
+static int build_set(const ofx_handle* h, const SetInput& in, const float* prefix, int prefix_stride, int* cu, float* X, int B, int L, hipStream_t s) {
+    const int D = h->d.d_model;
+    if (in.table) return ofx_launch_set_build_indexed(in.table, in.ld, in.n_table, in.item_index, in.cu_items, prefix, prefix_stride, cu, X, B, D, s);
+    return ofx_launch_set_build(in.x, in.pad_mask, prefix, prefix_stride, cu, X, B, L, D, s);
+}
+static int set_encoder_core(ofx_handle* h, const SetInput& in, const float* prefix, int prefix_stride, int B, int L, float* out_row0, void* ws,
+                            size_t ws_bytes, hipStream_t s);
+
 extern "C" int ofx_set_encoder_fwd(ofx_handle* h, const float* x, const uint8_t* pad_mask, const float* prefix,
                                    int prefix_stride, int B, int L, float* out_row0, void* ws, size_t ws_bytes,
                                    ofx_stream stream) {
     OFX_REQUIRE(h && h->out_ready, OFX_ESTATE, "set_encoder_fwd: outfit weights not packed");
     OFX_REQUIRE(B > 0 && L >= 0 && L <= 31, OFX_ESHAPE, "set_encoder_fwd: B=%d L=%d (L must be in [0,31])", B, L);
     OFX_REQUIRE((x || L == 0) && (pad_mask || L == 0) && out_row0 && ws, OFX_EINVAL, "set_encoder_fwd: NULL argument");
+    SetInput in; in.x = x; in.pad_mask = pad_mask;
+    return set_encoder_core(h, in, prefix, prefix_stride, B, L, out_row0, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int ofx_set_encoder_fwd_indexed(ofx_handle* h, const float* table, int ld, long long n_table, const int* item_index, const int* cu_items,
+                                           const float* prefix, int prefix_stride, int B, int max_len, float* out_row0, void* ws, size_t ws_bytes,
+                                           ofx_stream stream) {
+    OFX_REQUIRE(h && h->out_ready, OFX_ESTATE, "set_encoder_fwd_indexed: outfit weights not packed");
+    OFX_REQUIRE(B > 0 && max_len >= 0 && max_len <= 31, OFX_ESHAPE, "set_encoder_fwd_indexed: B=%d max_len=%d (must be in [0,31])", B, max_len);
+    OFX_REQUIRE(table && item_index && cu_items && out_row0 && ws && n_table > 0, OFX_EINVAL, "set_encoder_fwd_indexed: NULL argument");
+    SetInput in; in.table = table; in.ld = ld; in.n_table = n_table; in.item_index = item_index; in.cu_items = cu_items;
+    return set_encoder_core(h, in, prefix, prefix_stride, B, max_len, out_row0, ws, ws_bytes, (hipStream_t)stream);
+}
+static int set_encoder_core(ofx_handle* h, const SetInput& in, const float* prefix, int prefix_stride, int B, int L, float* out_row0, void* ws,
+                            size_t ws_bytes, hipStream_t s) {
     const ofx_model_desc& d = h->d;
-    hipStream_t s = (hipStream_t)stream;
     Bump bump(ws, ws_bytes);
     SetWs w;
     carve_set(h, bump, B, L, &w);
@@ -402,7 +428,7 @@ extern "C" int ofx_set_encoder_fwd(ofx_handle* h, const float* x, const uint8_t*
     const int D = d.d_model, km = h->ot_kmul, Fp = h->ot_ffn_pad, dt = h->ot_dtype, M = B * (L + 1);
     const int okind = km == 3 ? OFX_OUT_SPLIT3 : OFX_OUT_OP;
     if (!prefix) { prefix = h->outfit_token; prefix_stride = 0; }
-    TRY(ofx_launch_set_build(x, pad_mask, prefix, prefix_stride, w.cu, w.X, B, L, D, s));
+    TRY(build_set(h, in, prefix, prefix_stride, w.cu, w.X, B, L, s));
     const int* m_dev = w.cu + B;
     for (int l = 0; l < d.n_layers; ++l) {
         const OutfitLayer& Ly = h->ol[l];
@@ -655,14 +681,28 @@ extern "C" size_t ofx_cp_train_grad_floats(ofx_handle* h, size_t* offsets, int n
 
 // dropout sites: layer l -> 4l + {0 attention probabilities, 1 dropout1 (out_proj output), 2 FFN inner, 3 dropout2 (linear2 output)};
 // 4 * n_layers = the head's Dropout (cp_ffn[0]).  torch: nn.TransformerEncoderLayer._sa_block / _ff_block, MultiheadAttention dropout.
+static int cp_train_fwd_core(ofx_handle* h, const SetInput& in, int B, int L, float* logits, void* tape_mem, size_t tape_bytes, void* ws,
+                             size_t ws_bytes, float dropout_p, unsigned seed, hipStream_t s);
 extern "C" int ofx_cp_train_fwd(ofx_handle* h, const float* x, const uint8_t* pad_mask, int B, int L, float* logits, void* tape_mem,
                                 size_t tape_bytes, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream) {
+    OFX_REQUIRE(B > 0 && L >= 0 && L <= 31 && (x || L == 0) && (pad_mask || L == 0) && logits && tape_mem, OFX_EINVAL, "cp_train_fwd: bad argument");
+    SetInput in; in.x = x; in.pad_mask = pad_mask;
+    return cp_train_fwd_core(h, in, B, L, logits, tape_mem, tape_bytes, ws, ws_bytes, dropout_p, seed, (hipStream_t)stream);
+}
+extern "C" int ofx_cp_train_fwd_indexed(ofx_handle* h, const float* table, int ld, long long n_table, const int* item_index, const int* cu_items,
+                                        int B, int max_len, float* logits, void* tape_mem, size_t tape_bytes, void* ws, size_t ws_bytes,
+                                        float dropout_p, unsigned seed, ofx_stream stream) {
+    OFX_REQUIRE(B > 0 && max_len >= 0 && max_len <= 31 && table && item_index && cu_items && logits && tape_mem && n_table > 0, OFX_EINVAL,
+                "cp_train_fwd_indexed: bad argument");
+    SetInput in; in.table = table; in.ld = ld; in.n_table = n_table; in.item_index = item_index; in.cu_items = cu_items;
+    return cp_train_fwd_core(h, in, B, max_len, logits, tape_mem, tape_bytes, ws, ws_bytes, dropout_p, seed, (hipStream_t)stream);
+}
+static int cp_train_fwd_core(ofx_handle* h, const SetInput& in, int B, int L, float* logits, void* tape_mem, size_t tape_bytes, void* ws,
+                             size_t ws_bytes, float dropout_p, unsigned seed, hipStream_t s) {
     OFX_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, OFX_EINVAL, "cp_train_fwd: dropout_p=%g", dropout_p);
     OFX_REQUIRE(h && h->out_ready, OFX_ESTATE, "cp_train_fwd: outfit weights not packed");
     OFX_REQUIRE(h->ot_kmul == 1, OFX_ESTATE, "cp_train_fwd: training uses a single-product precision (bf16 / f16), not bf16x3");
-    OFX_REQUIRE(B > 0 && L >= 0 && L <= 31 && (x || L == 0) && (pad_mask || L == 0) && logits && tape_mem, OFX_EINVAL, "cp_train_fwd: bad argument");
     const ofx_model_desc& d = h->d;
-    hipStream_t s = (hipStream_t)stream;
     Bump tb(tape_mem, tape_bytes);
     Tape T;
     carve_tape(h, tb, B, L, &T);
@@ -672,7 +712,7 @@ extern "C" int ofx_cp_train_fwd(ofx_handle* h, const float* x, const uint8_t* pa
     carve_set(h, wb, B, L, &w);
     OFX_REQUIRE(wb.ok, OFX_EWORKSPACE, "cp_train_fwd: workspace too small");
     const int D = d.d_model, Fp = h->ot_ffn_pad, dt = h->ot_dtype, M = B * (L + 1);
-    TRY(ofx_launch_set_build(x, pad_mask, h->outfit_token, 0, T.cu, T.L[0].Xin, B, L, D, s));
+    TRY(build_set(h, in, h->outfit_token, 0, T.cu, T.L[0].Xin, B, L, s));
     const int* m_dev = T.cu + B;
     for (int l = 0; l < d.n_layers; ++l) {
         const OutfitLayer& Ly = h->ol[l];

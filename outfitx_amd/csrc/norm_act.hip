@@ -290,6 +290,26 @@ __global__ __launch_bounds__(256) void set_build_kernel(const float* x, const ui
     }
 }
 
+// Indexed (varlen) set build: outfit b = prefix + rows item_index[cu_items[b] .. cu_items[b+1]) of a device-resident embedding
+// table; writes the pad-free rows AND the row offsets cu_rows[b] = cu_items[b] + b (cu_rows[B] = live row count).
+// One wave per outfit.  Out-of-range indices are clamped (the host processor validates them).
+__global__ __launch_bounds__(256) void set_build_indexed_kernel(const float* table, int ld, long long n_table, const int* idx, const int* cu_items,
+                                                               const float* prefix, int prefix_stride, int* cu_rows, float* X, int B, int D) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int b = blockIdx.x * 4 + w; b < B; b += gridDim.x * 4) {
+        const int i0 = cu_items[b], n = cu_items[b + 1] - i0, r0 = i0 + b;
+        if (lane == 0) { cu_rows[b] = r0; if (b == B - 1) cu_rows[B] = cu_items[B] + B; }
+        const float* pp = prefix + (size_t)b * prefix_stride;
+        for (int c = lane; c < D / 4; c += 64) *(f32x4*)(X + (size_t)r0 * D + c * 4) = *(const f32x4*)(pp + c * 4);
+        for (int j = 0; j < n; ++j) {
+            long long t = idx[i0 + j];
+            t = t < 0 ? 0 : (t >= n_table ? n_table - 1 : t);
+            const float* src = table + (size_t)t * ld;
+            for (int c = lane; c < D / 4; c += 64) *(f32x4*)(X + (size_t)(r0 + 1 + j) * D + c * 4) = *(const f32x4*)(src + c * 4);
+        }
+    }
+}
+
 // dst[r] = src[idx[r]] for rows of row_bytes (multiple of 16)
 __global__ __launch_bounds__(256) void gather_rows_kernel(const char* src, const int* idx, char* dst, int rows, int row_bytes, int src_ld_bytes) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -382,6 +402,14 @@ int ofx_launch_set_build(const float* x, const uint8_t* mask, const float* prefi
     OFX_REQUIRE(B > 0 && B <= 65536 * 16 && L >= 0 && D % 4 == 0, OFX_ESHAPE, "set_build: B=%d L=%d D=%d", B, L, D);
     hipLaunchKernelGGL(set_offsets_kernel, dim3(1), dim3(1024), 0, s, mask, cu, B, L);
     hipLaunchKernelGGL(set_build_kernel, dim3(rows_grid(B * (L + 1))), dim3(256), 0, s, x, mask, prefix, prefix_stride, cu, X, B, L, D);
+    OFX_LAUNCH_CHECK();
+    return OFX_OK;
+}
+int ofx_launch_set_build_indexed(const float* table, int ld, long long n_table, const int* idx, const int* cu_items, const float* prefix,
+                                 int prefix_stride, int* cu_rows, float* X, int B, int D, hipStream_t s) {
+    OFX_REQUIRE(B > 0 && D % 4 == 0 && ld % 4 == 0 && ld >= D && n_table > 0, OFX_ESHAPE, "set_build_indexed: B=%d D=%d ld=%d", B, D, ld);
+    ProfScope prof(PROF_OTHER, s);
+    hipLaunchKernelGGL(set_build_indexed_kernel, dim3(rows_grid(B)), dim3(256), 0, s, table, ld, n_table, idx, cu_items, prefix, prefix_stride, cu_rows, X, B, D);
     OFX_LAUNCH_CHECK();
     return OFX_OK;
 }

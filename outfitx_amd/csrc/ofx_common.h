@@ -189,6 +189,8 @@ int ofx_launch_l2norm_store(const float* src, float* dst, int rows, int D, int l
 int ofx_launch_set_build(const float* x, const uint8_t* mask, const float* prefix, int prefix_stride, int* cu, float* X,
                          int B, int L, int D, hipStream_t s);
 int ofx_launch_gather_rows(const void* src, const int* idx, void* dst, int rows, int row_bytes, int src_ld_bytes, hipStream_t s);
+int ofx_launch_set_build_indexed(const float* table, int ld, long long n_table, const int* idx, const int* cu_items, const float* prefix,
+                                 int prefix_stride, int* cu_rows, float* X, int B, int D, hipStream_t s);
 int ofx_launch_gather_row0(const float* X, const int* cu, float* out, int B, int D, hipStream_t s);
 int ofx_launch_cir_prefix(const float* img_emb, const float* txt, float* out, int B, int D, hipStream_t s);
 int ofx_launch_cp_head(const float* row0, const float* w, const float* bias, float* logits, int B, int D, hipStream_t s);

@@ -87,6 +87,10 @@ class EmbeddingTable:
         out[o] = self.embeddings[r[o]]
         return out
 
+    def index(self) -> Dict[int, int]:
+        """item_id -> row of `embeddings` (what processor.OutfitXIndexedProcessor needs to emit table rows)."""
+        return {int(i): k for k, i in enumerate(self.ids)}
+
     def as_dict(self) -> Dict[int, np.ndarray]:
         """The reference's in-memory form (id -> row view)."""
         return {int(i): self.embeddings[k] for k, i in enumerate(self.ids)}

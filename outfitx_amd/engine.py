@@ -100,6 +100,63 @@ class Engine:
                                                  _ptr(ws), ws.numel(), _stream(self.device)), "ofx_set_encoder_fwd")
         return out
 
+    def _index_args(self, table: torch.Tensor, item_index: torch.Tensor, cu_seqlens: torch.Tensor):
+        """Validate / stage the indexed (varlen) set input.  Host-side index tensors are checked here (range, monotone
+        offsets, items per outfit); device-side ones are trusted (the kernel clamps indices)."""
+        if table.device != self.device or table.dtype != torch.float32 or table.dim() != 2 or table.stride(1) != 1:
+            raise L.OfxError("embedding table must be a [n, D] fp32 tensor on the engine's device with unit column stride")
+        if table.shape[1] != self.desc.d_model:
+            raise L.OfxError(f"embedding table has {table.shape[1]} columns, the model needs {self.desc.d_model}")
+        B = cu_seqlens.numel() - 1
+        if cu_seqlens.device.type == "cpu":
+            cu = cu_seqlens.to(torch.int64)
+            n = cu[1:] - cu[:-1]
+            if B < 1 or int(cu[0]) != 0 or bool((n < 0).any()) or int(cu[-1]) != item_index.numel():
+                raise ValueError("cu_seqlens must start at 0, be non-decreasing and end at len(item_index)")
+            max_items = int(n.max())
+        else:
+            max_items = None
+        if item_index.device.type == "cpu" and item_index.numel():
+            lo, hi = int(item_index.min()), int(item_index.max())
+            if lo < 0 or hi >= table.shape[0]:
+                raise IndexError(f"item_index out of range [0, {table.shape[0]}): min {lo}, max {hi}")
+        idx = item_index.to(device=self.device, dtype=torch.int32, non_blocking=True).contiguous()
+        cud = cu_seqlens.to(device=self.device, dtype=torch.int32, non_blocking=True).contiguous()
+        return idx, cud, B, max_items
+
+    def set_encoder_indexed(self, table: torch.Tensor, item_index: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int,
+                            prefix: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Outfits as row indices into a device-resident embedding table -> encoder output at the prefix token [B,D]."""
+        idx, cud, B, max_items = self._index_args(table, item_index, cu_seqlens)
+        if max_items is not None and max_items > max_len:
+            raise ValueError(f"an outfit holds {max_items} items, max_len is {max_len} (truncate in the processor)")
+        D = self.desc.d_model
+        stride = 0
+        if prefix is not None:
+            prefix = _f32c(prefix, self.device)
+            stride = 0 if prefix.dim() == 1 else D
+        out = torch.empty(B, D, dtype=torch.float32, device=self.device)
+        ws = self.workspace(self.ws_bytes(L.OP_SET_ENCODER, B, max_len))
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ofx_set_encoder_fwd_indexed(self.h, _ptr(table), table.stride(0), table.shape[0], _ptr(idx), _ptr(cud), _ptr(prefix), stride,
+                                                         B, max_len, _ptr(out), _ptr(ws), ws.numel(), _stream(self.device)), "ofx_set_encoder_fwd_indexed")
+        self._keep_idx = (idx, cud)
+        return out
+
+    def cp_train_fwd_indexed(self, table, item_index, cu_seqlens, max_len: int, dropout_p: float = 0.0, seed: int = 0):
+        idx, cud, B, max_items = self._index_args(table, item_index, cu_seqlens)
+        if max_items is not None and max_items > max_len:
+            raise ValueError(f"an outfit holds {max_items} items, max_len is {max_len} (truncate in the processor)")
+        tape = torch.empty(int(self.lib.ofx_cp_train_tape_bytes(self.h, B, max_len)), dtype=torch.uint8, device=self.device)
+        ws = self.workspace(int(self.lib.ofx_cp_train_ws_bytes(self.h, B, max_len)))
+        logits = torch.empty(B, 1, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ofx_cp_train_fwd_indexed(self.h, _ptr(table), table.stride(0), table.shape[0], _ptr(idx), _ptr(cud), B, max_len, _ptr(logits),
+                                                      _ptr(tape), tape.numel(), _ptr(ws), ws.numel(), float(dropout_p), int(seed) & 0xFFFFFFFF,
+                                                      _stream(self.device)), "ofx_cp_train_fwd_indexed")
+        self._keep_idx = (idx, cud)
+        return logits, tape
+
     def cp_head(self, row0: torch.Tensor) -> torch.Tensor:
         B = row0.shape[0]
         out = torch.empty(B, 1, dtype=torch.float32, device=self.device)

@@ -45,8 +45,14 @@ class _CPTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, eng, x, mask, F, drop, *params):
-        logits, tape = eng.cp_train_fwd(x, mask, *drop)
-        ctx.eng, ctx.tape, ctx.bl, ctx.F, ctx.drop = eng, tape, (x.shape[0], x.shape[1]), F, drop
+        if isinstance(x, tuple):                  # indexed (varlen) input: (table, item_index, cu_seqlens, max_len)
+            table, idx, cu, max_len = x
+            logits, tape = eng.cp_train_fwd_indexed(table, idx, cu, max_len, *drop)
+            bl = (cu.numel() - 1, max_len)
+        else:
+            logits, tape = eng.cp_train_fwd(x, mask, *drop)
+            bl = (x.shape[0], x.shape[1])
+        ctx.eng, ctx.tape, ctx.bl, ctx.F, ctx.drop = eng, tape, bl, F, drop
         ctx.shapes = [tuple(p.shape) for p in params]
         return logits
 
@@ -167,9 +173,30 @@ class OutfitX(nn.Module):
         eng = self._engine()
         return eng, eng.set_encoder(outfit_embedding, outfit_mask, prefix)
 
-    def _cp_forward(self, outfit_embedding: Optional[torch.Tensor], outfit_mask: torch.Tensor,
-                    encoder_input_dict: Optional[dict] = None) -> torch.Tensor:
-        """outfit_x.py:120-144 -> raw compatibility logits [B,1]."""
+    # ------------------------------------------------------------------ indexed (varlen) input, SURVEY.md §8f N3
+    def set_embedding_table(self, table: torch.Tensor) -> None:
+        """Keep the precomputed item embeddings [n_items, d_embed] resident on the model's device; batches can then be
+        index lists (`item_index`, `cu_seqlens` from processor.OutfitXIndexed*Processor) instead of padded tensors."""
+        self.embedding_table = table.to(device=self.device, dtype=torch.float32).contiguous()
+
+    def _indexed(self, item_index, cu_seqlens, embedding_table, max_len):
+        table = embedding_table if embedding_table is not None else getattr(self, "embedding_table", None)
+        if table is None:
+            raise ValueError("indexed input needs an embedding table: pass embedding_table= or call set_embedding_table()")
+        return table, item_index, cu_seqlens, int(max_len if max_len is not None else min(self.cfg.max_length, 31))
+
+    def _cp_forward(self, outfit_embedding: Optional[torch.Tensor] = None, outfit_mask: Optional[torch.Tensor] = None,
+                    encoder_input_dict: Optional[dict] = None, *, item_index: Optional[torch.Tensor] = None,
+                    cu_seqlens: Optional[torch.Tensor] = None, embedding_table: Optional[torch.Tensor] = None,
+                    max_len: Optional[int] = None) -> torch.Tensor:
+        """outfit_x.py:120-144 -> raw compatibility logits [B,1].  Beyond the reference's arguments: the indexed form
+        (item_index, cu_seqlens[, embedding_table, max_len]) — same result as the padded tensors built from those rows."""
+        if item_index is not None:
+            spec = self._indexed(item_index, cu_seqlens, embedding_table, max_len)
+            if self.training and torch.is_grad_enabled():
+                return self._cp_train_forward(spec, None)
+            eng = self._engine()
+            return eng.cp_head(eng.set_encoder_indexed(*spec))
         if encoder_input_dict is not None:
             outfit_embedding = self.item_encoder(**encoder_input_dict)
         if self.training and torch.is_grad_enabled():
@@ -182,7 +209,7 @@ class OutfitX(nn.Module):
         t = self.cfg.transformer
         if self.train_precision not in ("bf16", "f16"):
             raise ValueError("train_precision must be 'bf16' or 'f16'")
-        if outfit_embedding.requires_grad:
+        if isinstance(outfit_embedding, torch.Tensor) and outfit_embedding.requires_grad:
             raise NotImplementedError("gradients w.r.t. the item embeddings (encoder fine-tuning) are not built")
         eng = self._engine(self.train_precision)
         # dropout masks are hash(seed, site, element); the seed is drawn from torch's global generator, so
@@ -192,13 +219,19 @@ class OutfitX(nn.Module):
         self.last_dropout = (p, seed)
         return _CPTrainFn.apply(eng, outfit_embedding, outfit_mask, t.d_ffn, (p, seed), *self._outfit_tensors())
 
-    def _cir_forward(self, outfit_embedding: torch.Tensor, outfit_mask: torch.Tensor,
-                     target_item_text_embedding: torch.Tensor) -> torch.Tensor:
-        """outfit_x.py:147-172 -> target-item embedding [B, d_embed]."""
+    def _cir_forward(self, outfit_embedding: Optional[torch.Tensor] = None, outfit_mask: Optional[torch.Tensor] = None,
+                     target_item_text_embedding: Optional[torch.Tensor] = None, *, item_index: Optional[torch.Tensor] = None,
+                     cu_seqlens: Optional[torch.Tensor] = None, embedding_table: Optional[torch.Tensor] = None,
+                     max_len: Optional[int] = None) -> torch.Tensor:
+        """outfit_x.py:147-172 -> target-item embedding [B, d_embed] (indexed form as in _cp_forward)."""
         if self.training and torch.is_grad_enabled():
             raise NotImplementedError("the CIR / FITB training step (backward of the retrieval path) is not built; "
                                       "call under torch.no_grad() or model.eval()")
         eng = self._engine()
         prefix = eng.cir_prefix(target_item_text_embedding)
-        row0 = eng.set_encoder(outfit_embedding, outfit_mask, prefix)
+        if item_index is not None:
+            table, idx, cu, ml = self._indexed(item_index, cu_seqlens, embedding_table, max_len)
+            row0 = eng.set_encoder_indexed(table, idx, cu, ml, prefix)
+        else:
+            row0 = eng.set_encoder(outfit_embedding, outfit_mask, prefix)
         return eng.cir_head(row0)

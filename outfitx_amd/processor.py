@@ -107,6 +107,47 @@ class OutfitXPrecomputeEmbeddingTaskProcessor(OutfitXBaseProcessor):
                 "item_id": [t.fashion_item.item_id for t in batch]}
 
 
+class OutfitXIndexedProcessor:
+    """Index-emitting collate: the item embeddings stay in a device-resident table
+    (`OutfitX.set_embedding_table`), a batch is `item_index` int32 [total items] + `cu_seqlens` int32 [B+1] — a few KB
+    instead of the reference's padded fp32 [B, 16, 1024] (outfit_x_base_processor.py:20-81).  Outfits are truncated
+    to cfg.max_length items exactly like `_get_max_length` does with truncation=True; the encoder result is identical
+    to the padded form (padding never reaches the arithmetic: pad-free sets).  Picklable, CPU-only.
+
+    id_to_row: item_id -> row of the table (embedding_store.EmbeddingTable.index)."""
+
+    def __init__(self, task: Type, cfg: Optional[OutfitXConfig] = None, id_to_row=None):
+        self.task, self.cfg = task, cfg if cfg is not None else OutfitXConfig()
+        self.id_to_row = id_to_row
+
+    def _rows(self, items) -> List[int]:
+        ids = [it.item_id for it in items][: self.cfg.max_length]
+        return [int(i) for i in ids] if self.id_to_row is None else [int(self.id_to_row[i]) for i in ids]
+
+    def _index(self, outfits):
+        rows = [self._rows(o) for o in outfits]
+        cu = np.zeros(len(rows) + 1, np.int32)
+        cu[1:] = np.cumsum([len(r) for r in rows])
+        flat = np.fromiter((i for r in rows for i in r), np.int32, count=int(cu[-1]))
+        return torch.from_numpy(flat), torch.from_numpy(cu)
+
+    def __call__(self, batch):
+        if self.task is OutfitCompatibilityPredictionTask:
+            queries, labels = zip(*batch)
+            idx, cu = self._index([q.outfit for q in queries])
+            return {"input_dict": {"task": OutfitCompatibilityPredictionTask, "item_index": idx, "cu_seqlens": cu},
+                    "label": torch.tensor(labels, dtype=torch.float)}
+        if self.task is OutfitFillInTheBlankTask:
+            queries, cands, answers = zip(*batch)
+            idx, cu = self._index([q.outfit for q in queries])
+            txt = torch.from_numpy(np.stack([np.asarray(q.target_item.text_embedding, np.float32) for q in queries]))
+            return {"input_dict": {"task": OutfitComplementaryItemRetrievalTask, "item_index": idx, "cu_seqlens": cu,
+                                   "target_item_text_embedding": txt},
+                    "candidate_item_embedding": torch.stack([torch.as_tensor(c) for c in cands]),
+                    "answer_index": torch.tensor(answers, dtype=torch.long)}
+        raise ValueError(f"no indexed collate for task {self.task!r}")
+
+
 class OutfitXProcessorFactory:
     """outfit_x_processor_factory.py:16-36"""
 

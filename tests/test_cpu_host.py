@@ -224,6 +224,33 @@ def test_pool_sharded_topk_and_score_gather_world2_gloo(tmp_path):
     assert r.stdout.count("ok") == 2
 
 
+def test_indexed_processor_reproduces_the_reference_collate():
+    """N3: the index-emitting collate + a row gather equals the reference processor's padded output (fixture from the
+    reference itself: lengths 3, 8, 20 -> truncated to 16, 1)."""
+    from outfitx_amd.configs import ItemEncoderConfig, OutfitXConfig
+    from outfitx_amd.datatypes import FashionItem, OutfitCompatibilityPredictionTask as CP
+    from outfitx_amd.embedding_store import EmbeddingTable
+    from outfitx_amd.processor import OutfitXIndexedProcessor
+    g = golden("aux")
+    lens = g["proc_lens"].tolist()
+    rows = [synth.item_embeddings(1243, f"o{i}", n) for i, n in enumerate(lens)]
+    ids = np.arange(1000, 1000 + sum(lens))[::-1].copy()                 # arbitrary, non-sorted item ids
+    table = EmbeddingTable(ids, np.concatenate(rows))
+    off = np.concatenate([[0], np.cumsum(lens)])
+    batch = [(CP(outfit=[FashionItem(item_id=int(ids[off[i] + j])) for j in range(n)]), float(i % 2)) for i, n in enumerate(lens)]
+    proc = OutfitXIndexedProcessor(CP, OutfitXConfig(item_encoder=ItemEncoderConfig(type="clip")), id_to_row=table.index())
+    proc = pickle.loads(pickle.dumps(proc))                              # collate_fn objects travel to DataLoader workers
+    out = proc(batch)
+    idx, cu = out["input_dict"]["item_index"].numpy(), out["input_dict"]["cu_seqlens"].numpy()
+    assert idx.dtype == np.int32 and cu.tolist() == [0, 3, 11, 27, 28]
+    emb = np.zeros((len(lens), 16, 1024), np.float32); mask = np.ones((len(lens), 16), bool)
+    for b in range(len(lens)):
+        n = cu[b + 1] - cu[b]
+        emb[b, :n] = table.embeddings[idx[cu[b]:cu[b + 1]]]; mask[b, :n] = False
+    assert synth.checksum(emb) == str(g["proc_emb_crc"]) and np.array_equal(mask, g["proc_mask"])
+    assert np.array_equal(out["label"].numpy(), g["proc_label"])
+
+
 def test_embedding_store_roundtrip(tmp_path):
     from outfitx_amd import embedding_store as S
     g = np.random.default_rng(3)

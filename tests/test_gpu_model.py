@@ -274,3 +274,42 @@ def test_c_abi_error_codes():
     rc = lib.ofx_set_encoder_fwd(eng.h, x.data_ptr(), m.data_ptr(), None, 0, 2, 16, o.data_ptr(), ws.data_ptr(), 1024, s)
     assert rc == -4 and b"workspace" in lib.ofx_last_error()                      # OFX_EWORKSPACE
     torch.cuda.synchronize()
+
+
+def _indexed_batch(seed, n_items, n_table=500):
+    """A table of item embeddings, ragged outfits as row indices into it, and the padded tensors the same outfits give."""
+    g = np.random.default_rng(seed)
+    table = synth.item_embeddings(seed, "table", n_table)
+    idx = [g.integers(0, n_table, n) for n in n_items]
+    cu = np.concatenate([[0], np.cumsum(n_items)]).astype(np.int32)
+    L = 16
+    emb = np.zeros((len(n_items), L, 1024), np.float32); mask = np.ones((len(n_items), L), bool)
+    for b, r in enumerate(idx):
+        emb[b, :len(r)] = table[r]; mask[b, :len(r)] = False
+    flat = np.concatenate(idx).astype(np.int32) if len(idx) else np.zeros(0, np.int32)
+    return table, torch.from_numpy(flat), torch.from_numpy(cu), emb, mask
+
+
+def test_indexed_input_is_bit_identical_to_the_padded_form(model):
+    """N3: outfits as indices into a device-resident table (host index tensors -> a few KB of H2D) == padded tensors."""
+    CP, CIR, FITB, _ = tasks()
+    n_items = [3, 16, 0, 1, 9, 16, 2, 7]
+    table, idx, cu, emb, mask = _indexed_batch(31, n_items)
+    txt = synth.unit_rows(31, "target_text", len(n_items), 512)
+    model.set_embedding_table(torch.from_numpy(table))
+    with torch.no_grad():
+        a = model(task=CP, outfit_embedding=cu_(emb), outfit_mask=cu_(mask))
+        b = model(task=CP, item_index=idx, cu_seqlens=cu)
+        c = model(task=CIR, outfit_embedding=cu_(emb), outfit_mask=cu_(mask), target_item_text_embedding=cu_(txt))
+        d = model(task=FITB, item_index=idx.cuda(), cu_seqlens=cu.cuda(), target_item_text_embedding=cu_(txt), max_len=16)
+    assert torch.equal(a, b) and torch.equal(c, d)
+    with pytest.raises(IndexError):
+        model(task=CP, item_index=torch.tensor([0, 500], dtype=torch.int32), cu_seqlens=torch.tensor([0, 2], dtype=torch.int32))
+    with pytest.raises(ValueError):
+        model(task=CP, item_index=torch.zeros(17, dtype=torch.int32), cu_seqlens=torch.tensor([0, 17], dtype=torch.int32))
+    with pytest.raises(ValueError):
+        model(task=CP, item_index=torch.zeros(3, dtype=torch.int32), cu_seqlens=torch.tensor([0, 2], dtype=torch.int32))
+
+
+def cu_(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()

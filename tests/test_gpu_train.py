@@ -234,6 +234,30 @@ def test_dropout_training_step_matches_torch_autograd_with_the_same_masks():
     assert set(ours) == {k for k, v in P.items() if v.grad is not None}
 
 
+def test_indexed_training_step_equals_the_padded_one():
+    """N3 x N1: a training step fed by (item_index, cu_seqlens) into the resident table == the padded-tensor step."""
+    from src.models.datatypes import OutfitCompatibilityPredictionTask as CP
+    n_items = [5, 16, 1, 8, 3, 0]
+    g = np.random.default_rng(8)
+    table = synth.item_embeddings(8, "table", 300)
+    idx = [g.integers(0, 300, n) for n in n_items]
+    cu_items = torch.from_numpy(np.concatenate([[0], np.cumsum(n_items)]).astype(np.int32))
+    emb = np.zeros((len(n_items), 16, 1024), np.float32); mask = np.ones((len(n_items), 16), bool)
+    for b, r in enumerate(idx):
+        emb[b, :len(r)] = table[r]; mask[b, :len(r)] = False
+    m = make_model("bf16")
+    m.set_embedding_table(torch.from_numpy(table))
+    up = torch.linspace(-1.0, 2.0, len(n_items)).cuda()
+    (m(task=CP, outfit_embedding=cu(emb), outfit_mask=cu(mask)).squeeze(-1) * up).sum().backward()
+    dense = {k: v.grad.clone() for k, v in trainable(m).items() if v.grad is not None}
+    m.zero_grad(set_to_none=True)
+    y = m(task=CP, item_index=torch.from_numpy(np.concatenate(idx).astype(np.int32)), cu_seqlens=cu_items)
+    (y.squeeze(-1) * up).sum().backward()
+    for k, v in trainable(m).items():
+        if k in dense:
+            assert torch.equal(v.grad, dense[k]), k
+
+
 def test_training_guards():
     from src.models.datatypes import (OutfitCompatibilityPredictionTask as CP, OutfitComplementaryItemRetrievalTask as CIR)
     emb, mask = synth.outfit_batch(5, 2, 4, 3)
