@@ -124,6 +124,16 @@ int ofx_l2_topk(ofx_handle* h, const float* Q, const float* P, int nq, int np, i
 int ofx_topk_merge(const int64_t* idx_in, const float* dist_in, int parts, int nq, int k, int64_t* idx, float* dist,
                    ofx_stream stream);
 
+/* ------------------------------------------------------------------ image preprocessing ("next" row N2) --- */
+/* CLIPImageProcessor(do_convert_rgb=False) as the reference runs it on the host (clip_image_encoder.py:29-31,69-71): resize the
+ * shortest edge to `size` with PIL's antialiased BICUBIC (ImagingResample: 22-bit fixed-point coefficients, horizontal then
+ * vertical, 8-bit intermediate — bit-exact), centre crop size x size, x 1/255, (x - mean) / std -> out [N, 3, size, size] fp32
+ * (device), equal to the host pipeline bit for bit.  src: device buffer holding the N uint8 images row-major with `channels`
+ * (3 = RGB interleaved, 1 = grey, replicated) at byte offsets[i]; offsets / heights / widths are HOST arrays. */
+size_t ofx_clip_preprocess_ws(const int* heights, const int* widths, int N, int channels, int size);
+int ofx_clip_preprocess(const uint8_t* src, const long long* offsets, const int* heights, const int* widths, int N, int channels, int size,
+                        const float* mean, const float* stdv, float* out, void* ws, size_t ws_bytes, ofx_stream stream);
+
 /* ------------------------------------------------------------------ indexed (varlen) set input ("next" row N3) --- */
 /* The same encoder with the outfits given as ROW INDICES into a device-resident embedding table [n_table, ld] fp32
  * (the precomputed-embedding store kept in HBM) instead of a padded [B, L, D] tensor + mask: outfit b holds items

@@ -292,3 +292,93 @@ def pad_outfits(seqs, max_length=16, d=1024):
             emb[i, :n] = np.asarray(s, np.float32)[:n]
         mask[i, :n] = False
     return emb, mask
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Image preprocessing ("next" row N2).  The reference calls transformers.CLIPImageProcessor(do_convert_rgb=False) on the host
+# (src/models/encoders/image_encoders/clip_image_encoder.py:29-31,69-71); its resize is PIL's `Image.resize(BICUBIC)`, i.e.
+# Pillow's libImaging/Resample.c (third-party; reference pins pillow==11.0.0 in environment.yml:12, the container has 12.2.0 —
+# the routine is unchanged between them).  Restated here from its published algorithm and PINNED against the container's PIL
+# itself (tests/test_oracle_golden.py::test_pil_bicubic_restatement_is_bit_exact).
+_PBITS = 22
+
+
+def _bicubic_filter(x):
+    a = -0.5
+    x = np.abs(x)
+    r = np.zeros_like(x)
+    m1 = x < 1.0
+    m2 = (x >= 1.0) & (x < 2.0)
+    r[m1] = ((a + 2.0) * x[m1] - (a + 3.0)) * x[m1] * x[m1] + 1
+    r[m2] = (((x[m2] - 5) * x[m2] + 8) * x[m2] - 4) * a
+    return r
+
+
+def pil_bicubic_coeffs(in_size, out_size):
+    """Resample.c precompute_coeffs + normalize_coeffs_8bpc -> (kk int64 [out, ksize], bounds [out, 2] = (xmin, count))."""
+    scale = filterscale = in_size / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 2.0 * filterscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    kk = np.zeros((out_size, ksize), np.int64)
+    bounds = np.zeros((out_size, 2), np.int64)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size)
+        n = xmax - xmin
+        w = _bicubic_filter((np.arange(n, dtype=np.float64) + xmin - center + 0.5) * ss)
+        ww = 0.0
+        for v in w:                     # sequential sum, like the C loop
+            ww += v
+        if ww != 0.0:
+            w = w / ww
+        kk[xx, :n] = np.where(w < 0, (-0.5 + w * (1 << _PBITS)).astype(np.int64), (0.5 + w * (1 << _PBITS)).astype(np.int64))
+        bounds[xx] = (xmin, n)
+    return kk, bounds
+
+
+def _resample_axis0(img, out_size):
+    kk, b = pil_bicubic_coeffs(img.shape[0], out_size)
+    out = np.zeros((out_size,) + img.shape[1:], np.uint8)
+    for xx in range(out_size):
+        xmin, n = b[xx]
+        acc = (1 << (_PBITS - 1)) + (img[xmin:xmin + n].astype(np.int64) * kk[xx, :n].reshape((-1,) + (1,) * (img.ndim - 1))).sum(0)
+        out[xx] = np.clip(acc >> _PBITS, 0, 255).astype(np.uint8)
+    return out
+
+
+def pil_resize_bicubic(img, nw, nh):
+    """uint8 [H,W] or [H,W,C] -> [nh,nw(,C)]: horizontal pass, 8-bit intermediate, vertical pass (ImagingResample)."""
+    o = img
+    if nw != img.shape[1]:
+        o = np.swapaxes(_resample_axis0(np.swapaxes(o, 0, 1), nw), 0, 1)
+    if nh != img.shape[0]:
+        o = _resample_axis0(o, nh)
+    return np.ascontiguousarray(o)
+
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def clip_preprocess(images, size=224):
+    """CLIPImageProcessor: shortest edge -> size (bicubic), centre crop, / 255, normalise -> [N,3,size,size] fp32."""
+    out = np.empty((len(images), 3, size, size), np.float32)
+    mean = np.asarray(CLIP_MEAN, np.float32).reshape(3, 1, 1)
+    std = np.asarray(CLIP_STD, np.float32).reshape(3, 1, 1)
+    for i, a in enumerate(images):
+        a = np.asarray(a)
+        h, w = a.shape[:2]
+        short, long_ = (w, h) if w <= h else (h, w)
+        new_long = int(size * long_ / short)
+        nw, nh = (size, new_long) if w <= h else (new_long, size)
+        r = pil_resize_bicubic(a, nw, nh)
+        left, top = (nw - size) // 2, (nh - size) // 2
+        r = r[top:top + size, left:left + size].astype(np.float32)
+        if r.ndim == 2:
+            r = np.repeat(r[:, :, None], 3, 2)
+        out[i] = (r.transpose(2, 0, 1) * np.float32(1 / 255.0) - mean) / std
+    return out

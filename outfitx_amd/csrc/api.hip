@@ -89,21 +89,6 @@ int ofx_launch_topk_merge(const int64_t* idx_in, const float* dist_in, int parts
 
 namespace {
 
-inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-inline int pad128(int v) { return (v + 127) / 128 * 128; }
-
-struct Bump {                                       // carve a caller-provided workspace
-    char* base; size_t cap, off = 0; bool ok = true;
-    Bump(void* p, size_t c) : base((char*)p), cap(c) {}
-    template <typename T> T* take(size_t n) {
-        off = align_up(off, 256);
-        T* r = (T*)(base + off);
-        off += n * sizeof(T);
-        if (off > cap) ok = false;
-        return r;
-    }
-};
-
 struct Arena {                                      // library-owned HBM for packed weights
     char* base = nullptr; size_t cap = 0, off = 0;
     int reserve(size_t bytes) {
@@ -191,7 +176,6 @@ static int copy_f32(float* dst, const void* src, size_t n, hipStream_t s) {
     OFX_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     return OFX_OK;
 }
-#define TRY(x) do { int rc_ = (x); if (rc_ != OFX_OK) return rc_; } while (0)
 
 extern "C" int ofx_pack_outfit_weights(ofx_handle* h, const void* const* P, int n, ofx_stream stream) {
     OFX_REQUIRE(h, OFX_EINVAL, "pack_outfit: NULL handle");

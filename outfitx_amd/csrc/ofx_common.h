@@ -118,6 +118,22 @@ struct ProfScope {
 };
 
 // ---- internal launchers (defined in the .hip files, used by api.hip) ----
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int pad128(int v) { return (v + 127) / 128 * 128; }
+
+struct Bump {                                       // carve a caller-provided workspace
+    char* base; size_t cap, off = 0; bool ok = true;
+    Bump(void* p, size_t c) : base((char*)p), cap(c) {}
+    template <typename T> T* take(size_t n) {
+        off = align_up(off, 256);
+        T* r = (T*)(base + off);
+        off += n * sizeof(T);
+        if (off > cap) ok = false;
+        return r;
+    }
+};
+#define TRY(x) do { int rc_ = (x); if (rc_ != OFX_OK) return rc_; } while (0)
+
 // ---- dropout (training step): stateless masks.  Element (row, col) of dropout site `site` is kept iff
 // hash(seed, site, row, col) >= thresh, thresh = p * 2^32; kept values are scaled by 1 / (1 - p).  Forward and backward
 // recompute the same mask from the same counters, so no mask is ever stored.  thresh == 0 means "no dropout".

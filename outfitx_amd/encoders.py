@@ -279,7 +279,12 @@ class CLIPImageEncoder(_TowerBase):
             return images.reshape(b * images.size(1), *images.shape[2:]), b
         if len(set(len(seq) for seq in images)) != 1:
             raise ValueError("All sequences in images should have the same length.")
-        return clip_preprocess(flatten_seq_to_one_dim(images), self.model.config.image_size), len(images)
+        flat = flatten_seq_to_one_dim(images)
+        arrs = [np.asarray(im if not isinstance(im, Image.Image) or im.mode in ("RGB", "L") else im.convert("RGB")) for im in flat]
+        if all(a.dtype == np.uint8 for a in arrs) and self.device.type == "cuda":
+            # resize / crop / normalise on the GPU from the packed uint8 bytes, bit-identical to the host pipeline
+            return self._engine("vision").clip_preprocess(arrs, self.model.config.image_size, CLIP_MEAN, CLIP_STD), len(images)
+        return clip_preprocess(flat, self.model.config.image_size), len(images)
 
     @torch.no_grad()
     def encode_into(self, images, out: torch.Tensor, col: int, normalize: bool) -> int:

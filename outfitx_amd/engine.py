@@ -223,6 +223,43 @@ class Engine:
             L.check(self.lib.ofx_vit_b32_fwd(self.h, _ptr(px), N, _ptr(out), out.stride(0), col, int(normalize),
                                              _ptr(ws), ws.numel(), _stream(self.device)), "ofx_vit_b32_fwd")
 
+    def clip_preprocess(self, images: Sequence, size: int, mean: Sequence[float], std: Sequence[float]) -> torch.Tensor:
+        """uint8 images ([H,W,3] or [H,W] numpy arrays, any sizes) -> normalised pixel_values [N,3,size,size] fp32 on the
+        device: the packed bytes travel once (0.27 MB per 300x300 image instead of 0.6 MB of fp32 pixels) and the resize /
+        crop / normalise run on the GPU, bit-identical to PIL + CLIPImageProcessor (ofx_clip_preprocess)."""
+        import numpy as np
+        arrs = []
+        for a in images:
+            a = np.asarray(a)
+            if a.dtype != np.uint8 or a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] != 3):
+                raise ValueError(f"clip_preprocess takes uint8 [H,W,3] or [H,W] images, got {a.dtype} {a.shape}")
+            arrs.append(np.repeat(a[:, :, None], 3, 2) if a.ndim == 2 else a)
+        N = len(arrs)
+        hs = np.asarray([a.shape[0] for a in arrs], np.int32); ws_ = np.asarray([a.shape[1] for a in arrs], np.int32)
+        nbytes = hs.astype(np.int64) * ws_ * 3
+        offs = np.zeros(N, np.int64); offs[1:] = np.cumsum((nbytes[:-1] + 15) // 16 * 16)
+        total = int(offs[-1] + nbytes[-1])
+        stage = getattr(self, "_px_stage", None)
+        if stage is None or stage.numel() < total:
+            stage = torch.empty(int(total * 1.25) + 4096, dtype=torch.uint8).pin_memory()
+            self._px_stage = stage
+        else:
+            torch.cuda.current_stream(self.device).synchronize()      # the previous batch's copy must have left the staging buffer
+        buf = stage.numpy()
+        for a, o, n in zip(arrs, offs, nbytes):
+            buf[o:o + n] = a.reshape(-1)
+        src = stage[:total].to(self.device, non_blocking=True)
+        out = torch.empty(N, 3, size, size, dtype=torch.float32, device=self.device)
+        I = C.POINTER(C.c_int); LL = C.POINTER(C.c_longlong)
+        nb = int(self.lib.ofx_clip_preprocess_ws(hs.ctypes.data_as(I), ws_.ctypes.data_as(I), N, 3, size))
+        ws = self.workspace(nb)
+        m = (C.c_float * 3)(*mean); sd = (C.c_float * 3)(*std)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ofx_clip_preprocess(_ptr(src), offs.ctypes.data_as(LL), hs.ctypes.data_as(I), ws_.ctypes.data_as(I), N, 3, size,
+                                                 m, sd, _ptr(out), _ptr(ws), ws.numel(), _stream(self.device)), "ofx_clip_preprocess")
+        self._keep_px = src
+        return out
+
     def stage_tokens(self, ids: torch.Tensor, att: Optional[torch.Tensor]):
         """Token ids / mask -> device int64 (non-blocking from pinned memory).  Call this BEFORE enqueuing a long
         kernel sequence: a blocking H2D copy in the middle of a step stalls the host behind everything queued."""

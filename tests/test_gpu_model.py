@@ -313,3 +313,42 @@ def test_indexed_input_is_bit_identical_to_the_padded_form(model):
 
 def cu_(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_gpu_image_preprocessing_is_bit_identical_to_pil_pipeline(model):
+    """N2: resize (PIL antialiased bicubic) + centre crop + normalise on the GPU from packed uint8 images == the PIL-based host
+    pipeline AND the numpy oracle, bit for bit; mixed sizes, portrait / landscape / upscale / one-axis / grey."""
+    from PIL import Image
+    from outfitx_amd.encoders import CLIP_MEAN, CLIP_STD, clip_preprocess
+    g = np.random.default_rng(5)
+    shapes = [(300, 300, 3), (400, 300, 3), (300, 451, 3), (100, 80, 3), (1000, 777, 3), (224, 500, 3), (225, 224, 3), (37, 53, 3),
+              (224, 224, 3), (90, 130), (640, 480, 3), (2, 3, 3)]
+    ims = [g.integers(0, 256, s, dtype=np.uint8) for s in shapes]
+    eng = model.item_encoder.image_enc._engine("vision")
+    got = eng.clip_preprocess(ims, 224, CLIP_MEAN, CLIP_STD).cpu().numpy()
+    want = clip_preprocess([Image.fromarray(a) for a in ims]).numpy()
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert np.array_equal(got[:4], O.clip_preprocess(ims[:4]))
+    # smooth content too (random noise hides nothing, but gradients exercise the clamps differently)
+    yy, xx = np.mgrid[0:333, 0:517]
+    smooth = np.stack([(yy * 255 // 332), (xx * 255 // 516), ((yy + xx) % 256)], -1).astype(np.uint8)
+    assert np.array_equal(eng.clip_preprocess([smooth], 224, CLIP_MEAN, CLIP_STD).cpu().numpy(), clip_preprocess([Image.fromarray(smooth)]).numpy())
+    again = eng.clip_preprocess(ims[:3], 224, CLIP_MEAN, CLIP_STD).cpu().numpy()          # cached plans, reused staging
+    assert np.array_equal(again, want[:3])
+    with pytest.raises(ValueError):
+        eng.clip_preprocess([np.zeros((4, 4, 4), np.uint8)], 224, CLIP_MEAN, CLIP_STD)
+
+
+def test_item_encoder_takes_pil_images_through_the_gpu_preprocessor(model):
+    """PIL / uint8 inputs (what the reference's PE script feeds, precompute_embedding_script.py:44) -> same embeddings as
+    host-preprocessed pixel tensors fed to the tower directly."""
+    from PIL import Image
+    from outfitx_amd.encoders import clip_preprocess
+    g = np.random.default_rng(6)
+    ims = [[Image.fromarray(g.integers(0, 256, (h, w, 3), dtype=np.uint8))] for h, w in ((300, 300), (280, 350), (500, 400))]
+    enc = model.item_encoder.image_enc
+    with torch.no_grad():
+        a = enc(ims)
+        px = clip_preprocess([r[0] for r in ims]).view(3, 1, 3, 224, 224).cuda()
+        b = enc(px)
+    assert torch.equal(a, b)

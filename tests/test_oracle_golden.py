@@ -100,3 +100,21 @@ def test_aux_focal_and_collate():
     emb, mask = O.pad_outfits(rows)
     assert synth.checksum(emb) == str(g["proc_emb_crc"])
     assert np.array_equal(mask, g["proc_mask"])
+
+
+def test_pil_bicubic_restatement_is_bit_exact():
+    """N2 oracle pin: the numpy restatement of Pillow's ImagingResample (bicubic, antialiased, 8-bit two-pass) equals PIL
+    itself on down- and up-scales, odd sizes, one-axis resizes and grey images; and the whole CLIPImageProcessor chain equals
+    the PIL-based host pipeline bit for bit."""
+    from PIL import Image
+    from outfitx_amd.encoders import clip_preprocess as host_preprocess
+    g = np.random.default_rng(0)
+    for (h, w, nh, nw) in [(300, 300, 224, 224), (400, 300, 298, 224), (300, 451, 224, 336), (100, 80, 280, 224),
+                           (1000, 777, 288, 224), (224, 500, 224, 500), (225, 224, 225, 224), (37, 53, 224, 320)]:
+        a = g.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(a).resize((nw, nh), resample=Image.BICUBIC))
+        assert np.array_equal(O.pil_resize_bicubic(a, nw, nh), ref), (h, w)
+    grey = g.integers(0, 256, (90, 130), dtype=np.uint8)
+    assert np.array_equal(O.pil_resize_bicubic(grey, 323, 224), np.asarray(Image.fromarray(grey).resize((323, 224), resample=Image.BICUBIC)))
+    ims = [g.integers(0, 256, s, dtype=np.uint8) for s in [(300, 300, 3), (260, 400, 3), (500, 231, 3), (60, 45, 3), (224, 224, 3), (90, 130)]]
+    assert np.array_equal(O.clip_preprocess(ims), host_preprocess(ims).numpy())

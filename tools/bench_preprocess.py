@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""N2 measurement: 2048 images (300x300 uint8, Polyvore's size) -> normalised pixel_values on the device.
+  host: PIL resize + crop + normalise per image (the reference's CLIPImageProcessor work), then H2D of fp32 [N,3,224,224]
+  gpu : pack uint8 -> pinned -> H2D -> ofx_clip_preprocess (two integer passes + normalise)"""
+import argparse, json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from outfitx_amd import _lib as L
+from outfitx_amd.encoders import CLIP_MEAN, CLIP_STD, clip_preprocess
+from outfitx_amd.engine import Engine
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=2048)
+ap.add_argument("--hw", type=int, nargs=2, default=[300, 300])
+a = ap.parse_args()
+g = np.random.default_rng(0)
+ims = [g.integers(0, 256, (a.hw[0], a.hw[1], 3), dtype=np.uint8) for _ in range(a.n)]
+eng = Engine(torch.device("cuda"))
+res = {"n": a.n, "hw": a.hw}
+t0 = time.perf_counter(); host = clip_preprocess(ims[:256]); res["ms_host_pil_per_2048"] = (time.perf_counter() - t0) * 1e3 * a.n / 256
+hp = host.pin_memory()
+hp.cuda(non_blocking=True); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(5): hp.cuda(non_blocking=True)
+torch.cuda.synchronize()
+res["ms_h2d_fp32_per_2048"] = (time.perf_counter() - t0) / 5 * 1e3 * a.n / 256
+out = eng.clip_preprocess(ims, 224, CLIP_MEAN, CLIP_STD); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(3): out = eng.clip_preprocess(ims, 224, CLIP_MEAN, CLIP_STD)
+torch.cuda.synchronize(); res["ms_gpu_path_total"] = (time.perf_counter() - t0) / 3 * 1e3
+res["h2d_bytes_uint8"] = int(sum(i.nbytes for i in ims)); res["h2d_bytes_fp32"] = a.n * 3 * 224 * 224 * 4
+res["identical_to_host"] = bool(np.array_equal(out[:256].cpu().numpy(), host.numpy()))
+print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in res.items()}))
