@@ -129,7 +129,8 @@ int ofx_topk_merge(const int64_t* idx_in, const float* dist_in, int parts, int n
  * shortest edge to `size` with PIL's antialiased BICUBIC (ImagingResample: 22-bit fixed-point coefficients, horizontal then
  * vertical, 8-bit intermediate — bit-exact), centre crop size x size, x 1/255, (x - mean) / std -> out [N, 3, size, size] fp32
  * (device), equal to the host pipeline bit for bit.  src: device buffer holding the N uint8 images row-major with `channels`
- * (3 = RGB interleaved, 1 = grey, replicated) at byte offsets[i]; offsets / heights / widths are HOST arrays. */
+ * (3 = RGB interleaved, 1 = grey, replicated) at byte offsets[i]; offsets / heights / widths are HOST arrays.  RGB pixels are
+ * fetched as unaligned dwords: src must stay readable 1 byte past the end of every image (give the buffer >= 4 bytes of slack). */
 size_t ofx_clip_preprocess_ws(const int* heights, const int* widths, int N, int channels, int size);
 int ofx_clip_preprocess(const uint8_t* src, const long long* offsets, const int* heights, const int* widths, int N, int channels, int size,
                         const float* mean, const float* stdv, float* out, void* ws, size_t ws_bytes, ofx_stream stream);

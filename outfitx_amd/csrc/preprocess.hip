@@ -34,35 +34,65 @@ struct ImgDesc {
     int y0, nrows;         // input rows [y0, y0 + nrows) feed the vertical pass
 };
 
-// ---- horizontal pass: inter[row][col][ch] for the needed input rows and the crop's columns
+// ---- horizontal pass: inter[row][col] = one RGBX dword per pixel, for the needed input rows and the crop's columns.
+// RGB sources are read with ONE (unaligned) dword load per tap - the three channels plus one byte of the next pixel - so
+// the packed source must stay readable 1 byte past every image (offsets are 16-byte aligned and the buffer ends in slack).
+__device__ __forceinline__ unsigned load_u32_unaligned(const uint8_t* p) {
+    unsigned v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+// One thread per output column: its taps (window start + up to KT fixed-point coefficients) stay in registers while the
+// block walks ROWS_H input rows, so the inner loop is one dword load + three integer MACs per tap.  KT is the smallest
+// bucket covering the batch's widest window (taps past a column's own count carry coefficient 0 and a clamped address).
+constexpr int ROWS_H = 16;
+template <int KT>
 __global__ __launch_bounds__(256) void resample_h_kernel(const uint8_t* src, const ImgDesc* descs, const int* blob, uint8_t* inter, int size) {
     const ImgDesc d = descs[blockIdx.y];
+    const int row0 = blockIdx.x * ROWS_H;
+    if (row0 >= d.nrows) return;
     const int* plan = blob + d.hplan;
     const int ksize = plan[0];
     const int* bounds = plan + 1;
     const int* coef = plan + 1 + 2 * size;
-    const uint8_t* img = src + d.src_off;
-    uint8_t* out = inter + d.inter_off;
-    const int total = d.nrows * size;
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < total; p += gridDim.x * 256) {
-        const int row = p / size, col = p - row * size;
+    unsigned* out = (unsigned*)(inter + d.inter_off);
+    const int rows = min(ROWS_H, d.nrows - row0);
+    for (int col = threadIdx.x; col < size; col += 256) {
         const int xmin = bounds[2 * col], n = bounds[2 * col + 1];
-        const int* k = coef + col * ksize;
-        const uint8_t* px = img + ((size_t)(d.y0 + row) * d.w + xmin) * d.c;
-        if (d.c == 3) {
-            int s0 = 1 << (PBITS - 1), s1 = s0, s2 = s0;
-            for (int x = 0; x < n; ++x) {
-                const int kv = k[x];
-                s0 += px[3 * x] * kv; s1 += px[3 * x + 1] * kv; s2 += px[3 * x + 2] * kv;
+        const uint8_t* px = src + d.src_off + ((size_t)(d.y0 + row0) * d.w + xmin) * d.c;
+        const size_t pitch = (size_t)d.w * d.c;
+        if (KT > 0 && d.c == 3) {
+            int kv[KT > 0 ? KT : 1], xo[KT > 0 ? KT : 1];
+#pragma unroll
+            for (int x = 0; x < KT; ++x) { kv[x] = x < n ? coef[col * ksize + x] : 0; xo[x] = 3 * max(min(x, n - 1), 0); }
+            for (int r = 0; r < rows; ++r) {
+                int s0 = 1 << (PBITS - 1), s1 = s0, s2 = s0;
+#pragma unroll
+                for (int x = 0; x < KT; ++x) {
+                    const unsigned v = load_u32_unaligned(px + xo[x]);
+                    s0 += (int)(v & 255u) * kv[x]; s1 += (int)((v >> 8) & 255u) * kv[x]; s2 += (int)((v >> 16) & 255u) * kv[x];
+                }
+                out[(size_t)(row0 + r) * size + col] = (unsigned)min(max(s0 >> PBITS, 0), 255) | ((unsigned)min(max(s1 >> PBITS, 0), 255) << 8) |
+                                                       ((unsigned)min(max(s2 >> PBITS, 0), 255) << 16);
+                px += pitch;
             }
-            uint8_t* o = out + (size_t)p * 3;
-            o[0] = (uint8_t)min(max(s0 >> PBITS, 0), 255);
-            o[1] = (uint8_t)min(max(s1 >> PBITS, 0), 255);
-            o[2] = (uint8_t)min(max(s2 >> PBITS, 0), 255);
-        } else {
-            int s0 = 1 << (PBITS - 1);
-            for (int x = 0; x < n; ++x) s0 += px[x] * k[x];
-            out[p] = (uint8_t)min(max(s0 >> PBITS, 0), 255);
+        } else {                                            // wide windows (heavy down-scaling) and grey sources: taps from memory
+            const int* k = coef + col * ksize;
+            for (int r = 0; r < rows; ++r) {
+                int s0 = 1 << (PBITS - 1), s1 = s0, s2 = s0;
+                if (d.c == 3) {
+                    for (int x = 0; x < n; ++x) {
+                        const unsigned v = load_u32_unaligned(px + 3 * x);
+                        s0 += (int)(v & 255u) * k[x]; s1 += (int)((v >> 8) & 255u) * k[x]; s2 += (int)((v >> 16) & 255u) * k[x];
+                    }
+                } else {
+                    for (int x = 0; x < n; ++x) s0 += px[x] * k[x];
+                    s1 = s2 = s0;
+                }
+                out[(size_t)(row0 + r) * size + col] = (unsigned)min(max(s0 >> PBITS, 0), 255) | ((unsigned)min(max(s1 >> PBITS, 0), 255) << 8) |
+                                                       ((unsigned)min(max(s2 >> PBITS, 0), 255) << 16);
+                px += pitch;
+            }
         }
     }
 }
@@ -77,6 +107,7 @@ __device__ __forceinline__ float mul_then_sub(float a, float b, float c) {
 
 // ---- vertical pass + rescale + normalise -> planar fp32 [N, 3, size, size].  float ops are individually rounded
 // (no fma contraction) so the result equals numpy's (a * f32(1/255) - mean) / std bit for bit.
+constexpr int ROWS_V = 8;
 __global__ __launch_bounds__(256) void resample_v_kernel(const ImgDesc* descs, const int* blob, const uint8_t* inter, float* out, int size,
                                                          float m0, float m1, float m2, float s0d, float s1d, float s2d) {
     const ImgDesc d = descs[blockIdx.y];
@@ -84,31 +115,29 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const ImgDesc* descs, c
     const int ksize = plan[0];
     const int* bounds = plan + 1;
     const int* coef = plan + 1 + 2 * size;
-    const uint8_t* in = inter + d.inter_off;
+    const unsigned* in = (const unsigned*)(inter + d.inter_off);
     const float r255 = (float)(1.0 / 255.0);
     float* o = out + (size_t)blockIdx.y * 3 * size * size;
     const int total = size * size;
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < total; p += gridDim.x * 256) {
-        const int row = p / size, col = p - row * size;
+    for (int rr = 0; rr < ROWS_V; ++rr) {
+        const int row = blockIdx.x * ROWS_V + rr;               // block-uniform: bounds and coefficients come through scalar loads
+        if (row >= size) break;
         const int ymin = bounds[2 * row] - d.y0, n = bounds[2 * row + 1];
         const int* k = coef + row * ksize;
-        int a0 = 1 << (PBITS - 1), a1 = a0, a2 = a0;
-        if (d.c == 3) {
-            const uint8_t* px = in + ((size_t)ymin * size + col) * 3;
+        for (int col = threadIdx.x; col < size; col += 256) {
+            int a0 = 1 << (PBITS - 1), a1 = a0, a2 = a0;
+            const unsigned* px = in + (size_t)ymin * size + col;
             for (int y = 0; y < n; ++y) {
                 const int kv = k[y];
-                a0 += px[0] * kv; a1 += px[1] * kv; a2 += px[2] * kv;
-                px += (size_t)size * 3;
+                const unsigned v = px[(size_t)y * size];
+                a0 += (int)(v & 255u) * kv; a1 += (int)((v >> 8) & 255u) * kv; a2 += (int)((v >> 16) & 255u) * kv;
             }
-        } else {
-            const uint8_t* px = in + (size_t)ymin * size + col;
-            for (int y = 0; y < n; ++y) { a0 += px[0] * k[y]; px += size; }
-            a1 = a2 = a0;
+            const float v0 = (float)min(max(a0 >> PBITS, 0), 255), v1 = (float)min(max(a1 >> PBITS, 0), 255), v2 = (float)min(max(a2 >> PBITS, 0), 255);
+            const int p = row * size + col;
+            o[p] = __fdiv_rn(mul_then_sub(v0, r255, m0), s0d);
+            o[total + p] = __fdiv_rn(mul_then_sub(v1, r255, m1), s1d);
+            o[2 * total + p] = __fdiv_rn(mul_then_sub(v2, r255, m2), s2d);
         }
-        const float v0 = (float)min(max(a0 >> PBITS, 0), 255), v1 = (float)min(max(a1 >> PBITS, 0), 255), v2 = (float)min(max(a2 >> PBITS, 0), 255);
-        o[p] = __fdiv_rn(mul_then_sub(v0, r255, m0), s0d);
-        o[total + p] = __fdiv_rn(mul_then_sub(v1, r255, m1), s1d);
-        o[2 * total + p] = __fdiv_rn(mul_then_sub(v2, r255, m2), s2d);
     }
 }
 
@@ -194,7 +223,7 @@ struct Batch {
     std::vector<ImgDesc> descs;
     std::vector<int> blob;
     size_t inter_bytes = 0;
-    int max_rows = 0;
+    int max_rows = 0, max_ksize_h = 0;
 };
 int plan_batch(const long long* offsets, const int* hs, const int* ws, int N, int channels, int size, Batch* b) {
     std::lock_guard<std::mutex> lk(g_plan_mu);
@@ -214,8 +243,9 @@ int plan_batch(const long long* offsets, const int* hs, const int* ws, int N, in
         d.y0 = vb[0];
         d.nrows = vb[2 * (size - 1)] + vb[2 * (size - 1) + 1] - d.y0;
         d.inter_off = (long long)b->inter_bytes;
-        b->inter_bytes += align_up((size_t)d.nrows * size * channels, 16);
+        b->inter_bytes += align_up((size_t)d.nrows * size * 4, 16);        // one RGBX dword per intermediate pixel
         b->max_rows = std::max(b->max_rows, d.nrows);
+        b->max_ksize_h = std::max(b->max_ksize_h, (*hp)[0]);
     }
     return OFX_OK;
 }
@@ -259,10 +289,12 @@ extern "C" int ofx_clip_preprocess(const uint8_t* src, const long long* offsets,
         OFX_HIP(hipEventRecord(g_stage.ev, s));
     }
     ProfScope prof(PROF_OTHER, s);
-    int gx = (b.max_rows * size + 255) / 256; gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
-    hipLaunchKernelGGL(resample_h_kernel, dim3(gx, N), dim3(256), 0, s, src, d_desc, d_blob, d_inter, size);
-    int gv = (size * size + 255) / 256; gv = gv > 64 ? 64 : gv;
-    hipLaunchKernelGGL(resample_v_kernel, dim3(gv, N), dim3(256), 0, s, d_desc, d_blob, d_inter, out, size, mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2]);
+    const dim3 gh((b.max_rows + ROWS_H - 1) / ROWS_H, N);
+    if (channels == 3 && b.max_ksize_h <= 8) hipLaunchKernelGGL(resample_h_kernel<8>, gh, dim3(256), 0, s, src, d_desc, d_blob, d_inter, size);
+    else if (channels == 3 && b.max_ksize_h <= 16) hipLaunchKernelGGL(resample_h_kernel<16>, gh, dim3(256), 0, s, src, d_desc, d_blob, d_inter, size);
+    else hipLaunchKernelGGL(resample_h_kernel<0>, gh, dim3(256), 0, s, src, d_desc, d_blob, d_inter, size);
+    hipLaunchKernelGGL(resample_v_kernel, dim3((size + ROWS_V - 1) / ROWS_V, N), dim3(256), 0, s, d_desc, d_blob, d_inter, out, size, mean[0], mean[1], mean[2], stdv[0],
+                       stdv[1], stdv[2]);
     OFX_LAUNCH_CHECK();
     return OFX_OK;
 }
