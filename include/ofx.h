@@ -164,6 +164,15 @@ int ofx_cp_train_bwd(ofx_handle* h, void* tape, size_t tape_bytes, const float* 
 int ofx_cp_train_fwd_indexed(ofx_handle* h, const float* table, int ld, long long n_table, const int* item_index, const int* cu_items,
                              int B, int max_len, float* logits, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes,
                              float dropout_p, unsigned seed, ofx_stream stream);
+/* CIR / FITB path (outfit_x.py:147-172) with a tape and its backward: prefix = [target_item_image_emb | target_text[b]],
+ * y [B, d_model] = row0 Wc^T (cir_ffn, no bias, no dropout).  The set is given either padded (x, pad_mask) or indexed
+ * (table, ld, n_table, item_index, cu_items) - pass NULL for the form not used.  Gradients land in the same flat buffer
+ * (slots: target_item_image_emb, cir_ffn weight, all layer tensors; the CP head's and outfit_token's slots are not written). */
+int ofx_cir_train_fwd(ofx_handle* h, const float* x, const uint8_t* pad_mask, const float* table, int ld, long long n_table,
+                      const int* item_index, const int* cu_items, const float* target_text, int B, int L, float* y, void* tape,
+                      size_t tape_bytes, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream);
+int ofx_cir_train_bwd(ofx_handle* h, void* tape, size_t tape_bytes, const float* dy, int B, int L, float* grads, size_t grad_floats,
+                      void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream);
 /* out[rows, cols] fp32 = keep-mask / (1 - p) of dropout site `site` (layer l: 4l + {0 attention [B*heads, 32*i + j], 1 dropout1,
  * 2 FFN, 3 dropout2}; 4 * n_layers = head), exactly as the kernels compute it.  Test / debugging aid. */
 int ofx_dropout_mask(float dropout_p, unsigned seed, int site, int rows, int cols, float* out, ofx_stream stream);

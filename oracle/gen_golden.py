@@ -76,6 +76,8 @@ def import_reference():
     import src.models.configs as C
     import src.models.datatypes as T
     from src.losses.focal_loss import FocalLoss
+    from src.losses.set_wise_ranking_loss import SetWiseRankingLoss
+    FocalLoss.SetWiseRankingLoss = SetWiseRankingLoss            # carried along without changing the tuple below
     from src.models.processor import OutfitXProcessorFactory
     return M, C, T, FocalLoss, OutfitXProcessorFactory, TableTokenizer, transformers.__version__
 
@@ -237,6 +239,40 @@ def main():
     out["post/transformer_encoder.layers.0.norm1.weight"] = m2.transformer_encoder.layers[0].norm1.weight.detach().numpy()
     np.savez_compressed(os.path.join(OUT, "train_step.npz"), **out)
     print("train step: loss", float(loss), "clip norm", out["clip_norm"], "params with grad", len(names))
+
+    # ---- 9. one CIR training step: reference model in train() mode (dropout 0, fp32), SetWiseRankingLoss(margin 2) ----
+    # complementary_item_retrieval_trainer.py:73-88: y_hat = model(CIR batch); loss(batch_y, batch_y_hat, negatives, mask); backward.
+    m2.load_state_dict(sd, strict=True)                      # §8's optimizer step moved the weights: back to the seeded ones
+    m2.zero_grad(set_to_none=True)
+    n_c = np.array([2, 5, 8, 1, 3, 7, 16, 4, 6, 9])
+    Bc, Kn = len(n_c), 6
+    emb_c, mask_c = synth.outfit_batch(1245, Bc, 16, n_c)
+    txt_c = synth.unit_rows(1245, "target_text", Bc, 512)
+    pos = synth.item_embeddings(1245, "pos", Bc)
+    neg = synth.item_embeddings(1245, "neg", Bc * Kn).reshape(Bc, Kn, 1024)
+    g_ = np.random.Generator(np.random.PCG64(1245))
+    neg_mask = g_.random((Bc, Kn)) < 0.25
+    neg_mask[:, 0] = False
+    y_c = m2(task=CIR, outfit_embedding=t(emb_c), outfit_mask=t(mask_c), target_item_text_embedding=t(txt_c))
+    loss_c = FocalLoss.SetWiseRankingLoss(margin=2.0)(batch_y=t(pos) * 3.0, batch_y_hat=y_c, batch_negative_samples=t(neg) * 3.0,
+                                                     batch_negative_mask=t(neg_mask))
+    loss_c.backward()
+    outc = dict(seed=1245, n_items=n_c, K=Kn, neg_mask=neg_mask, emb_crc=synth.checksum(emb_c), y_hat=y_c.detach().numpy(), loss=float(loss_c),
+                meta=str(meta))
+    names, norms = [], []
+    for k, v in params.items():
+        if v.grad is None:
+            continue
+        gr = v.grad.detach().numpy()
+        names.append(k); norms.append(float(np.sqrt((gr.astype(np.float64) ** 2).sum())))
+        if gr.size <= 4096:
+            outc["grad/" + k] = gr.copy()
+        else:
+            outc["gsample/" + k] = gr.ravel()[::1009].copy()
+    outc["grad_names"] = np.asarray(names); outc["grad_norms"] = np.asarray(norms)
+    outc["no_grad_names"] = np.asarray([k for k, v in params.items() if v.grad is None])
+    np.savez_compressed(os.path.join(OUT, "train_step_cir.npz"), **outc)
+    print("cir train step: loss", float(loss_c), "params with grad", len(names), "without", list(outc["no_grad_names"]))
 
 
 if __name__ == "__main__":

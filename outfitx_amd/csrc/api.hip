@@ -78,7 +78,7 @@ int ofx_launch_set_attention_bwd(const float* qkv, const float* d_o, void* dqkv,
                                  float scale, int op_dtype, const DropArgs& drop, hipStream_t s);
 int ofx_launch_drop_rows(float* x, int rows, int cols, const DropArgs& d, hipStream_t s);
 int ofx_launch_focal_loss(const float* logits, const float* labels, int B, float alpha, float gamma, float upstream, float* loss, float* dlogits, hipStream_t s);
-int ofx_launch_cp_head_bwd(const float* dlogits, const float* w, const int* cu, float* dX, void* dXb, float* db, int B, int D, int op_dtype,
+int ofx_launch_cp_head_bwd(const float* dlogits, const float* w_or_rows, const int* cu, float* dX, void* dXb, float* db, int B, int D, int op_dtype,
                            const DropArgs& head, const DropArgs& below, hipStream_t s);
 int ofx_launch_fitb(const float* y, const float* cand, int B, int C, int D, int64_t* idx, float* dist, hipStream_t s);
 int ofx_launch_l2_topk(const float* Q, const float* P, int nq, int np, int D, int k, int64_t index_base, int64_t* idx,
@@ -121,7 +121,7 @@ struct ofx_handle {
     Arena a_out; bool out_ready = false;
     int ot_dtype, ot_kmul, ot_ffn_pad;
     std::vector<OutfitLayer> ol;
-    float *outfit_token, *tgt_img_emb, *cp_w, *cp_b; void* cir_w;
+    float *outfit_token, *tgt_img_emb, *cp_w, *cp_b; void* cir_w; void* cir_w_t = nullptr;   // cir_w_t: W^T operand copy (training dgrad)
     // towers
     int tw_dtype;
     Arena a_vis; bool vis_ready = false;
@@ -186,7 +186,7 @@ extern "C" int ofx_pack_outfit_weights(ofx_handle* h, const void* const* P, int 
     const size_t D = d.d_model, F = d.d_ffn, Fp = h->ot_ffn_pad, km = h->ot_kmul;
     const size_t per_layer = 2 * km * (3 * D * D + D * D + Fp * D + D * Fp) + 4 * (3 * D + D + Fp + D + 4 * D) + 16 * 256;
     const size_t per_layer_t = km == 1 ? 2 * (3 * D * D + D * D + 2 * Fp * D) + 8 * 256 : 0;
-    TRY(h->a_out.reserve((per_layer + per_layer_t) * d.n_layers + 2 * km * D * D + 4 * (3 * D + 8) + 16 * 256));
+    TRY(h->a_out.reserve((per_layer + per_layer_t) * d.n_layers + 2 * (km + 1) * D * D + 4 * (3 * D + 8) + 16 * 256));
     Arena& A = h->a_out;
     const int dt = h->ot_dtype, mode = km == 3 ? 2 : 0;
     h->outfit_token = A.take<float>(D); TRY(copy_f32(h->outfit_token, P[0], D, s));
@@ -194,6 +194,8 @@ extern "C" int ofx_pack_outfit_weights(ofx_handle* h, const void* const* P, int 
     h->cp_w = A.take<float>(D); TRY(copy_f32(h->cp_w, P[2], D, s));
     h->cp_b = A.take<float>(1); TRY(copy_f32(h->cp_b, P[3], 1, s));
     h->cir_w = A.take<char>(2 * km * D * D); TRY(ofx_launch_pack_rows((const float*)P[4], h->cir_w, D, D, D, D, D, mode, dt, s));
+    h->cir_w_t = nullptr;
+    if (km == 1) { h->cir_w_t = A.take<char>(2 * D * D); TRY(ofx_launch_transpose_cast((const float*)P[4], h->cir_w_t, (int)D, (int)D, (int)D, dt, s)); }
     h->ol.resize(d.n_layers);
     for (int l = 0; l < d.n_layers; ++l) {
         const void* const* q = P + 5 + 12 * l;
@@ -602,12 +604,14 @@ static bool d_outfit_act_is_mish(const ofx_handle* h) { return h->d.outfit_act =
 // (bf16 / f16, like the reference's AMP training); dropout is NOT applied (the caller must use dropout = 0).
 namespace {
 struct TapeLayer { float* Xin; float* st1; char* H1; float* QKV; char* O; float* Xmid; float* st2; char* H2; float* Upre; char* A; };
-struct Tape { int* cu; float* Xfinal; float* row0; std::vector<TapeLayer> L; size_t bytes; };
+struct Tape { int* cu; float* Xfinal; float* row0; float* prefix; char* row0b; std::vector<TapeLayer> L; size_t bytes; };
 size_t carve_tape(const ofx_handle* h, Bump& b, int B, int Lq, Tape* t) {
     const size_t M = (size_t)B * (Lq + 1), D = h->d.d_model, Fp = h->ot_ffn_pad, Mp = align_up(M, 64);   // operand copies: rows readable up to Mp (TN GEMM)
     Tape tp;
     tp.cu = b.take<int>(B + 1);
     tp.row0 = b.take<float>((size_t)B * D);
+    tp.prefix = b.take<float>((size_t)B * D);                              // CIR: per-outfit prefix [img_emb | target text]
+    tp.row0b = b.take<char>(align_up((size_t)B, 64) * D * 2);             // CIR: operand copy of row0 (dW of cir_ffn)
     tp.L.resize(h->d.n_layers);
     for (TapeLayer& l : tp.L) {
         l.Xin = b.take<float>(M * D); l.st1 = b.take<float>(M * 2); l.H1 = b.take<char>(Mp * D * 2); l.QKV = b.take<float>(M * 3 * D);
@@ -619,16 +623,18 @@ size_t carve_tape(const ofx_handle* h, Bump& b, int B, int Lq, Tape* t) {
     if (t) *t = tp;
     return tp.bytes;
 }
-struct BwdWs { float *dXa, *dXb_f, *dH, *dO, *part; char *gXb, *dU, *gQb; char* slab; size_t slab_bytes; };
+struct BwdWs { float *dXa, *dXb_f, *dH, *dO, *part, *d_row0; char *gXb, *dU, *gQb, *dyb; char* slab; size_t slab_bytes; };
 size_t carve_bwd(const ofx_handle* h, Bump& b, int B, int Lq, BwdWs* w) {
     const size_t M = (size_t)B * (Lq + 1), D = h->d.d_model, Fp = h->ot_ffn_pad, Mp = align_up(M, 64);
     BwdWs t;
     t.dXa = b.take<float>(M * D); t.dXb_f = b.take<float>(M * D); t.dH = b.take<float>(M * D); t.dO = b.take<float>(M * D);
     t.part = b.take<float>(std::max(ofx_ln_bwd_part_floats((int)D), ofx_colsum_part_floats((int)(3 * D))));
     t.gXb = b.take<char>(Mp * D * 2); t.dU = b.take<char>(Mp * Fp * 2); t.gQb = b.take<char>(Mp * 3 * D * 2);
+    t.d_row0 = b.take<float>((size_t)B * D); t.dyb = b.take<char>(align_up((size_t)B, 64) * D * 2);      // CIR head
     t.slab_bytes = 0;
     const int m = (int)M, Di = (int)D, Fi = (int)Fp;
-    for (auto s : {ofx_gemm_tn_slab_bytes(Di, Fi, m), ofx_gemm_tn_slab_bytes(Fi, Di, m), ofx_gemm_tn_slab_bytes(Di, Di, m), ofx_gemm_tn_slab_bytes(3 * Di, Di, m),
+    for (auto s : {ofx_gemm_tn_slab_bytes(Di, Di, B), ofx_gemm_splitk_bytes(B, Di, Di),
+                   ofx_gemm_tn_slab_bytes(Di, Fi, m), ofx_gemm_tn_slab_bytes(Fi, Di, m), ofx_gemm_tn_slab_bytes(Di, Di, m), ofx_gemm_tn_slab_bytes(3 * Di, Di, m),
                    ofx_gemm_splitk_bytes(m, Fi, Di), ofx_gemm_splitk_bytes(m, Di, Fi), ofx_gemm_splitk_bytes(m, Di, Di), ofx_gemm_splitk_bytes(m, Di, 3 * Di)})
         t.slab_bytes = std::max(t.slab_bytes, s);
     t.slab = b.take<char>(t.slab_bytes);
@@ -665,8 +671,9 @@ extern "C" size_t ofx_cp_train_grad_floats(ofx_handle* h, size_t* offsets, int n
 
 // dropout sites: layer l -> 4l + {0 attention probabilities, 1 dropout1 (out_proj output), 2 FFN inner, 3 dropout2 (linear2 output)};
 // 4 * n_layers = the head's Dropout (cp_ffn[0]).  torch: nn.TransformerEncoderLayer._sa_block / _ff_block, MultiheadAttention dropout.
+// head: 0 = CP (logits [B,1] = Dropout(row0) . w + b), 1 = CIR (y [B,D] = row0 Wc^T; prefix = [target_item_image_emb | target text])
 static int cp_train_fwd_core(ofx_handle* h, const SetInput& in, int B, int L, float* logits, void* tape_mem, size_t tape_bytes, void* ws,
-                             size_t ws_bytes, float dropout_p, unsigned seed, hipStream_t s);
+                             size_t ws_bytes, float dropout_p, unsigned seed, hipStream_t s, int head = 0, const float* target_text = nullptr);
 extern "C" int ofx_cp_train_fwd(ofx_handle* h, const float* x, const uint8_t* pad_mask, int B, int L, float* logits, void* tape_mem,
                                 size_t tape_bytes, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream) {
     OFX_REQUIRE(B > 0 && L >= 0 && L <= 31 && (x || L == 0) && (pad_mask || L == 0) && logits && tape_mem, OFX_EINVAL, "cp_train_fwd: bad argument");
@@ -681,8 +688,18 @@ extern "C" int ofx_cp_train_fwd_indexed(ofx_handle* h, const float* table, int l
     SetInput in; in.table = table; in.ld = ld; in.n_table = n_table; in.item_index = item_index; in.cu_items = cu_items;
     return cp_train_fwd_core(h, in, B, max_len, logits, tape_mem, tape_bytes, ws, ws_bytes, dropout_p, seed, (hipStream_t)stream);
 }
+extern "C" int ofx_cir_train_fwd(ofx_handle* h, const float* x, const uint8_t* pad_mask, const float* table, int ld, long long n_table,
+                                 const int* item_index, const int* cu_items, const float* target_text, int B, int L, float* y, void* tape_mem,
+                                 size_t tape_bytes, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream) {
+    OFX_REQUIRE(B > 0 && L >= 0 && L <= 31 && target_text && y && tape_mem, OFX_EINVAL, "cir_train_fwd: bad argument");
+    OFX_REQUIRE((x && pad_mask) || L == 0 || (table && item_index && cu_items && n_table > 0), OFX_EINVAL, "cir_train_fwd: give (x, pad_mask) or (table, item_index, cu_items)");
+    SetInput in;
+    if (table) { in.table = table; in.ld = ld; in.n_table = n_table; in.item_index = item_index; in.cu_items = cu_items; }
+    else { in.x = x; in.pad_mask = pad_mask; }
+    return cp_train_fwd_core(h, in, B, L, y, tape_mem, tape_bytes, ws, ws_bytes, dropout_p, seed, (hipStream_t)stream, 1, target_text);
+}
 static int cp_train_fwd_core(ofx_handle* h, const SetInput& in, int B, int L, float* logits, void* tape_mem, size_t tape_bytes, void* ws,
-                             size_t ws_bytes, float dropout_p, unsigned seed, hipStream_t s) {
+                             size_t ws_bytes, float dropout_p, unsigned seed, hipStream_t s, int head, const float* target_text) {
     OFX_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, OFX_EINVAL, "cp_train_fwd: dropout_p=%g", dropout_p);
     OFX_REQUIRE(h && h->out_ready, OFX_ESTATE, "cp_train_fwd: outfit weights not packed");
     OFX_REQUIRE(h->ot_kmul == 1, OFX_ESTATE, "cp_train_fwd: training uses a single-product precision (bf16 / f16), not bf16x3");
@@ -696,7 +713,12 @@ static int cp_train_fwd_core(ofx_handle* h, const SetInput& in, int B, int L, fl
     carve_set(h, wb, B, L, &w);
     OFX_REQUIRE(wb.ok, OFX_EWORKSPACE, "cp_train_fwd: workspace too small");
     const int D = d.d_model, Fp = h->ot_ffn_pad, dt = h->ot_dtype, M = B * (L + 1);
-    TRY(build_set(h, in, h->outfit_token, 0, T.cu, T.L[0].Xin, B, L, s));
+    if (head == 1) {
+        TRY(ofx_launch_cir_prefix(h->tgt_img_emb, target_text, T.prefix, B, D, s));
+        TRY(build_set(h, in, T.prefix, D, T.cu, T.L[0].Xin, B, L, s));
+    } else {
+        TRY(build_set(h, in, h->outfit_token, 0, T.cu, T.L[0].Xin, B, L, s));
+    }
     const int* m_dev = T.cu + B;
     for (int l = 0; l < d.n_layers; ++l) {
         const OutfitLayer& Ly = h->ol[l];
@@ -726,12 +748,28 @@ static int cp_train_fwd_core(ofx_handle* h, const SetInput& in, int B, int L, fl
         TRY(ofx_launch_gemm(g4, dt, s));
     }
     TRY(ofx_launch_gather_row0(T.Xfinal, T.cu, T.row0, B, D, s));
+    if (head == 1) {                                                // cir_ffn = Linear(D, d_embed, bias=False): no dropout (outfit_x.py:61-63)
+        TRY(ofx_launch_pack_rows(T.row0, T.row0b, B, B, D, D, D, 0, dt, s));
+        GemmArgs g{}; g.A = T.row0b; g.W = h->cir_w; g.C = logits; g.M = B; g.N = D; g.K = D; g.lda = D; g.ldc = D; g.out_kind = OFX_OUT_F32;
+        g.slab = w.slab; g.slab_bytes = w.slab_bytes;
+        return ofx_launch_gemm(g, dt, s);
+    }
     TRY(ofx_launch_drop_rows(T.row0, B, D, make_drop(dropout_p, seed, 4 * d.n_layers), s));     // the tape keeps the dropped-out rows
     return ofx_launch_cp_head(T.row0, h->cp_w, h->cp_b, logits, B, D, s);
 }
 
+static int set_train_bwd_core(ofx_handle* h, void* tape_mem, size_t tape_bytes, const float* dlogits, int B, int L, float* grads,
+                              size_t grad_floats, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream, int head);
 extern "C" int ofx_cp_train_bwd(ofx_handle* h, void* tape_mem, size_t tape_bytes, const float* dlogits, int B, int L, float* grads,
                                 size_t grad_floats, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream) {
+    return set_train_bwd_core(h, tape_mem, tape_bytes, dlogits, B, L, grads, grad_floats, ws, ws_bytes, dropout_p, seed, stream, 0);
+}
+extern "C" int ofx_cir_train_bwd(ofx_handle* h, void* tape_mem, size_t tape_bytes, const float* dy, int B, int L, float* grads,
+                                 size_t grad_floats, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream) {
+    return set_train_bwd_core(h, tape_mem, tape_bytes, dy, B, L, grads, grad_floats, ws, ws_bytes, dropout_p, seed, stream, 1);
+}
+static int set_train_bwd_core(ofx_handle* h, void* tape_mem, size_t tape_bytes, const float* dlogits, int B, int L, float* grads,
+                              size_t grad_floats, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream, int head) {
     OFX_REQUIRE(h && h->out_ready && h->ot_kmul == 1, OFX_ESTATE, "cp_train_bwd: needs packed single-product weights");
     OFX_REQUIRE(tape_mem && dlogits && grads && ws && B > 0, OFX_EINVAL, "cp_train_bwd: bad argument");
     OFX_REQUIRE(d_outfit_act_is_mish(h), OFX_ESTATE, "cp_train_bwd: only the Mish activation has a backward epilogue");
@@ -766,8 +804,18 @@ extern "C" int ofx_cp_train_bwd(ofx_handle* h, void* tape_mem, size_t tape_bytes
     float* dX = w.dXa; float* dX2 = w.dXb_f;
     OFX_HIP(hipMemsetAsync(dX, 0, (size_t)M * D * 4, s));
     OFX_HIP(hipMemsetAsync(w.gXb, 0, (size_t)M * D * 2, s));
+    if (head == 1) {
+        // y = row0 Wc^T:  dWc = dy^T row0 (TN GEMM over the B rows), d row0 = dy Wc; then dX[cu[b]] = d row0[b]
+        TRY(ofx_launch_pack_rows(dlogits, w.dyb, B, B, D, D, D, 0, dt, s));
+        TRY(ofx_launch_gemm_tn(w.dyb, D, T.row0b, D, G(4), D, D, D, B, nullptr, w.slab, w.slab_bytes, dt, s));
+        GemmArgs g{}; g.A = w.dyb; g.W = h->cir_w_t; g.C = w.d_row0; g.M = B; g.N = D; g.K = D; g.lda = D; g.ldc = D; g.out_kind = OFX_OUT_F32;
+        g.slab = w.slab; g.slab_bytes = w.slab_bytes;
+        TRY(ofx_launch_gemm(g, dt, s));
+        TRY(ofx_launch_cp_head_bwd(nullptr, w.d_row0, T.cu, dX, w.gXb, nullptr, B, D, dt, nodrop, site(d.n_layers - 1, 3), s));
+    } else {
     TRY(ofx_launch_cp_head_bwd(dlogits, h->cp_w, T.cu, dX, w.gXb, G(3), B, D, dt, site(d.n_layers, 0), site(d.n_layers - 1, 3), s));
     TRY(ofx_launch_colsum(T.row0, 0, D, nullptr, dlogits, G(2), nullptr, nullptr, D, w.part, D, nullptr, B, dt, s));                 // d cp_w = sum_b dlogit_b (row0_b . m_head)
+    }
     // bias gradient of the last layer's linear2 = column sums of (dX . m_dropout2): only the prefix rows are non-zero
     TRY(ofx_launch_colsum(w.gXb, 1, D, T.cu, nullptr, G(5 + 12 * (d.n_layers - 1) + 7), nullptr, nullptr, D, w.part, D, nullptr, B, dt, s));
     for (int l = d.n_layers - 1; l >= 0; --l) {
@@ -792,6 +840,8 @@ extern "C" int ofx_cp_train_bwd(ofx_handle* h, void* tape_mem, size_t tape_bytes
         TRY(ofx_launch_ln_bwd(w.dH, t.Xin, t.st1, Ly.g1, dX2, dX, w.gXb, G(g0 + 8), G(g0 + 9), l > 0 ? G(g0 - 12 + 7) : nullptr, w.part, D, m_dev, M, dt,
                               l > 0 ? site(l - 1, 3) : nodrop, s));
     }
+    // CIR: the prefix is [target_item_image_emb | text]: d target_item_image_emb = sum_b dX0[cu[b]][:D/2]
+    if (head == 1) return ofx_launch_colsum(dX, 0, D, T.cu, nullptr, G(1), nullptr, nullptr, D / 2, w.part, D / 2, nullptr, B, dt, s);
     // shared prefix token: d outfit_token = sum_b dX0[cu[b]]
     return ofx_launch_colsum(dX, 0, D, T.cu, nullptr, G(0), nullptr, nullptr, D, w.part, D, nullptr, B, dt, s);
 }

@@ -265,11 +265,13 @@ __global__ __launch_bounds__(256) void cp_head_bwd_kernel(const float* dlogits, 
                                                          DropArgs head, DropArgs below) {
     typedef typename OpT<T>::v4 v4;
     const int b = blockIdx.x;
-    const float g = dlogits[b];
     const int r = cu[b];
     const size_t row = (size_t)r * D;
+    // dlogits == nullptr: `w` is a ready [B, D] matrix of row gradients (CIR head) instead of the CP head's weight vector
+    const float g = dlogits ? dlogits[b] : 1.0f;
+    const float* wv = dlogits ? w : w + (size_t)b * D;
     for (int c = threadIdx.x * 4; c < D; c += 1024) {
-        f32x4 v = *(const f32x4*)(w + c) * g;
+        f32x4 v = *(const f32x4*)(wv + c) * g;
         if (head.thresh) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= drop_mul(head, b, c + e);
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256) void cp_head_bwd_kernel(const float* dlogits, 
         for (int e = 0; e < 4; ++e) o[e] = (T)(below.thresh ? v[e] * drop_mul(below, r, c + e) : v[e]);
         *(v4*)(dXb + row + c) = o;
     }
-    if (b == 0) {
+    if (b == 0 && db) {
         __shared__ float red[256];
         float s = 0.f;
         for (int i = threadIdx.x; i < B; i += 256) s += dlogits[i];

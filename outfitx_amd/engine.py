@@ -157,6 +157,44 @@ class Engine:
         self._keep_idx = (idx, cud)
         return logits, tape
 
+    def cir_train_fwd(self, setin, target_text: torch.Tensor, dropout_p: float = 0.0, seed: int = 0):
+        """Tape-saving CIR forward.  setin: (x [B,L,D], mask [B,L]) or (table, item_index, cu_seqlens, max_len).
+        -> (y [B,D] fp32, tape, (B, L))"""
+        txt = _f32c(target_text, self.device)
+        null = None
+        if len(setin) == 4:
+            table, item_index, cu_seqlens, Lq = setin
+            idx, cud, B, max_items = self._index_args(table, item_index, cu_seqlens)
+            if max_items is not None and max_items > Lq:
+                raise ValueError(f"an outfit holds {max_items} items, max_len is {Lq} (truncate in the processor)")
+            args = (null, null, _ptr(table), table.stride(0), table.shape[0], _ptr(idx), _ptr(cud))
+            self._keep_idx = (idx, cud)
+        else:
+            x, mask = setin
+            B, Lq, _ = x.shape
+            x = _f32c(x, self.device)
+            m = mask.to(device=self.device)
+            m = (m if m.dtype == torch.bool else m != 0).contiguous().view(torch.uint8)
+            args = (_ptr(x), _ptr(m), null, 0, 0, null, null)
+            self._keep_idx = (x, m)
+        tape = torch.empty(int(self.lib.ofx_cp_train_tape_bytes(self.h, B, Lq)), dtype=torch.uint8, device=self.device)
+        ws = self.workspace(int(self.lib.ofx_cp_train_ws_bytes(self.h, B, Lq)))
+        y = torch.empty(B, self.desc.d_model, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ofx_cir_train_fwd(self.h, *args, _ptr(txt), B, Lq, _ptr(y), _ptr(tape), tape.numel(), _ptr(ws), ws.numel(),
+                                               float(dropout_p), int(seed) & 0xFFFFFFFF, _stream(self.device)), "ofx_cir_train_fwd")
+        return y, tape, (B, Lq)
+
+    def cir_train_bwd(self, tape: torch.Tensor, dy: torch.Tensor, B: int, Lq: int, dropout_p: float = 0.0, seed: int = 0) -> torch.Tensor:
+        total, _ = self.grad_layout()
+        g = torch.empty(total, dtype=torch.float32, device=self.device)
+        d = _f32c(dy, self.device)
+        ws = self.workspace(int(self.lib.ofx_cp_train_ws_bytes(self.h, B, Lq)))
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ofx_cir_train_bwd(self.h, _ptr(tape), tape.numel(), _ptr(d), B, Lq, _ptr(g), total, _ptr(ws), ws.numel(),
+                                               float(dropout_p), int(seed) & 0xFFFFFFFF, _stream(self.device)), "ofx_cir_train_bwd")
+        return g
+
     def cp_head(self, row0: torch.Tensor) -> torch.Tensor:
         B = row0.shape[0]
         out = torch.empty(B, 1, dtype=torch.float32, device=self.device)

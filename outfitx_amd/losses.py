@@ -36,3 +36,25 @@ class FocalLoss(nn.Module):
 
     def forward(self, y_hat: torch.Tensor, y_true: torch.Tensor) -> torch.Tensor:
         return _FocalFn.apply(y_hat, y_true, float(self.alpha), float(self.gamma))
+
+
+class SetWiseRankingLoss(nn.Module):
+    """Drop-in for the reference's `src.losses.SetWiseRankingLoss` (src/losses/set_wise_ranking_loss.py:5-39), the CIR trainer's
+    loss (complementary_item_retrieval_trainer.py:79-88): with d+ = ||y_hat - y||, d-_k = ||y_hat - neg_k||,
+        L_all  = sum over valid negatives of relu(d+ - d-_k + margin) / max(#valid, 1)
+        L_hard = mean_b relu(d+ - min_k d-_k + margin)            (padded negatives count as +inf)
+    returned as L_all + L_hard.  Caller-side torch code on [B,D] / [B,K,D] tensors (autograd supplies d loss / d y_hat, which
+    the HIP backward of the CIR path consumes); `pairwise_distance`'s eps = 1e-6 is kept."""
+
+    def __init__(self, margin: float = 2.0):
+        super().__init__()
+        self.margin = margin
+
+    def forward(self, batch_y, batch_y_hat, batch_negative_samples, batch_negative_mask):
+        d_pos = torch.linalg.vector_norm(batch_y_hat - batch_y + 1e-6, dim=-1)                 # F.pairwise_distance adds eps to the difference
+        d_neg = torch.linalg.vector_norm(batch_y_hat[:, None, :] - batch_negative_samples, dim=-1)
+        valid = ~batch_negative_mask
+        n_valid = valid.sum().clamp(min=1)
+        hinge_all = torch.relu(d_pos[:, None] - d_neg + self.margin) * valid
+        hardest = d_neg.masked_fill(batch_negative_mask, float("inf")).amin(dim=1)
+        return hinge_all.sum() / n_valid + torch.relu(d_pos - hardest + self.margin).mean()

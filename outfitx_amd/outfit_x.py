@@ -63,26 +63,50 @@ class _CPTrainFn(torch.autograd.Function):
         g = eng.cp_train_bwd(ctx.tape, dlogits.contiguous(), B, Lq, *ctx.drop)
         ctx.tape = None
         _, offs = eng.grad_layout()
-        D, F = eng.desc.d_model, ctx.F
-        Fp = (F + 127) // 128 * 128
-        out = []
-        for i, shp in enumerate(ctx.shapes):
-            if i in (1, 4):                       # target_item_image_emb, cir_ffn: not on the CP path
-                out.append(None)
-                continue
-            k = (i - 5) % 12 if i >= 5 else -1
-            if k == 4:
-                out.append(g[offs[i]:offs[i] + Fp * D].view(Fp, D)[:F])
-            elif k == 5:
-                out.append(g[offs[i]:offs[i] + F])
-            elif k == 6:
-                out.append(g[offs[i]:offs[i] + D * Fp].view(D, Fp)[:, :F])
-            else:
-                n = 1
-                for v in shp:
-                    n *= v
-                out.append(g[offs[i]:offs[i] + n].view(shp))
+        out = _grad_views(g, offs, ctx.shapes, eng.desc.d_model, ctx.F, skip=(1, 4))   # target_item_image_emb, cir_ffn: not on the CP path
         return (None, None, None, None, None, *out)
+
+
+def _grad_views(g, offs, shapes, D, F, skip):
+    Fp = (F + 127) // 128 * 128
+    out = []
+    for i, shp in enumerate(shapes):
+        if i in skip:
+            out.append(None)
+            continue
+        k = (i - 5) % 12 if i >= 5 else -1
+        if k == 4:
+            out.append(g[offs[i]:offs[i] + Fp * D].view(Fp, D)[:F])
+        elif k == 5:
+            out.append(g[offs[i]:offs[i] + F])
+        elif k == 6:
+            out.append(g[offs[i]:offs[i] + D * Fp].view(D, Fp)[:, :F])
+        else:
+            n = 1
+            for v in shp:
+                n *= v
+            out.append(g[offs[i]:offs[i] + n].view(shp))
+    return out
+
+
+class _CIRTrainFn(torch.autograd.Function):
+    """CIR / FITB path with the hand-written backward (ofx_cir_train_fwd / ofx_cir_train_bwd): gradients reach the
+    transformer, target_item_image_emb and cir_ffn (the CP head and outfit_token are not on this path)."""
+
+    @staticmethod
+    def forward(ctx, eng, setin, txt, F, drop, *params):
+        y, tape, bl = eng.cir_train_fwd(setin, txt, *drop)
+        ctx.eng, ctx.tape, ctx.bl, ctx.F, ctx.drop = eng, tape, bl, F, drop
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        eng = ctx.eng
+        g = eng.cir_train_bwd(ctx.tape, dy.contiguous(), *ctx.bl, *ctx.drop)
+        ctx.tape = None
+        _, offs = eng.grad_layout()
+        return (None, None, None, None, None, *_grad_views(g, offs, ctx.shapes, eng.desc.d_model, ctx.F, skip=(0, 2, 3)))
 
 
 class OutfitX(nn.Module):
@@ -225,8 +249,18 @@ class OutfitX(nn.Module):
                      max_len: Optional[int] = None) -> torch.Tensor:
         """outfit_x.py:147-172 -> target-item embedding [B, d_embed] (indexed form as in _cp_forward)."""
         if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("the CIR / FITB training step (backward of the retrieval path) is not built; "
-                                      "call under torch.no_grad() or model.eval()")
+            t = self.cfg.transformer
+            if self.train_precision not in ("bf16", "f16"):
+                raise ValueError("train_precision must be 'bf16' or 'f16'")
+            if (isinstance(outfit_embedding, torch.Tensor) and outfit_embedding.requires_grad) or target_item_text_embedding.requires_grad:
+                raise NotImplementedError("gradients w.r.t. the item / text embeddings (encoder fine-tuning) are not built")
+            setin = (self._indexed(item_index, cu_seqlens, embedding_table, max_len) if item_index is not None
+                     else (outfit_embedding, outfit_mask))
+            p = float(t.dropout)
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0.0 else 0
+            self.last_dropout = (p, seed)
+            return _CIRTrainFn.apply(self._engine(self.train_precision), setin, target_item_text_embedding, t.d_ffn, (p, seed),
+                                     *self._outfit_tensors())
         eng = self._engine()
         prefix = eng.cir_prefix(target_item_text_embedding)
         if item_index is not None:

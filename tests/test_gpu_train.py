@@ -267,8 +267,71 @@ def test_training_guards():
         b = m(task=CP, outfit_embedding=cu(emb), outfit_mask=cu(mask))
     assert torch.equal(a, b)
     m.cfg.transformer.dropout = 0.0
-    with pytest.raises(NotImplementedError):
-        m(task=CIR, outfit_embedding=cu(emb), outfit_mask=cu(mask), target_item_text_embedding=cu(synth.unit_rows(5, "t", 2, 512)))
+    with pytest.raises(NotImplementedError):        # encoder fine-tuning (gradients into the embeddings) is not built
+        m(task=CP, outfit_embedding=cu(emb).requires_grad_(True), outfit_mask=cu(mask))
     m.train_precision = "bf16x3"
     with pytest.raises(ValueError):
         m(task=CP, outfit_embedding=cu(emb), outfit_mask=cu(mask))
+
+
+@pytest.mark.parametrize("prec,gtol,ltol", [("f16", 5e-3, 1e-3), ("bf16", 3e-2, 1e-2)])
+def test_cir_train_step_vs_reference_golden(prec, gtol, ltol):
+    """CIR trainer step (complementary_item_retrieval_trainer.py:73-92): y_hat = model(CIR batch) in train() mode,
+    SetWiseRankingLoss(margin 2), backward — against the reference's own loss / y_hat / gradients (dropout 0)."""
+    from src.losses import SetWiseRankingLoss
+    from src.models.datatypes import OutfitComplementaryItemRetrievalTask as CIR
+    g = golden("train_step_cir")
+    n, seed, K = g["n_items"], int(g["seed"]), int(g["K"])
+    B = len(n)
+    emb, mask = synth.outfit_batch(seed, B, 16, n)
+    assert synth.checksum(emb) == str(g["emb_crc"])
+    txt = synth.unit_rows(seed, "target_text", B, 512)
+    pos = synth.item_embeddings(seed, "pos", B) * 3.0
+    neg = synth.item_embeddings(seed, "neg", B * K).reshape(B, K, 1024) * 3.0
+    m = make_model(prec)
+    y = m(task=CIR, outfit_embedding=cu(emb), outfit_mask=cu(mask), target_item_text_embedding=cu(txt))
+    loss = SetWiseRankingLoss(margin=2.0)(batch_y=cu(pos), batch_y_hat=y, batch_negative_samples=cu(neg), batch_negative_mask=cu(g["neg_mask"]))
+    loss.backward()
+    assert np.abs(y.detach().cpu().numpy() - g["y_hat"]).max() <= ltol * np.abs(g["y_hat"]).max()
+    assert abs(float(loss) - float(g["loss"])) <= ltol * abs(float(g["loss"]))
+    params = trainable(m)
+    for k in g["no_grad_names"]:
+        assert params[str(k)].grad is None, k
+    bad = {}
+    for k, ref_norm in zip(g["grad_names"], g["grad_norms"]):
+        k = str(k)
+        gr = params[k].grad.detach().cpu().numpy()
+        if "grad/" + k in g.files:
+            err = nrm(gr - g["grad/" + k]) / max(ref_norm, 1e-30)
+        else:
+            ref = g["gsample/" + k]
+            err = nrm(gr.ravel()[::1009] - ref) / max(nrm(ref), 1e-30)
+            assert abs(nrm(gr) - ref_norm) <= gtol * ref_norm, (k, nrm(gr), ref_norm)
+        if not err <= gtol:
+            bad[k] = err
+    assert not bad, bad
+
+
+def test_cir_training_with_dropout_and_indexed_input_runs_and_is_reproducible():
+    from src.models.datatypes import OutfitFillInTheBlankTask as FITB
+    n_items = [4, 9, 1]
+    g = np.random.default_rng(3)
+    table = synth.item_embeddings(3, "table", 64)
+    idx = torch.from_numpy(np.concatenate([g.integers(0, 64, n) for n in n_items]).astype(np.int32))
+    cu_items = torch.from_numpy(np.concatenate([[0], np.cumsum(n_items)]).astype(np.int32))
+    txt = cu(synth.unit_rows(3, "t", 3, 512))
+    m = make_model("bf16", dropout=0.3)
+    m.set_embedding_table(torch.from_numpy(table))
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(5)
+        m.zero_grad(set_to_none=True)
+        y = m(task=FITB, item_index=idx, cu_seqlens=cu_items, target_item_text_embedding=txt)
+        y.square().sum().backward()
+        outs.append((y.detach().clone(), m.cir_ffn[0].weight.grad.clone(), m.target_item_image_emb.grad.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    assert m.outfit_token.grad is None and m.cp_ffn[1].weight.grad is None
+    m.eval()
+    with torch.no_grad():
+        y_eval = m(task=FITB, item_index=idx, cu_seqlens=cu_items, target_item_text_embedding=txt)
+    assert not torch.equal(y_eval, outs[0][0])          # dropout was really applied in train mode
