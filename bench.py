@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--precision", default="bf16x3", help="outfit transformer MFMA operand format")
     ap.add_argument("--tower-precision", default="bf16", help="CLIP towers MFMA operand format (bf16|f16)")
     ap.add_argument("--cpu-outfits", type=int, default=8, help="sample size of the CPU baseline (0 = skip)")
+    ap.add_argument("--ln-fold", type=int, default=1, help="1: towers' LayerNorms folded into the GEMM epilogues (product default); 0: materialised (A/B)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
@@ -92,6 +93,7 @@ def main():
     from src.models.configs import ItemEncoderConfig, OutfitXConfig
     from src.models.datatypes import OutfitCompatibilityPredictionTask as CP
     from outfitx_amd import _lib as L
+    L.load().ofx_tune(6, a.ln_fold)
 
     model = OutfitX(OutfitXConfig(item_encoder=ItemEncoderConfig(type="clip")), precision=a.precision,
                     tower_precision=a.tower_precision)

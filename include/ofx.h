@@ -187,7 +187,8 @@ int ofx_focal_loss(const float* logits, const float* labels, int B, float alpha,
 void ofx_profile_enable(int on);
 int ofx_profile_read(double* ms, double* flops, long long* launches);
 
-/* Process-wide tuning knobs (benchmarks only).  knob 0: GEMM rasterisation group (row panels per L2 group, default 8). */
+/* Process-wide tuning knobs (benchmarks / tests only).  knob 0: GEMM rasterisation group (row panels per L2 group, default 8);
+ * knob 6: 1 (default) folds the CLIP towers' LayerNorms into the neighbouring GEMM epilogues, 0 materialises them. */
 int ofx_tune(int knob, int value);
 /* Diagnostics: when buf != NULL the big-tile GEMM writes {shader cycles, 100 MHz ticks} of its main loop per block (16 B each). */
 void ofx_debug_gemm_clock(void* buf);

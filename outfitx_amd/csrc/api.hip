@@ -110,7 +110,9 @@ struct Arena {                                      // library-owned HBM for pac
 
 struct OutfitLayer { void *w_in, *w_out, *w_1, *w_2; float *b_in, *b_out, *b_1, *b_2, *g1, *be1, *g2, *be2;
                      void *w_in_t, *w_out_t, *w_1_t, *w_2_t; };   // transposed operand copies (dgrad), single-product precisions only
-struct ClipLayer { void *w_qkv, *w_o, *w_fc1, *w_fc2; float *b_qkv, *b_o, *b_fc1, *b_fc2, *g1, *be1, *g2, *be2; };
+struct ClipLayer { void *w_qkv, *w_o, *w_fc1, *w_fc2; float *b_qkv, *b_o, *b_fc1, *b_fc2, *g1, *be1, *g2, *be2;
+                   // LayerNorm-folded copies: W . gamma (rounded), column sums of the rounded rows, bias + W beta
+                   void *w_qkv_f, *w_fc1_f; float *cs_qkv, *bf_qkv, *cs_fc1, *bf_fc1; };
 
 }  // namespace
 
@@ -247,9 +249,18 @@ static int pack_clip_layer(Arena& A, ClipLayer& L, const void* const* q, size_t 
     L.b_fc2 = A.take<float>(W); TRY(copy_f32(L.b_fc2, q[13], W, s));
     L.g2 = A.take<float>(W); TRY(copy_f32(L.g2, q[14], W, s));
     L.be2 = A.take<float>(W); TRY(copy_f32(L.be2, q[15], W, s));
+    // folded copies (q, k, v order as above: HF stores k, v, q, out in q[0..7])
+    char* wf = A.take<char>(2 * 3 * W * W);
+    L.w_qkv_f = wf; L.cs_qkv = A.take<float>(3 * W); L.bf_qkv = A.take<float>(3 * W);
+    const int Wi = (int)W;
+    TRY(ofx_launch_fold_pack((const float*)q[4], L.g1, L.be1, (const float*)q[5], wf, L.cs_qkv, L.bf_qkv, Wi, Wi, dt, s));
+    TRY(ofx_launch_fold_pack((const float*)q[0], L.g1, L.be1, (const float*)q[1], wf + 2 * W * W, L.cs_qkv + W, L.bf_qkv + W, Wi, Wi, dt, s));
+    TRY(ofx_launch_fold_pack((const float*)q[2], L.g1, L.be1, (const float*)q[3], wf + 4 * W * W, L.cs_qkv + 2 * W, L.bf_qkv + 2 * W, Wi, Wi, dt, s));
+    L.w_fc1_f = A.take<char>(2 * MLP * W); L.cs_fc1 = A.take<float>(MLP); L.bf_fc1 = A.take<float>(MLP);
+    TRY(ofx_launch_fold_pack((const float*)q[10], L.g2, L.be2, (const float*)q[11], L.w_fc1_f, L.cs_fc1, L.bf_fc1, (int)MLP, Wi, dt, s));
     return OFX_OK;
 }
-static size_t clip_layer_bytes(size_t W, size_t MLP) { return 2 * (4 * W * W + 2 * W * MLP) + 4 * (9 * W + MLP) + 16 * 256; }
+static size_t clip_layer_bytes(size_t W, size_t MLP) { return 2 * (4 * W * W + 2 * W * MLP) + 4 * (9 * W + MLP) + 2 * (3 * W * W + W * MLP) + 4 * (6 * W + 2 * MLP) + 32 * 256; }
 
 extern "C" int ofx_pack_vision_weights(ofx_handle* h, const void* const* P, int n, ofx_stream stream) {
     OFX_REQUIRE(h, OFX_EINVAL, "pack_vision: NULL handle");
@@ -325,7 +336,8 @@ size_t carve_set(const ofx_handle* h, Bump& b, int B, int L, SetWs* w) {
     if (w) *w = t;
     return b.off;
 }
-struct ClipWs { float* X; char* H; char* QKV; char* U; int* idx; char* PL; float* E; float* XP; char* HP; char* UP; char* slab; size_t slab_bytes; };
+struct ClipWs { float* X; char* H; char* QKV; char* U; int* idx; char* PL; float* E; float* XP; char* HP; char* UP; char* slab; size_t slab_bytes;
+                char* XB; float* P; float* S; };   // LayerNorm folding: raw operand copy of X, per-segment partial stats, (mean, rstd)
 size_t carve_clip(Bump& b, size_t rows, size_t n, size_t W, size_t MLP, size_t PD, size_t u_min_bytes, size_t qkv_min_bytes, ClipWs* w) {
     ClipWs t;
     t.X = b.take<float>(rows * W);
@@ -341,6 +353,9 @@ size_t carve_clip(Bump& b, size_t rows, size_t n, size_t W, size_t MLP, size_t P
     t.slab_bytes = std::max(std::max(ofx_gemm_splitk_bytes((int)n, (int)W, (int)W), ofx_gemm_splitk_bytes((int)n, (int)MLP, (int)W)),
                             std::max(ofx_gemm_splitk_bytes((int)n, (int)W, (int)MLP), ofx_gemm_splitk_bytes((int)n, (int)PD, (int)W)));
     t.slab = b.take<char>(t.slab_bytes);
+    t.XB = b.take<char>(rows * W * 2);
+    t.P = b.take<float>(rows * (W / 64) * 2);
+    t.S = b.take<float>(rows * 2);
     if (w) *w = t;
     return b.off;
 }
@@ -478,12 +493,21 @@ extern "C" int ofx_cir_prefix(ofx_handle* h, const float* txt, int B, float* out
 // ------------------------------------------------------------------------------------ CLIP towers
 // One CLIP encoder layer on `rows` rows.  When `pool_idx` is given (last layer) everything after the attention
 // runs only on the n pooled rows (CLS / EOS): they are the only ones the tower's output depends on.
+int g_ln_fold = 1;      // ofx_tune(6, v): 0 = materialise every LayerNorm, 1 = fold the towers' LayerNorms into the GEMM epilogues
+
+// fold == true: on entry w.XB / w.S hold the operand copy and the (mean, rstd) of X; on exit (non-pooled layers) they hold
+// those of the layer's output, produced by the fc2 epilogue.  No LayerNorm kernel runs on the full rows.
 static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, int S, int W, int MLP, int heads, int act,
-                      float eps, int causal, const int64_t* key_mask, int mask_ld, int dt, const int* pool_idx, hipStream_t s) {
-    LnArgs ln{w.X, nullptr, L.g1, L.be1, w.H, rows, W, W, OFX_OUT_OP, eps};
-    TRY(ofx_launch_layernorm(ln, dt, s));
-    GemmArgs g1{}; g1.A = w.H; g1.W = L.w_qkv; g1.C = w.QKV; g1.bias = L.b_qkv; g1.M = rows; g1.N = 3 * W; g1.K = W; g1.lda = W;
+                      float eps, int causal, const int64_t* key_mask, int mask_ld, int dt, const int* pool_idx, hipStream_t s, bool fold = false) {
+    GemmArgs g1{}; g1.C = w.QKV; g1.M = rows; g1.N = 3 * W; g1.K = W; g1.lda = W;
     g1.ldc = 3 * W; g1.act = OFX_ACT_NONE; g1.out_kind = OFX_OUT_OP;
+    if (fold) {
+        g1.A = w.XB; g1.W = L.w_qkv_f; g1.bias = L.bf_qkv; g1.row_stat = w.S; g1.col_sum = L.cs_qkv;
+    } else {
+        LnArgs ln{w.X, nullptr, L.g1, L.be1, w.H, rows, W, W, OFX_OUT_OP, eps};
+        TRY(ofx_launch_layernorm(ln, dt, s));
+        g1.A = w.H; g1.W = L.w_qkv; g1.bias = L.b_qkv;
+    }
     TRY(ofx_launch_gemm(g1, dt, s));
     AttnArgs at{w.QKV, w.H, key_mask, nseq, S, heads, 3 * W, W, W, 2 * W, mask_ld, causal, 0.125f};
     TRY(ofx_launch_attention_mfma(at, dt, s));
@@ -496,26 +520,39 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
     GemmArgs g2{}; g2.A = H; g2.W = L.w_o; g2.C = X; g2.bias = L.b_o; g2.resid = X; g2.M = M; g2.N = W; g2.K = W; g2.lda = W;
     g2.ldc = W; g2.ldr = W; g2.act = OFX_ACT_NONE; g2.out_kind = OFX_OUT_F32;
     if (pool_idx) { g2.slab = w.slab; g2.slab_bytes = w.slab_bytes; }
+    const bool fold2 = fold && !pool_idx;          // the pruned last layer runs its tail on the pooled rows, unfolded
+    if (fold2) { g2.xb_out = w.XB; g2.stat_part = w.P; }
     TRY(ofx_launch_gemm(g2, dt, s));
-    LnArgs ln2{X, nullptr, L.g2, L.be2, H, M, W, W, OFX_OUT_OP, eps};
-    TRY(ofx_launch_layernorm(ln2, dt, s));
-    GemmArgs g3{}; g3.A = H; g3.W = L.w_fc1; g3.C = U; g3.bias = L.b_fc1; g3.M = M; g3.N = MLP; g3.K = W; g3.lda = W;
+    GemmArgs g3{}; g3.C = U; g3.M = M; g3.N = MLP; g3.K = W; g3.lda = W;
     g3.ldc = MLP; g3.act = act; g3.out_kind = OFX_OUT_OP;
+    if (fold2) {
+        TRY(ofx_launch_stats_finalize(w.P, W / 64, W, eps, w.S, M, s));
+        g3.A = w.XB; g3.W = L.w_fc1_f; g3.bias = L.bf_fc1; g3.row_stat = w.S; g3.col_sum = L.cs_fc1;
+    } else {
+        LnArgs ln2{X, nullptr, L.g2, L.be2, H, M, W, W, OFX_OUT_OP, eps};
+        TRY(ofx_launch_layernorm(ln2, dt, s));
+        g3.A = H; g3.W = L.w_fc1; g3.bias = L.b_fc1;
+    }
     if (pool_idx) { g3.slab = w.slab; g3.slab_bytes = w.slab_bytes; }
     TRY(ofx_launch_gemm(g3, dt, s));
     GemmArgs g4{}; g4.A = U; g4.W = L.w_fc2; g4.C = X; g4.bias = L.b_fc2; g4.resid = X; g4.M = M; g4.N = W; g4.K = MLP;
     g4.lda = MLP; g4.ldc = W; g4.ldr = W; g4.act = OFX_ACT_NONE; g4.out_kind = OFX_OUT_F32;
     if (pool_idx) { g4.slab = w.slab; g4.slab_bytes = w.slab_bytes; }
-    return ofx_launch_gemm(g4, dt, s);
+    if (fold2) { g4.xb_out = w.XB; g4.stat_part = w.P; }
+    TRY(ofx_launch_gemm(g4, dt, s));
+    if (fold2) TRY(ofx_launch_stats_finalize(w.P, W / 64, W, eps, w.S, M, s));
+    return OFX_OK;
 }
 
 // All layers; the pooled rows end up compacted in w.XP [nseq, W].
 static int clip_layers(const std::vector<ClipLayer>& Ls, const ClipWs& w, int rows, int nseq, int S, int W, int MLP,
                        int heads, int act, float eps, int causal, const int64_t* key_mask, int mask_ld, int dt,
                        const int* pool_idx, hipStream_t s) {
+    const bool fold = g_ln_fold != 0 && W % 64 == 0;
+    if (fold) TRY(ofx_launch_row_stats_cast(w.X, w.XB, w.S, rows, W, eps, dt, s));     // layer 0's LayerNorm-1 inputs
     for (size_t l = 0; l < Ls.size(); ++l)
         TRY(clip_layer(Ls[l], w, rows, nseq, S, W, MLP, heads, act, eps, causal, key_mask, mask_ld, dt,
-                       l + 1 == Ls.size() ? pool_idx : nullptr, s));
+                       l + 1 == Ls.size() ? pool_idx : nullptr, s, fold));
     return OFX_OK;
 }
 
@@ -875,6 +912,7 @@ extern "C" int ofx_tune(int knob, int value) {
         case 3: g_gemm_skew = value; return OFX_OK;
         case 4: g_gemm_pref = value; return OFX_OK;
         case 5: g_gemm_splitk = value; return OFX_OK;
+        case 6: g_ln_fold = value; return OFX_OK;
         default: ofx_set_error("ofx_tune: unknown knob %d", knob); return OFX_EINVAL;
     }
 }

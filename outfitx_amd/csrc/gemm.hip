@@ -43,6 +43,7 @@ struct KArgs {
     int splits, kt_per_split;   // 128x128 kernel only: blockIdx.y owns k-tiles [y*kt_per_split, ...) and writes a raw fp32 slab
     float* slab;                // [splits, M, N] partial sums when splits > 1
     DropArgs drop;
+    char* xb_out; float* stat_part; const float* row_stat; const float* col_sum;   // LayerNorm folding (GemmArgs)
 };
 
 __device__ __forceinline__ void glds16(const char* g, OFX_LDS char* l) {
@@ -64,7 +65,10 @@ __device__ __forceinline__ void epilogue(const KArgs& p, OFX_LDS float* ep, int 
         const int gm = gm0 + row;
         f32x4 v = *(OFX_LDS f32x4*)(ep + row * EPI_STRIDE + col);
         if (gm < p.M) {
-            v += bias4;
+            if (p.row_stat) {
+                const float mu = p.row_stat[2 * (size_t)gm], rs = p.row_stat[2 * (size_t)gm + 1];
+                v = (v - *(const f32x4*)(p.col_sum + gn) * mu) * rs + bias4;
+            } else v += bias4;
             if (p.aux_out) *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn) = v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -85,6 +89,17 @@ __device__ __forceinline__ void epilogue(const KArgs& p, OFX_LDS float* ep, int 
             }
             if (p.out_kind == 0) {
                 *(f32x4*)(p.C + ((size_t)gm * p.ldc + gn) * 4) = v;
+                if (p.xb_out) {
+                    v4 hb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hb[e] = (T)v[e];
+                    *(v4*)((T*)p.xb_out + (size_t)gm * p.N + gn) = hb;
+                }
+                if (p.stat_part) {          // gm is uniform over the 16 lanes that share this row
+                    const float ssum = row16_sum_to_lane15((v[0] + v[1]) + (v[2] + v[3]));
+                    const float ssq = row16_sum_to_lane15((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+                    if ((lane & 15) == 15) *(f32x2*)(p.stat_part + ((size_t)gm * (p.N >> 6) + (gn0 >> 6)) * 2) = f32x2{ssum, ssq};
+                }
             } else {
                 v4 hi;
 #pragma unroll
@@ -257,7 +272,9 @@ __device__ __forceinline__ float act_apply(float v) {
     return v;
 }
 
-template <typename T, int ACT>
+// FOLD (LayerNorm folding, compile-time so the common path keeps its registers): 0 none, 1 producer (fp32 output + operand copy
+// + per-segment statistics), 2 consumer (row statistics + column sums applied to the accumulator).
+template <typename T, int ACT, int FOLD = 0>
 __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x4 (&acc)[8][4], int gm0, int gn0, int lane) {
     typedef typename OpT<T>::v8 v8;
     const int fr = lane & 15, fq = lane >> 4;
@@ -290,11 +307,14 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
                 const int gm = gm0 + i * 16 + row;
                 f32x4 v = *(OFX_LDS f32x4*)(ep + row * 256 + ((chunk ^ (row & 7)) << 4));
                 if (gm < p.M) {
-                    v += bias4;
-                    if (p.aux_out) *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn) = v;
+                    if (FOLD == 2) {
+                        const float mu = p.row_stat[2 * (size_t)gm], rs = p.row_stat[2 * (size_t)gm + 1];
+                        v = (v - *(const f32x4*)(p.col_sum + gn) * mu) * rs + bias4;
+                    } else v += bias4;
+                    if (FOLD == 0 && p.aux_out) *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn) = v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = act_apply<T, ACT>(v[e]);
-                    if (p.drop.thresh) {
+                    if (FOLD == 0 && p.drop.thresh) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] *= drop_mul(p.drop, gm, gn + e);
                     }
@@ -303,6 +323,17 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
                         for (int e = 0; e < 4; ++e) v[e] *= act_mish_grad(res[i % (DEPTH + 1)][it][e]);
                     } else v += res[i % (DEPTH + 1)][it];
                     *(f32x4*)(p.C + ((size_t)gm * p.ldc + gn) * 4) = v;
+                    if (FOLD == 1 && p.xb_out) {
+                        typename OpT<T>::v4 hb;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hb[e] = (T)v[e];
+                        *(typename OpT<T>::v4*)((T*)p.xb_out + (size_t)gm * p.N + gn) = hb;
+                    }
+                    if (FOLD == 1 && p.stat_part) {      // gm is uniform over the 16 lanes (same rsub) that share this row
+                        const float ssum = row16_sum_to_lane15((v[0] + v[1]) + (v[2] + v[3]));
+                        const float ssq = row16_sum_to_lane15((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+                        if (chunk == 15) *(f32x2*)(p.stat_part + ((size_t)gm * (p.N >> 6) + (gn0 >> 6)) * 2) = f32x2{ssum, ssq};
+                    }
                 }
             }
         }
@@ -311,6 +342,8 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
         const int gn = gn0 + c8 * 8;
         f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
         if (p.bias) { b0 = *(const f32x4*)(p.bias + gn); b1 = *(const f32x4*)(p.bias + gn + 4); }
+        f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = cs0;
+        if (FOLD == 2) { cs0 = *(const f32x4*)(p.col_sum + gn); cs1 = *(const f32x4*)(p.col_sum + gn + 4); }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -322,11 +355,14 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
                 f32x4 v0 = *(OFX_LDS f32x4*)(ep + row * 256 + (((2 * c8) ^ (row & 7)) << 4));
                 f32x4 v1 = *(OFX_LDS f32x4*)(ep + row * 256 + (((2 * c8 + 1) ^ (row & 7)) << 4));
                 if (gm < p.M) {
-                    v0 += b0; v1 += b1;
-                    if (p.aux_out) { *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn) = v0; *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn + 4) = v1; }
+                    if (FOLD == 2) {
+                        const float mu = p.row_stat[2 * (size_t)gm], rs = p.row_stat[2 * (size_t)gm + 1];
+                        v0 = (v0 - cs0 * mu) * rs + b0; v1 = (v1 - cs1 * mu) * rs + b1;
+                    } else { v0 += b0; v1 += b1; }
+                    if (FOLD == 0 && p.aux_out) { *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn) = v0; *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn + 4) = v1; }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v0[e] = act_apply<T, ACT>(v0[e]); v1[e] = act_apply<T, ACT>(v1[e]); }
-                    if (p.drop.thresh) {
+                    if (FOLD == 0 && p.drop.thresh) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v0[e] *= drop_mul(p.drop, gm, gn + e); v1[e] *= drop_mul(p.drop, gm, gn + 4 + e); }
                     }
@@ -352,6 +388,26 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
                 }
             }
         }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void epilogue2_dispatch(const KArgs& p, OFX_LDS char* ep, f32x4 (&acc)[8][4], int gm0, int gn0, int lane) {
+    if (p.row_stat) {                                  // LayerNorm-fold consumer: towers only (no residual, no dropout, no tape)
+        switch (p.act) {
+            case OFX_ACT_QUICK_GELU: epilogue2<T, OFX_ACT_QUICK_GELU, 2>(p, ep, acc, gm0, gn0, lane); break;
+            case OFX_ACT_GELU: epilogue2<T, OFX_ACT_GELU, 2>(p, ep, acc, gm0, gn0, lane); break;
+            default: epilogue2<T, OFX_ACT_NONE, 2>(p, ep, acc, gm0, gn0, lane); break;
+        }
+        return;
+    }
+    if (p.xb_out || p.stat_part) { epilogue2<T, OFX_ACT_NONE, 1>(p, ep, acc, gm0, gn0, lane); return; }
+    switch (p.act) {
+        case OFX_ACT_QUICK_GELU: epilogue2<T, OFX_ACT_QUICK_GELU>(p, ep, acc, gm0, gn0, lane); break;
+        case OFX_ACT_GELU: epilogue2<T, OFX_ACT_GELU>(p, ep, acc, gm0, gn0, lane); break;
+        case OFX_ACT_MISH: epilogue2<T, OFX_ACT_MISH>(p, ep, acc, gm0, gn0, lane); break;
+        case OFX_ACT_MISH_GRAD: epilogue2<T, OFX_ACT_MISH_GRAD>(p, ep, acc, gm0, gn0, lane); break;
+        default: epilogue2<T, OFX_ACT_NONE>(p, ep, acc, gm0, gn0, lane); break;
     }
 }
 
@@ -544,13 +600,7 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_big_kernel(KArgs p) {
 
     OFX_LDS char* ep = lds + NST * STAGE + wave * EPI2_BYTES_PER_WAVE;   // private staging, outside the stages
     const int gm0 = m0 + wr * 128, gn0 = n0 + wc * 64;
-    switch (p.act) {
-        case OFX_ACT_QUICK_GELU: epilogue2<T, OFX_ACT_QUICK_GELU>(p, ep, acc, gm0, gn0, lane); break;
-        case OFX_ACT_GELU: epilogue2<T, OFX_ACT_GELU>(p, ep, acc, gm0, gn0, lane); break;
-        case OFX_ACT_MISH: epilogue2<T, OFX_ACT_MISH>(p, ep, acc, gm0, gn0, lane); break;
-        case OFX_ACT_MISH_GRAD: epilogue2<T, OFX_ACT_MISH_GRAD>(p, ep, acc, gm0, gn0, lane); break;
-        default: epilogue2<T, OFX_ACT_NONE>(p, ep, acc, gm0, gn0, lane); break;
-    }
+    epilogue2_dispatch<T>(p, ep, acc, gm0, gn0, lane);
     if (p.dbg) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) p.dbg[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memtime() - cloop_end;
@@ -698,13 +748,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(KArgs p) {
 
     OFX_LDS char* ep = lds + 2 * STAGE + wave * EPI2_BYTES_PER_WAVE;
     const int gm0 = m0 + wr * 128, gn0 = n0 + wc * 64;
-    switch (p.act) {
-        case OFX_ACT_QUICK_GELU: epilogue2<T, OFX_ACT_QUICK_GELU>(p, ep, acc, gm0, gn0, lane); break;
-        case OFX_ACT_GELU: epilogue2<T, OFX_ACT_GELU>(p, ep, acc, gm0, gn0, lane); break;
-        case OFX_ACT_MISH: epilogue2<T, OFX_ACT_MISH>(p, ep, acc, gm0, gn0, lane); break;
-        case OFX_ACT_MISH_GRAD: epilogue2<T, OFX_ACT_MISH_GRAD>(p, ep, acc, gm0, gn0, lane); break;
-        default: epilogue2<T, OFX_ACT_NONE>(p, ep, acc, gm0, gn0, lane); break;
-    }
+    epilogue2_dispatch<T>(p, ep, acc, gm0, gn0, lane);
 }
 
 
@@ -994,6 +1038,13 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
     KArgs k;
     k.A = (const char*)g.A; k.W = (const char*)g.W; k.C = (char*)g.C; k.bias = g.bias; k.resid = g.resid; k.aux_out = g.aux_out; k.m_dev = g.m_dev; k.dbg = g_gemm_dbg; k.skew = g_gemm_skew; k.splits = 1; k.slab = nullptr; k.m_slab = g.M; k.kt_per_split = 0;
     k.M = g.M; k.N = g.N; k.K = g.K; k.lda = g.lda; k.ldc = g.ldc; k.ldr = g.ldr; k.act = g.act; k.out_kind = g.out_kind; k.drop = g.drop;
+    k.xb_out = (char*)g.xb_out; k.stat_part = g.stat_part; k.row_stat = g.row_stat; k.col_sum = g.col_sum;
+    OFX_REQUIRE(!(g.xb_out || g.stat_part) || (g.out_kind == 0 && g.N % 64 == 0), OFX_EINVAL, "gemm: LayerNorm-fold producer outputs need an fp32 output");
+    OFX_REQUIRE(!g.row_stat || g.col_sum, OFX_EINVAL, "gemm: row_stat needs col_sum");
+    OFX_REQUIRE(!(g.row_stat || g.xb_out || g.stat_part) || (!g.aux_out && !g.drop.thresh && g.act != OFX_ACT_MISH && g.act != OFX_ACT_MISH_GRAD), OFX_EINVAL,
+                "gemm: LayerNorm folding does not combine with the training epilogue features");
+    OFX_REQUIRE(!g.row_stat || !g.resid, OFX_EINVAL, "gemm: a LayerNorm-fold consumer takes no residual");
+    OFX_REQUIRE(!(g.xb_out || g.stat_part) || g.act == OFX_ACT_NONE, OFX_EINVAL, "gemm: a LayerNorm-fold producer has no activation");
     static bool attr_set = false;
     if (!attr_set) {
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<bf16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
@@ -1031,7 +1082,7 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
         int gm = g_gemm_group_m;
         if (gm <= 0) { gm = (int)((3u << 20) / ((size_t)BM * g.K * 2) / 2); gm = gm < 1 ? 1 : (gm > 8 ? 8 : gm); }
         k.group_m = gm;
-        const int splits = g.slab ? ofx_gemm_splitk_plan(g.M, g.N, g.K) : 1;
+        const int splits = (g.slab && !g.xb_out && !g.stat_part && !g.row_stat) ? ofx_gemm_splitk_plan(g.M, g.N, g.K) : 1;
         k.splits = splits; k.slab = (float*)g.slab; k.m_slab = g.M;
         k.kt_per_split = splits > 1 ? (g.K / BK + splits - 1) / splits : 0;
         if (splits > 1) OFX_REQUIRE(g.slab_bytes >= (size_t)splits * g.M * g.N * 4, OFX_EWORKSPACE, "gemm: split-K slab too small");

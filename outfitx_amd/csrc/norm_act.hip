@@ -336,6 +336,60 @@ __global__ __launch_bounds__(256) void cir_prefix_kernel(const float* img_emb, c
         }
 }
 
+// ---- LayerNorm folding support (GemmArgs::row_stat / col_sum) ---------------------------------------------------------
+// First layer of a tower: operand-type copy of the raw rows + their (mean, rstd).  One wave per row.
+template <typename T>
+__global__ __launch_bounds__(256) void row_stats_cast_kernel(const float* X, T* Xb, float* stat, int rows, int W, float eps) {
+    typedef typename OpT<T>::v4 v4;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int r = blockIdx.x * 4 + w; r < rows; r += gridDim.x * 4) {
+        const float* xr = X + (size_t)r * W;
+        float s = 0.f;
+        for (int c = lane * 4; c < W; c += 256) { const f32x4 v = *(const f32x4*)(xr + c); s += (v[0] + v[1]) + (v[2] + v[3]); }
+        const float mu = wave_sum(s) / W;
+        float q = 0.f;
+        for (int c = lane * 4; c < W; c += 256) {
+            const f32x4 v = *(const f32x4*)(xr + c);
+            v4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[e] - mu; q += d * d; o[e] = (T)v[e]; }
+            *(v4*)(Xb + (size_t)r * W + c) = o;
+        }
+        q = wave_sum(q);
+        if (lane == 0) { stat[2 * (size_t)r] = mu; stat[2 * (size_t)r + 1] = rsqrtf(q / W + eps); }
+    }
+}
+// (sum, sum of squares) per 64-column segment -> (mean, rstd) per row
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const float* part, int slots, int W, float eps, float* stat, int rows) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float* p = part + (size_t)r * slots * 2;
+    float s = 0.f, q = 0.f;
+    for (int k = 0; k < slots; ++k) { s += p[2 * k]; q += p[2 * k + 1]; }
+    const float mu = s / W;
+    const float var = fmaxf(q / W - mu * mu, 0.f);
+    stat[2 * (size_t)r] = mu;
+    stat[2 * (size_t)r + 1] = rsqrtf(var + eps);
+}
+// Pack time: W'[n,:] = round(W[n,:] * gamma), col_sum[n] = sum_k W'[n,k] (of the ROUNDED values), bias'[n] = bias[n] + sum_k beta[k] W[n,k].
+template <typename T>
+__global__ __launch_bounds__(256) void fold_pack_kernel(const float* Wsrc, const float* gamma, const float* beta, const float* bias, T* Wf,
+                                                       float* col_sum, float* bias_f, int N, int K) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int n = blockIdx.x * 4 + w; n < N; n += gridDim.x * 4) {
+        float cs = 0.f, bb = 0.f;
+        for (int k = lane; k < K; k += 64) {
+            const float wv = Wsrc[(size_t)n * K + k];
+            const T r = (T)(wv * gamma[k]);
+            Wf[(size_t)n * K + k] = r;
+            cs += (float)r;
+            bb += beta[k] * wv;
+        }
+        cs = wave_sum(cs); bb = wave_sum(bb);
+        if (lane == 0) { col_sum[n] = cs; bias_f[n] = bias[n] + bb; }
+    }
+}
+
 // logits[b] = row0[b] . w + bias    (fp32, exact-order independent of B)
 __global__ __launch_bounds__(256) void cp_head_kernel(const float* row0, const float* w, const float* bias, float* logits, int B, int D) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -417,6 +471,27 @@ int ofx_launch_gather_rows(const void* src, const int* idx, void* dst, int rows,
     OFX_REQUIRE(row_bytes % 16 == 0 && src_ld_bytes % 16 == 0, OFX_ESHAPE, "gather_rows: row bytes must be multiples of 16");
     ProfScope prof(PROF_OTHER, s);
     hipLaunchKernelGGL(gather_rows_kernel, dim3(rows_grid(rows)), dim3(256), 0, s, (const char*)src, idx, (char*)dst, rows, row_bytes, src_ld_bytes);
+    OFX_LAUNCH_CHECK();
+    return OFX_OK;
+}
+int ofx_launch_row_stats_cast(const float* X, void* Xb, float* stat, int rows, int W, float eps, int op_dtype, hipStream_t s) {
+    OFX_REQUIRE(W % 4 == 0 && rows > 0, OFX_ESHAPE, "row_stats_cast: rows=%d W=%d", rows, W);
+    ProfScope prof(PROF_NORM, s);
+    if (op_dtype == OFX_F16) hipLaunchKernelGGL(row_stats_cast_kernel<f16_t>, dim3(rows_grid(rows)), dim3(256), 0, s, X, (f16_t*)Xb, stat, rows, W, eps);
+    else hipLaunchKernelGGL(row_stats_cast_kernel<bf16_t>, dim3(rows_grid(rows)), dim3(256), 0, s, X, (bf16_t*)Xb, stat, rows, W, eps);
+    OFX_LAUNCH_CHECK();
+    return OFX_OK;
+}
+int ofx_launch_stats_finalize(const float* part, int slots, int W, float eps, float* stat, int rows, hipStream_t s) {
+    ProfScope prof(PROF_NORM, s);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, part, slots, W, eps, stat, rows);
+    OFX_LAUNCH_CHECK();
+    return OFX_OK;
+}
+int ofx_launch_fold_pack(const float* Wsrc, const float* gamma, const float* beta, const float* bias, void* Wf, float* col_sum, float* bias_f,
+                         int N, int K, int op_dtype, hipStream_t s) {
+    if (op_dtype == OFX_F16) hipLaunchKernelGGL(fold_pack_kernel<f16_t>, dim3(rows_grid(N)), dim3(256), 0, s, Wsrc, gamma, beta, bias, (f16_t*)Wf, col_sum, bias_f, N, K);
+    else hipLaunchKernelGGL(fold_pack_kernel<bf16_t>, dim3(rows_grid(N)), dim3(256), 0, s, Wsrc, gamma, beta, bias, (bf16_t*)Wf, col_sum, bias_f, N, K);
     OFX_LAUNCH_CHECK();
     return OFX_OK;
 }

@@ -13,6 +13,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -94,6 +95,14 @@ __device__ __forceinline__ float apply_act(float u, int act) {
     }
 }
 
+// sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15); the total is valid in lane 15 of the row
+__device__ __forceinline__ float row16_sum_to_lane15(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));   // row_shr:1
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));   // row_shr:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));   // row_shr:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));   // row_shr:8
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -170,6 +179,14 @@ struct GemmArgs {
     int act;            // ofx_act
     int out_kind;       // 0 fp32 | 1 operand type | 2 split3 (hi|lo|hi at column blocks of width N, ldc >= 3N; bf16 only)
     DropArgs drop;      // applied to act(acc + bias) BEFORE the residual add (MISH_GRAD: to acc before the mish' factor)
+    // ---- LayerNorm folding (CLIP towers): the LayerNorm between a residual-stream producer and the next linear layer is
+    // never materialised.  Producer side (fp32 output): also store the operand-type copy of the output row and, per row
+    // and per 64-column segment, (sum, sum of squares) -> stat_part[row][segment] (float2).  Consumer side: A is that raw
+    // copy, W is pre-scaled by gamma, and the epilogue applies  rstd[row] * (acc - mean[row] * col_sum[n]) + bias[n].
+    void* xb_out = nullptr;         // [M, N] operand type
+    float* stat_part = nullptr;     // [M, N / 64, 2]
+    const float* row_stat = nullptr;   // [M, 2] (mean, rstd)
+    const float* col_sum = nullptr;    // [N] column sums of the (rounded) gamma-scaled weight rows
 };
 int ofx_launch_gemm(const GemmArgs& g, int op_dtype /*OFX_BF16|OFX_F16*/, hipStream_t s);
 int ofx_gemm_splitk_plan(int M, int N, int K);
@@ -207,6 +224,10 @@ int ofx_launch_set_build(const float* x, const uint8_t* mask, const float* prefi
 int ofx_launch_gather_rows(const void* src, const int* idx, void* dst, int rows, int row_bytes, int src_ld_bytes, hipStream_t s);
 int ofx_launch_set_build_indexed(const float* table, int ld, long long n_table, const int* idx, const int* cu_items, const float* prefix,
                                  int prefix_stride, int* cu_rows, float* X, int B, int D, hipStream_t s);
+int ofx_launch_row_stats_cast(const float* X, void* Xb, float* stat, int rows, int W, float eps, int op_dtype, hipStream_t s);
+int ofx_launch_stats_finalize(const float* part, int slots, int W, float eps, float* stat, int rows, hipStream_t s);
+int ofx_launch_fold_pack(const float* Wsrc, const float* gamma, const float* beta, const float* bias, void* Wf, float* col_sum, float* bias_f,
+                         int N, int K, int op_dtype, hipStream_t s);
 int ofx_launch_gather_row0(const float* X, const int* cu, float* out, int B, int D, hipStream_t s);
 int ofx_launch_cir_prefix(const float* img_emb, const float* txt, float* out, int B, int D, hipStream_t s);
 int ofx_launch_cp_head(const float* row0, const float* w, const float* bias, float* logits, int B, int D, hipStream_t s);

@@ -352,3 +352,26 @@ def test_item_encoder_takes_pil_images_through_the_gpu_preprocessor(model):
         px = clip_preprocess([r[0] for r in ims]).view(3, 1, 3, 224, 224).cuda()
         b = enc(px)
     assert torch.equal(a, b)
+
+
+def test_layernorm_folding_matches_the_materialised_path(model):
+    """Towers with their LayerNorms folded into the GEMM epilogues (default) vs every LayerNorm materialised (ofx_tune(6, 0)):
+    same embeddings within the operand-rounding floor, on a batch large enough for every tile kernel and on a tiny one."""
+    from outfitx_amd import _lib as L
+    lib = L.load()
+    enc = model.item_encoder
+    for n_img in (3, 300):
+        px = torch.from_numpy(synth.pixel_values(77, n_img)).view(n_img, 1, 3, 224, 224).cuda()
+        ids, att = synth.token_batch(77, n_img, 64, synth.ragged_lengths(77, n_img, 2, 40))
+        tok = {"input_ids": torch.from_numpy(ids).view(n_img, 1, 64), "attention_mask": torch.from_numpy(att).view(n_img, 1, 64)}
+        outs = []
+        for fold in (1, 0):
+            lib.ofx_tune(6, fold)
+            try:
+                with torch.no_grad():
+                    outs.append((enc.image_enc(px).cpu().numpy(), enc.text_enc(tok).cpu().numpy()))
+            finally:
+                lib.ofx_tune(6, 1)
+        for a, b in zip(*outs):
+            assert not np.array_equal(a, b)                  # the two paths really differ in rounding
+            assert rel_err(a, b) < 2e-2
