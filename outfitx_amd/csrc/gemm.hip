@@ -1035,6 +1035,9 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
     OFX_REQUIRE(((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.W % 16 == 0) && ((uintptr_t)g.C % 16 == 0), OFX_EINVAL,
                 "gemm: operands must be 16-byte aligned");
     OFX_REQUIRE(op_dtype == OFX_BF16 || op_dtype == OFX_F16, OFX_EINVAL, "gemm: operand dtype must be bf16 or f16");
+#ifndef OFX_DIAG
+    OFX_REQUIRE(g_gemm_ablate == 0, OFX_ESTATE, "gemm: the ablation kernels are only built with `make DIAG=1`");
+#endif
     KArgs k;
     k.A = (const char*)g.A; k.W = (const char*)g.W; k.C = (char*)g.C; k.bias = g.bias; k.resid = g.resid; k.aux_out = g.aux_out; k.m_dev = g.m_dev; k.dbg = g_gemm_dbg; k.skew = g_gemm_skew; k.splits = 1; k.slab = nullptr; k.m_slab = g.M; k.kt_per_split = 0;
     k.M = g.M; k.N = g.N; k.K = g.K; k.lda = g.lda; k.ldc = g.ldc; k.ldr = g.ldr; k.act = g.act; k.out_kind = g.out_kind; k.drop = g.drop;
@@ -1049,9 +1052,11 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
     if (!attr_set) {
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<bf16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<f16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+#ifdef OFX_DIAG
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<bf16_t, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+#endif
         attr_set = true;
     }
     // big tiles when they still fill the chip, else the 128^2 kernel
@@ -1068,11 +1073,13 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
         k.group_m = g_gemm_group_m > 0 ? g_gemm_group_m : (kind == 3 ? 4 : 8);
         int rc;
         if (kind == 4) rc = op_dtype == OFX_F16 ? launch_pp<f16_t>(k, g.M, g.N, s) : launch_pp<bf16_t>(k, g.M, g.N, s);
+#ifdef OFX_DIAG      // ablation variants (wrong results, timing diagnostics): `make DIAG=1`; they double the build time of this file
         else if (kind == 2 && g_gemm_ablate == 1) rc = launch_big<bf16_t, 2, 4, 2, 1>(k, g.M, g.N, s);
         else if (kind == 2 && g_gemm_ablate == 2) rc = launch_big<bf16_t, 2, 4, 2, 2>(k, g.M, g.N, s);
         else if (kind == 2 && g_gemm_ablate == 3) rc = launch_big<bf16_t, 2, 4, 2, 3>(k, g.M, g.N, s);
         else if (kind == 2 && g_gemm_ablate == 4) rc = launch_big<bf16_t, 2, 4, 2, 4>(k, g.M, g.N, s);
         else if (kind == 2 && g_gemm_ablate == 5) rc = launch_big<bf16_t, 2, 4, 2, 5>(k, g.M, g.N, s);
+#endif
         else if (kind == 2) rc = op_dtype == OFX_F16 ? launch_big<f16_t, 2, 4, 2>(k, g.M, g.N, s) : launch_big<bf16_t, 2, 4, 2>(k, g.M, g.N, s);
         else rc = op_dtype == OFX_F16 ? launch_big<f16_t, 2, 2, 1>(k, g.M, g.N, s) : launch_big<bf16_t, 2, 2, 1>(k, g.M, g.N, s);
         if (rc != OFX_OK) return rc;
@@ -1088,9 +1095,11 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
         if (splits > 1) OFX_REQUIRE(g.slab_bytes >= (size_t)splits * g.M * g.N * 4, OFX_EWORKSPACE, "gemm: split-K slab too small");
         const dim3 grid(k.nwg, splits > 1 ? splits : 1);
         if (op_dtype == OFX_F16) hipLaunchKernelGGL((gemm_128x128_kernel<f16_t, 0>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
+#ifdef OFX_DIAG
         else if (g_gemm_ablate == 1) hipLaunchKernelGGL((gemm_128x128_kernel<bf16_t, 1>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
         else if (g_gemm_ablate == 2) hipLaunchKernelGGL((gemm_128x128_kernel<bf16_t, 2>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
         else if (g_gemm_ablate == 3) hipLaunchKernelGGL((gemm_128x128_kernel<bf16_t, 3>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
+#endif
         else hipLaunchKernelGGL((gemm_128x128_kernel<bf16_t, 0>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
         if (splits > 1) {
             size_t tot = (size_t)g.M * (g.N / 4);
