@@ -72,10 +72,11 @@ size_t ofx_colsum_part_floats(int C);
 int ofx_launch_colsum(const void* x, int x_kind, int ld, const int* gather, const float* row_scale, float* out0, float* out1, float* out2, int seg,
                       float* part, int C, const int* m_dev, int M, int op_dtype, hipStream_t s);
 size_t ofx_ln_bwd_part_floats(int D);
-int ofx_launch_ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* add, float* dx_out, void* dx_op,
+int ofx_launch_row_map(const int* cu, int* map, int B, int M, hipStream_t s);
+int ofx_launch_ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* add, const int* add_map, float* dx_out, void* dx_op,
                       float* dgamma, float* dbeta, float* dcols, float* part, int D, const int* m_dev, int M, int op_dtype, const DropArgs& drop, hipStream_t s);
 int ofx_launch_set_attention_bwd(const float* qkv, const float* d_o, void* dqkv, const int* cu, int nseq, int n_head, int D, int max_len,
-                                 float scale, int op_dtype, const DropArgs& drop, hipStream_t s);
+                                 float scale, int op_dtype, const DropArgs& drop, int only_row0, hipStream_t s);
 int ofx_launch_drop_rows(float* x, int rows, int cols, const DropArgs& d, hipStream_t s);
 int ofx_launch_focal_loss(const float* logits, const float* labels, int B, float alpha, float gamma, float upstream, float* loss, float* dlogits, hipStream_t s);
 int ofx_launch_cp_head_bwd(const float* dlogits, const float* w_or_rows, const int* cu, float* dX, void* dXb, float* db, int B, int D, int op_dtype,
@@ -641,7 +642,7 @@ static bool d_outfit_act_is_mish(const ofx_handle* h) { return h->d.outfit_act =
 // (bf16 / f16, like the reference's AMP training); dropout is NOT applied (the caller must use dropout = 0).
 namespace {
 struct TapeLayer { float* Xin; float* st1; char* H1; float* QKV; char* O; float* Xmid; float* st2; char* H2; float* Upre; char* A; };
-struct Tape { int* cu; float* Xfinal; float* row0; float* prefix; char* row0b; std::vector<TapeLayer> L; size_t bytes; };
+struct Tape { int* cu; float* Xfinal; float* row0; float* prefix; char* row0b; char* pO; float* pX; std::vector<TapeLayer> L; size_t bytes; };
 size_t carve_tape(const ofx_handle* h, Bump& b, int B, int Lq, Tape* t) {
     const size_t M = (size_t)B * (Lq + 1), D = h->d.d_model, Fp = h->ot_ffn_pad, Mp = align_up(M, 64);   // operand copies: rows readable up to Mp (TN GEMM)
     Tape tp;
@@ -649,6 +650,8 @@ size_t carve_tape(const ofx_handle* h, Bump& b, int B, int Lq, Tape* t) {
     tp.row0 = b.take<float>((size_t)B * D);
     tp.prefix = b.take<float>((size_t)B * D);                              // CIR: per-outfit prefix [img_emb | target text]
     tp.row0b = b.take<char>(align_up((size_t)B, 64) * D * 2);             // CIR: operand copy of row0 (dW of cir_ffn)
+    tp.pO = b.take<char>(align_up((size_t)B, 64) * D * 2);                // last layer: attention output of the prefix rows
+    tp.pX = b.take<float>((size_t)B * D);                                 // last layer: layer input at the prefix rows (residual)
     tp.L.resize(h->d.n_layers);
     for (TapeLayer& l : tp.L) {
         l.Xin = b.take<float>(M * D); l.st1 = b.take<float>(M * 2); l.H1 = b.take<char>(Mp * D * 2); l.QKV = b.take<float>(M * 3 * D);
@@ -660,7 +663,7 @@ size_t carve_tape(const ofx_handle* h, Bump& b, int B, int Lq, Tape* t) {
     if (t) *t = tp;
     return tp.bytes;
 }
-struct BwdWs { float *dXa, *dXb_f, *dH, *dO, *part, *d_row0; char *gXb, *dU, *gQb, *dyb; char* slab; size_t slab_bytes; };
+struct BwdWs { float *dXa, *dXb_f, *dH, *dO, *part, *d_row0; char *gXb, *dU, *gQb, *dyb; int* rowmap; char* slab; size_t slab_bytes; };
 size_t carve_bwd(const ofx_handle* h, Bump& b, int B, int Lq, BwdWs* w) {
     const size_t M = (size_t)B * (Lq + 1), D = h->d.d_model, Fp = h->ot_ffn_pad, Mp = align_up(M, 64);
     BwdWs t;
@@ -668,9 +671,11 @@ size_t carve_bwd(const ofx_handle* h, Bump& b, int B, int Lq, BwdWs* w) {
     t.part = b.take<float>(std::max(ofx_ln_bwd_part_floats((int)D), ofx_colsum_part_floats((int)(3 * D))));
     t.gXb = b.take<char>(Mp * D * 2); t.dU = b.take<char>(Mp * Fp * 2); t.gQb = b.take<char>(Mp * 3 * D * 2);
     t.d_row0 = b.take<float>((size_t)B * D); t.dyb = b.take<char>(align_up((size_t)B, 64) * D * 2);      // CIR head
+    t.rowmap = b.take<int>(M);
     t.slab_bytes = 0;
     const int m = (int)M, Di = (int)D, Fi = (int)Fp;
-    for (auto s : {ofx_gemm_tn_slab_bytes(Di, Di, B), ofx_gemm_splitk_bytes(B, Di, Di),
+    for (auto s : {ofx_gemm_tn_slab_bytes(Di, Di, B), ofx_gemm_splitk_bytes(B, Di, Di), ofx_gemm_tn_slab_bytes(Di, Fi, B), ofx_gemm_tn_slab_bytes(Fi, Di, B),
+                   ofx_gemm_splitk_bytes(B, Fi, Di), ofx_gemm_splitk_bytes(B, Di, Fi),
                    ofx_gemm_tn_slab_bytes(Di, Fi, m), ofx_gemm_tn_slab_bytes(Fi, Di, m), ofx_gemm_tn_slab_bytes(Di, Di, m), ofx_gemm_tn_slab_bytes(3 * Di, Di, m),
                    ofx_gemm_splitk_bytes(m, Fi, Di), ofx_gemm_splitk_bytes(m, Di, Fi), ofx_gemm_splitk_bytes(m, Di, Di), ofx_gemm_splitk_bytes(m, Di, 3 * Di)})
         t.slab_bytes = std::max(t.slab_bytes, s);
@@ -766,9 +771,31 @@ static int cp_train_fwd_core(ofx_handle* h, const SetInput& in, int B, int L, fl
         GemmArgs g1{}; g1.A = t.H1; g1.W = Ly.w_in; g1.C = t.QKV; g1.bias = Ly.b_in; g1.m_dev = m_dev; g1.M = M; g1.N = 3 * D; g1.K = D; g1.lda = D;
         g1.ldc = 3 * D; g1.out_kind = OFX_OUT_F32; g1.slab = w.slab; g1.slab_bytes = w.slab_bytes;
         TRY(ofx_launch_gemm(g1, dt, s));
-        SetAttnArgs sa{t.QKV, t.O, T.cu, B, d.n_head, D, D, OFX_OUT_OP, L + 1, 0, 0.125f};
+        const bool last = l + 1 == d.n_layers;
+        SetAttnArgs sa{t.QKV, t.O, T.cu, B, d.n_head, D, D, OFX_OUT_OP, L + 1, last ? 1 : 0, 0.125f};
         sa.drop = make_drop(dropout_p, seed, 4 * l + 0);
         TRY(ofx_launch_set_attention(sa, dt, s));
+        if (last) {
+            // Only the prefix row of every outfit feeds the heads (outfit_x.py:142,170): out-proj, LayerNorm-2 and the FFN of the last
+            // layer run on those B rows (compacted: row b of the Xmid / st2 / H2 / Upre / A tape buffers; dropout rows = b).
+            TRY(ofx_launch_gather_rows(t.O, T.cu, T.pO, B, D * 2, D * 2, s));
+            TRY(ofx_launch_gather_rows(t.Xin, T.cu, T.pX, B, D * 4, D * 4, s));
+            GemmArgs p2{}; p2.A = T.pO; p2.W = Ly.w_out; p2.C = t.Xmid; p2.bias = Ly.b_out; p2.resid = T.pX; p2.M = B; p2.N = D; p2.K = D;
+            p2.lda = D; p2.ldc = D; p2.ldr = D; p2.out_kind = OFX_OUT_F32; p2.slab = w.slab; p2.slab_bytes = w.slab_bytes;
+            p2.drop = make_drop(dropout_p, seed, 4 * l + 1);
+            TRY(ofx_launch_gemm(p2, dt, s));
+            LnArgs lp{t.Xmid, nullptr, Ly.g2, Ly.be2, t.H2, B, D, D, OFX_OUT_OP, d.ln_eps}; lp.stats = t.st2;
+            TRY(ofx_launch_layernorm(lp, dt, s));
+            GemmArgs p3{}; p3.A = t.H2; p3.W = Ly.w_1; p3.C = t.A; p3.bias = Ly.b_1; p3.aux_out = t.Upre; p3.M = B; p3.N = Fp; p3.K = D;
+            p3.lda = D; p3.ldc = Fp; p3.act = d.outfit_act; p3.out_kind = OFX_OUT_OP; p3.slab = w.slab; p3.slab_bytes = w.slab_bytes;
+            p3.drop = make_drop(dropout_p, seed, 4 * l + 2);
+            TRY(ofx_launch_gemm(p3, dt, s));
+            GemmArgs p4{}; p4.A = t.A; p4.W = Ly.w_2; p4.C = T.row0; p4.bias = Ly.b_2; p4.resid = t.Xmid; p4.M = B; p4.N = D; p4.K = Fp;
+            p4.lda = Fp; p4.ldc = D; p4.ldr = D; p4.out_kind = OFX_OUT_F32; p4.slab = w.slab; p4.slab_bytes = w.slab_bytes;
+            p4.drop = make_drop(dropout_p, seed, 4 * l + 3);
+            TRY(ofx_launch_gemm(p4, dt, s));
+            break;
+        }
         GemmArgs g2{}; g2.A = t.O; g2.W = Ly.w_out; g2.C = t.Xmid; g2.bias = Ly.b_out; g2.resid = t.Xin; g2.m_dev = m_dev; g2.M = M; g2.N = D; g2.K = D;
         g2.lda = D; g2.ldc = D; g2.ldr = D; g2.out_kind = OFX_OUT_F32; g2.slab = w.slab; g2.slab_bytes = w.slab_bytes;
         g2.drop = make_drop(dropout_p, seed, 4 * l + 1);
@@ -784,7 +811,6 @@ static int cp_train_fwd_core(ofx_handle* h, const SetInput& in, int B, int L, fl
         g4.drop = make_drop(dropout_p, seed, 4 * l + 3);
         TRY(ofx_launch_gemm(g4, dt, s));
     }
-    TRY(ofx_launch_gather_row0(T.Xfinal, T.cu, T.row0, B, D, s));
     if (head == 1) {                                                // cir_ffn = Linear(D, d_embed, bias=False): no dropout (outfit_x.py:61-63)
         TRY(ofx_launch_pack_rows(T.row0, T.row0b, B, B, D, D, D, 0, dt, s));
         GemmArgs g{}; g.A = T.row0b; g.W = h->cir_w; g.C = logits; g.M = B; g.N = D; g.K = D; g.lda = D; g.ldc = D; g.out_kind = OFX_OUT_F32;
@@ -837,25 +863,55 @@ static int set_train_bwd_core(ofx_handle* h, void* tape_mem, size_t tape_bytes, 
     auto wgrad = [&](const void* dY, int n_w, const void* X, int k_w, float* out) {
         return ofx_launch_gemm_tn(dY, n_w, X, k_w, out, k_w, n_w, k_w, M, m_dev, w.slab, w.slab_bytes, dt, s);
     };
-    // head: logits = X[cu[b]] . w + b.  dX is zero except the prefix rows.
+    // rows == M with m_dev: the pad-free live rows; rows == B with md == nullptr: the compacted prefix rows of the pruned last layer
+    auto dgrad_rows = [&](int rows, const int* md, const void* A, int lda, const void* W, void* C, int ldc, int n, int k, int out_kind, int act, const float* resid,
+                          int ldr, const DropArgs& drop) {
+        GemmArgs g{}; g.A = A; g.W = W; g.C = C; g.M = rows; g.N = n; g.K = k; g.lda = lda; g.ldc = ldc; g.out_kind = out_kind; g.act = act; g.resid = resid; g.ldr = ldr;
+        g.m_dev = md; g.slab = w.slab; g.slab_bytes = w.slab_bytes; g.drop = drop;
+        return ofx_launch_gemm(g, dt, s);
+    };
+    auto wgrad_rows = [&](int rows, const int* md, const void* dY, int n_w, const void* X, int k_w, float* out) {
+        return ofx_launch_gemm_tn(dY, n_w, X, k_w, out, k_w, n_w, k_w, rows, md, w.slab, w.slab_bytes, dt, s);
+    };
     float* dX = w.dXa; float* dX2 = w.dXb_f;
-    OFX_HIP(hipMemsetAsync(dX, 0, (size_t)M * D * 4, s));
-    OFX_HIP(hipMemsetAsync(w.gXb, 0, (size_t)M * D * 2, s));
+    const int lastl = d.n_layers - 1;
+    // ---- heads -> d row0 [B, D] (fp32, w.d_row0) and its operand copy times the last layer's dropout2 mask (w.gXb rows 0..B)
     if (head == 1) {
-        // y = row0 Wc^T:  dWc = dy^T row0 (TN GEMM over the B rows), d row0 = dy Wc; then dX[cu[b]] = d row0[b]
+        // y = row0 Wc^T:  dWc = dy^T row0 (TN GEMM over the B rows), d row0 = dy Wc
         TRY(ofx_launch_pack_rows(dlogits, w.dyb, B, B, D, D, D, 0, dt, s));
         TRY(ofx_launch_gemm_tn(w.dyb, D, T.row0b, D, G(4), D, D, D, B, nullptr, w.slab, w.slab_bytes, dt, s));
         GemmArgs g{}; g.A = w.dyb; g.W = h->cir_w_t; g.C = w.d_row0; g.M = B; g.N = D; g.K = D; g.lda = D; g.ldc = D; g.out_kind = OFX_OUT_F32;
         g.slab = w.slab; g.slab_bytes = w.slab_bytes;
         TRY(ofx_launch_gemm(g, dt, s));
-        TRY(ofx_launch_cp_head_bwd(nullptr, w.d_row0, T.cu, dX, w.gXb, nullptr, B, D, dt, nodrop, site(d.n_layers - 1, 3), s));
+        TRY(ofx_launch_cp_head_bwd(nullptr, w.d_row0, nullptr, w.d_row0, w.gXb, nullptr, B, D, dt, nodrop, site(lastl, 3), s));
     } else {
-    TRY(ofx_launch_cp_head_bwd(dlogits, h->cp_w, T.cu, dX, w.gXb, G(3), B, D, dt, site(d.n_layers, 0), site(d.n_layers - 1, 3), s));
-    TRY(ofx_launch_colsum(T.row0, 0, D, nullptr, dlogits, G(2), nullptr, nullptr, D, w.part, D, nullptr, B, dt, s));                 // d cp_w = sum_b dlogit_b (row0_b . m_head)
+        TRY(ofx_launch_cp_head_bwd(dlogits, h->cp_w, nullptr, w.d_row0, w.gXb, G(3), B, D, dt, site(d.n_layers, 0), site(lastl, 3), s));
+        TRY(ofx_launch_colsum(T.row0, 0, D, nullptr, dlogits, G(2), nullptr, nullptr, D, w.part, D, nullptr, B, dt, s));             // d cp_w = sum_b dlogit_b (row0_b . m_head)
     }
-    // bias gradient of the last layer's linear2 = column sums of (dX . m_dropout2): only the prefix rows are non-zero
-    TRY(ofx_launch_colsum(w.gXb, 1, D, T.cu, nullptr, G(5 + 12 * (d.n_layers - 1) + 7), nullptr, nullptr, D, w.part, D, nullptr, B, dt, s));
-    for (int l = d.n_layers - 1; l >= 0; --l) {
+    TRY(ofx_launch_row_map(T.cu, w.rowmap, B, M, s));
+    {   // ---- last layer: FFN, LayerNorm-2 and out-proj only saw the B prefix rows (compacted, static count)
+        const OutfitLayer& Ly = h->ol[lastl];
+        const TapeLayer& t = T.L[lastl];
+        const int g0 = 5 + 12 * lastl;
+        TRY(ofx_launch_colsum(w.gXb, 1, D, nullptr, nullptr, G(g0 + 7), nullptr, nullptr, D, w.part, D, nullptr, B, dt, s));                      // db2
+        TRY(wgrad_rows(B, nullptr, w.gXb, D, t.A, Fp, G(g0 + 6)));                                                                    // dW2
+        TRY(dgrad_rows(B, nullptr, w.gXb, D, Ly.w_2_t, w.dU, Fp, Fp, D, OFX_OUT_OP, OFX_ACT_MISH_GRAD, t.Upre, Fp, site(lastl, 2)));  // dU
+        TRY(ofx_launch_colsum(w.dU, 1, Fp, nullptr, nullptr, G(g0 + 5), nullptr, nullptr, Fp, w.part, Fp, nullptr, B, dt, s));                    // db1
+        TRY(wgrad_rows(B, nullptr, w.dU, Fp, t.H2, D, G(g0 + 4)));                                                                    // dW1
+        TRY(dgrad_rows(B, nullptr, w.dU, Fp, Ly.w_1_t, w.dH, D, D, Fp, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nodrop));               // dH2
+        TRY(ofx_launch_ln_bwd(w.dH, t.Xmid, t.st2, Ly.g2, w.d_row0, nullptr, dX2, w.gXb, G(g0 + 10), G(g0 + 11), G(g0 + 3), w.part, D, nullptr, B, dt,
+                              site(lastl, 1), s));                                                                                    // dXmid (B rows) + dbo
+        TRY(wgrad_rows(B, nullptr, w.gXb, D, T.pO, D, G(g0 + 2)));                                                                    // dWo
+        TRY(dgrad_rows(B, nullptr, w.gXb, D, Ly.w_out_t, w.dO, D, D, D, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nodrop));              // dO (B rows)
+        TRY(ofx_launch_set_attention_bwd(t.QKV, w.dO, w.gQb, T.cu, B, d.n_head, D, L + 1, 0.125f, dt, site(lastl, 0), 1, s));         // all rows get dK, dV
+        TRY(ofx_launch_colsum(w.gQb, 1, 3 * D, nullptr, nullptr, G(g0 + 1), nullptr, nullptr, 3 * D, w.part, 3 * D, m_dev, M, dt, s));
+        TRY(wgrad_rows(M, m_dev, w.gQb, 3 * D, t.H1, D, G(g0 + 0)));
+        TRY(dgrad_rows(M, m_dev, w.gQb, 3 * D, Ly.w_in_t, w.dH, D, D, 3 * D, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nodrop));
+        // dXin = LayerNorm-1 backward + (dXmid at the prefix rows); its column sums = bias gradient of the layer below's linear2
+        TRY(ofx_launch_ln_bwd(w.dH, t.Xin, t.st1, Ly.g1, dX2, w.rowmap, dX, w.gXb, G(g0 + 8), G(g0 + 9), lastl > 0 ? G(g0 - 12 + 7) : nullptr, w.part, D, m_dev, M, dt,
+                              lastl > 0 ? site(lastl - 1, 3) : nodrop, s));
+    }
+    for (int l = lastl - 1; l >= 0; --l) {
         const OutfitLayer& Ly = h->ol[l];
         const TapeLayer& t = T.L[l];
         const int g0 = 5 + 12 * l;                    // Win, bin, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2
@@ -865,16 +921,16 @@ static int set_train_bwd_core(ofx_handle* h, void* tape_mem, size_t tape_bytes, 
         TRY(ofx_launch_colsum(w.dU, 1, Fp, nullptr, nullptr, G(g0 + 5), nullptr, nullptr, Fp, w.part, Fp, m_dev, M, dt, s));   // db1
         TRY(wgrad(w.dU, Fp, t.H2, D, G(g0 + 4)));                                                                   // dW1 [Fp, D]
         TRY(dgrad(w.dU, Fp, Ly.w_1_t, w.dH, D, D, Fp, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nodrop));                      // dH2
-        TRY(ofx_launch_ln_bwd(w.dH, t.Xmid, t.st2, Ly.g2, dX, dX2, w.gXb, G(g0 + 10), G(g0 + 11), G(g0 + 3), w.part, D, m_dev, M, dt, site(l, 1), s));   // dXmid (+ dbo)
+        TRY(ofx_launch_ln_bwd(w.dH, t.Xmid, t.st2, Ly.g2, dX, nullptr, dX2, w.gXb, G(g0 + 10), G(g0 + 11), G(g0 + 3), w.part, D, m_dev, M, dt, site(l, 1), s));   // dXmid (+ dbo)
         // ---- attention branch: Xmid = Xin + O Wo^T + bo
         TRY(wgrad(w.gXb, D, t.O, D, G(g0 + 2)));                                                                    // dWo [D, D]
         TRY(dgrad(w.gXb, D, Ly.w_out_t, w.dO, D, D, D, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nodrop));                     // dO
-        TRY(ofx_launch_set_attention_bwd(t.QKV, w.dO, w.gQb, T.cu, B, d.n_head, D, L + 1, 0.125f, dt, site(l, 0), s));
+        TRY(ofx_launch_set_attention_bwd(t.QKV, w.dO, w.gQb, T.cu, B, d.n_head, D, L + 1, 0.125f, dt, site(l, 0), 0, s));
         TRY(ofx_launch_colsum(w.gQb, 1, 3 * D, nullptr, nullptr, G(g0 + 1), nullptr, nullptr, 3 * D, w.part, 3 * D, m_dev, M, dt, s));   // dbin
         TRY(wgrad(w.gQb, 3 * D, t.H1, D, G(g0 + 0)));                                                               // dWin [3D, D]
         TRY(dgrad(w.gQb, 3 * D, Ly.w_in_t, w.dH, D, D, 3 * D, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nodrop));              // dH1
         // dXin; its column sums are the bias gradient of the layer below's linear2
-        TRY(ofx_launch_ln_bwd(w.dH, t.Xin, t.st1, Ly.g1, dX2, dX, w.gXb, G(g0 + 8), G(g0 + 9), l > 0 ? G(g0 - 12 + 7) : nullptr, w.part, D, m_dev, M, dt,
+        TRY(ofx_launch_ln_bwd(w.dH, t.Xin, t.st1, Ly.g1, dX2, nullptr, dX, w.gXb, G(g0 + 8), G(g0 + 9), l > 0 ? G(g0 - 12 + 7) : nullptr, w.part, D, m_dev, M, dt,
                               l > 0 ? site(l - 1, 3) : nodrop, s));
     }
     // CIR: the prefix is [target_item_image_emb | text]: d target_item_image_emb = sum_b dX0[cu[b]][:D/2]

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* part, in
 // dgamma = dy * xhat, dbeta = dy and of the OUTPUT's columns (= bias gradient of the linear layer below) -> part[block][3D].
 template <int NCH, typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const float* x, const float* stats, const float* gamma, const float* add,
-                                                     float* dx_out, T* dx_op, float* part, const int* m_dev, int M_static, DropArgs drop) {
+                                                     const int* add_map, float* dx_out, T* dx_op, float* part, const int* m_dev, int M_static, DropArgs drop) {
     typedef typename OpT<T>::v4 v4;
     constexpr int D = NCH * 256;
     __shared__ __attribute__((aligned(16))) float red[3 * D];
@@ -115,7 +115,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const floa
         for (int c = 0; c < NCH; ++c) {
             const int col = (lane + 64 * c) * 4;
             f32x4 o = (g[c] - m1 - xh[c] * m2) * rstd;
-            if (add) o += *(const f32x4*)(add + (size_t)r * D + col);
+            if (add) {                 // add_map: `add` holds one row per outfit and only the mapped (prefix) rows receive it
+                const int ar = add_map ? add_map[r] : r;
+                if (ar >= 0) o += *(const f32x4*)(add + (size_t)ar * D + col);
+            }
             *(f32x4*)(dx_out + (size_t)r * D + col) = o;
             if (drop.thresh) {           // the copy that feeds the linear layer below is the gradient of ITS (dropped-out) output
 #pragma unroll
@@ -157,6 +160,7 @@ struct SetBwdK {
     int n_head, D;
     float scale;
     DropArgs drop;
+    int only_row0;      // d_o is [nseq, D]: only query row 0 of every set has an upstream gradient (pruned last layer)
 };
 template <typename T, int SMAX>
 __global__ __launch_bounds__(64) void set_attention_bwd_kernel(SetBwdK a) {
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(64) void set_attention_bwd_kernel(SetBwdK a) {
         qs[j * STR + lane] = rp[0];
         ks[j * STR + lane] = rp[D];
         vs[j * STR + lane] = rp[2 * D];
-        gs[j * STR + lane] = a.d_o[(size_t)(r0 + j) * D + h * 64 + lane];
+        gs[j * STR + lane] = a.only_row0 ? (j == 0 ? a.d_o[(size_t)b * D + h * 64 + lane] : 0.f) : a.d_o[(size_t)(r0 + j) * D + h * 64 + lane];
     }
     __syncthreads();
     for (int p = lane; p < S * S; p += 64) {                 // scores and dP = dO . V^T
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(256) void cp_head_bwd_kernel(const float* dlogits, 
                                                          DropArgs head, DropArgs below) {
     typedef typename OpT<T>::v4 v4;
     const int b = blockIdx.x;
-    const int r = cu[b];
+    const int r = cu ? cu[b] : b;
     const size_t row = (size_t)r * D;
     // dlogits == nullptr: `w` is a ready [B, D] matrix of row gradients (CIR head) instead of the CP head's weight vector
     const float g = dlogits ? dlogits[b] : 1.0f;
@@ -293,6 +297,12 @@ __global__ __launch_bounds__(256) void cp_head_bwd_kernel(const float* dlogits, 
     }
 }
 
+// map[cu[b]] = b (the rest of map was set to -1): which outfit's prefix row a pad-free row is
+__global__ __launch_bounds__(256) void row_map_kernel(const int* cu, int* map, int B) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < B) map[cu[b]] = b;
+}
+
 // x[r][c] *= mask(r, c)   (head dropout on the pooled rows; also exports a mask for the tests when x is all ones)
 __global__ __launch_bounds__(256) void drop_rows_kernel(float* x, int rows, int cols, DropArgs d) {
     const size_t total = (size_t)rows * cols;
@@ -304,6 +314,12 @@ __global__ __launch_bounds__(256) void drop_rows_kernel(float* x, int rows, int 
 
 #define BWD_CHECK() OFX_LAUNCH_CHECK()
 
+int ofx_launch_row_map(const int* cu, int* map, int B, int M, hipStream_t s) {
+    OFX_HIP(hipMemsetAsync(map, 0xFF, (size_t)M * 4, s));
+    hipLaunchKernelGGL(row_map_kernel, dim3((B + 255) / 256), dim3(256), 0, s, cu, map, B);
+    BWD_CHECK();
+    return OFX_OK;
+}
 int ofx_launch_drop_rows(float* x, int rows, int cols, const DropArgs& d, hipStream_t s) {
     if (!d.thresh) return OFX_OK;
     size_t total = (size_t)rows * cols;
@@ -342,11 +358,11 @@ int ofx_launch_colsum(const void* x, int x_kind /*0 fp32 | 1 operand type*/, int
 
 constexpr int LN_BWD_BLOCKS = 256;
 size_t ofx_ln_bwd_part_floats(int D) { return (size_t)LN_BWD_BLOCKS * 3 * D; }
-int ofx_launch_ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* add, float* dx_out, void* dx_op,
+int ofx_launch_ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* add, const int* add_map, float* dx_out, void* dx_op,
                       float* dgamma, float* dbeta, float* dcols, float* part, int D, const int* m_dev, int M, int op_dtype, const DropArgs& drop, hipStream_t s) {
     OFX_REQUIRE(D == 512 || D == 768 || D == 1024, OFX_ESHAPE, "ln_bwd: D=%d", D);
     ProfScope prof(PROF_NORM, s);
-#define LNB(NCH, T) hipLaunchKernelGGL((ln_bwd_kernel<NCH, T>), dim3(LN_BWD_BLOCKS), dim3(256), 0, s, dy, x, stats, gamma, add, dx_out, (T*)dx_op, part, m_dev, M, drop)
+#define LNB(NCH, T) hipLaunchKernelGGL((ln_bwd_kernel<NCH, T>), dim3(LN_BWD_BLOCKS), dim3(256), 0, s, dy, x, stats, gamma, add, add_map, dx_out, (T*)dx_op, part, m_dev, M, drop)
     if (op_dtype == OFX_F16) { if (D == 1024) LNB(4, f16_t); else if (D == 768) LNB(3, f16_t); else LNB(2, f16_t); }
     else { if (D == 1024) LNB(4, bf16_t); else if (D == 768) LNB(3, bf16_t); else LNB(2, bf16_t); }
 #undef LNB
@@ -356,9 +372,9 @@ int ofx_launch_ln_bwd(const float* dy, const float* x, const float* stats, const
 }
 
 int ofx_launch_set_attention_bwd(const float* qkv, const float* d_o, void* dqkv, const int* cu, int nseq, int n_head, int D, int max_len,
-                                 float scale, int op_dtype, const DropArgs& drop, hipStream_t s) {
+                                 float scale, int op_dtype, const DropArgs& drop, int only_row0, hipStream_t s) {
     OFX_REQUIRE(D == n_head * 64 && max_len >= 1 && max_len <= 32, OFX_ESHAPE, "set_attention_bwd: bad shape");
-    SetBwdK k{qkv, d_o, dqkv, cu, n_head, D, scale, drop};
+    SetBwdK k{qkv, d_o, dqkv, cu, n_head, D, scale, drop, only_row0};
     ProfScope prof(PROF_ATTN, s);
 #define SAB(T, S) hipLaunchKernelGGL((set_attention_bwd_kernel<T, S>), dim3(nseq * n_head), dim3(64), 0, s, k)
     if (op_dtype == OFX_F16) { if (max_len <= 20) SAB(f16_t, 20); else SAB(f16_t, 32); }

@@ -205,7 +205,10 @@ def test_dropout_training_step_matches_torch_autograd_with_the_same_masks():
     nl, H, D, F = m.cfg.transformer.n_layers, 16, 1024, m.cfg.transformer.d_ffn
     mk = lambda site, r, c: dropout_mask(p, seed, site, r, c, dev).cpu().double()
     logits = []
-    masks = {l: (mk(4 * l, B * H, 32 * 32).view(B, H, 32, 32), mk(4 * l + 1, M, D), mk(4 * l + 2, M, 2048)[:, :F], mk(4 * l + 3, M, D)) for l in range(nl)}
+    # rows of the non-attention masks: the global pad-free row, except in the LAST layer, whose out-proj / FFN only run on the
+    # B prefix rows (compacted: mask row = outfit index; the other rows of that layer never reach the head)
+    masks = {l: (mk(4 * l, B * H, 32 * 32).view(B, H, 32, 32), mk(4 * l + 1, M, D), mk(4 * l + 2, M, 2048)[:, :F], mk(4 * l + 3, M, D)) for l in range(nl - 1)}
+    last = (mk(4 * (nl - 1), B * H, 32 * 32).view(B, H, 32, 32), mk(4 * (nl - 1) + 1, B, D), mk(4 * (nl - 1) + 2, B, 2048)[:, :F], mk(4 * (nl - 1) + 3, B, D))
     mh = mk(4 * nl, B, D)
     ln = torch.nn.functional.layer_norm
     for b in range(B):
@@ -213,16 +216,21 @@ def test_dropout_training_step_matches_torch_autograd_with_the_same_masks():
         X = torch.cat([P["outfit_token"].view(1, D), torch.from_numpy(emb[b, :n[b]]).double()], 0)
         for l in range(nl):
             q = lambda name: P[f"transformer_encoder.layers.{l}.{name}"]
-            m0, m1, m2, m3 = masks[l]
+            if l < nl - 1:
+                m0, m1, m2, m3 = masks[l]
+                m1, m2, m3 = m1[r0:r0 + s], m2[r0:r0 + s], m3[r0:r0 + s]
+            else:
+                m0 = last[0]
+                m1, m2, m3 = [torch.cat([t_[b:b + 1], torch.ones(s - 1, t_.shape[1], dtype=torch.float64)], 0) for t_ in last[1:]]
             h1 = ln(X, (D,), q("norm1.weight"), q("norm1.bias"), 1e-5)
             qkv = h1 @ q("self_attn.in_proj_weight").t() + q("self_attn.in_proj_bias")
             qh, kh, vh = [t.view(s, H, 64).transpose(0, 1) for t in qkv.split(D, dim=1)]
             pr = torch.softmax(qh @ kh.transpose(1, 2) / 8.0, -1) * m0[b, :, :s, :s]
             o = (pr @ vh).transpose(0, 1).reshape(s, D)
-            X = X + (o @ q("self_attn.out_proj.weight").t() + q("self_attn.out_proj.bias")) * m1[r0:r0 + s]
+            X = X + (o @ q("self_attn.out_proj.weight").t() + q("self_attn.out_proj.bias")) * m1
             h2 = ln(X, (D,), q("norm2.weight"), q("norm2.bias"), 1e-5)
-            a = torch.nn.functional.mish(h2 @ q("linear1.weight").t() + q("linear1.bias")) * m2[r0:r0 + s]
-            X = X + (a @ q("linear2.weight").t() + q("linear2.bias")) * m3[r0:r0 + s]
+            a = torch.nn.functional.mish(h2 @ q("linear1.weight").t() + q("linear1.bias")) * m2
+            X = X + (a @ q("linear2.weight").t() + q("linear2.bias")) * m3
         logits.append((X[0] * mh[b]) @ P["cp_ffn.1.weight"].view(-1) + P["cp_ffn.1.bias"].view(()))
     ref_logits = torch.stack(logits)
     (ref_logits * up.double()).sum().backward()
