@@ -10,7 +10,7 @@ FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function 
 
 all: $(LIB)
 
-$(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/ofx_common.h include/ofx.h
+$(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/ofx_common.h $(CSRC)/gemm_common.h include/ofx.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(FLAGS) -c $< -o $@
 

@@ -1,0 +1,317 @@
+// Shared pieces of the GEMM translation units (gemm.hip: 128x128 kernel + dispatcher; gemm_big.hip: 256x256 / 256x128 tiles;
+// gemm_pp.hip: ping-pong 256x256; gemm_tn.hip: weight-gradient TN kernel): kernel arguments, the LDS-DMA helper and the fused
+// epilogues.  Everything here has internal linkage (anonymous namespace / templates); the files are split only so that they
+// compile in parallel.
+#pragma once
+#include <type_traits>
+
+#include "ofx_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int STAGE_BYTES = (BM + BN) * BK * 2;        // 32 KiB
+constexpr int EPI_STRIDE = 68;                         // floats per staged output row (64 + 4 pad)
+constexpr int EPI_BYTES_PER_WAVE = 64 * EPI_STRIDE * 4;
+constexpr int GEMM_LDS_BYTES = 4 * EPI_BYTES_PER_WAVE > 2 * STAGE_BYTES ? 4 * EPI_BYTES_PER_WAVE : 2 * STAGE_BYTES;
+
+struct KArgs {
+    const char* A;
+    const char* W;
+    char* C;
+    const float* bias;
+    const float* resid;
+    float* aux_out;     // optional fp32 [M, N] pre-activation copy
+    const int* m_dev;   // optional device-side row count (pad-free varlen sets); M is then the upper bound
+    unsigned long long* dbg;   // diagnostics only (tools/gemm_bench.py --clock): per block {shader cycles, 100 MHz ticks} of the main loop
+    int M, N, K, lda, ldc, ldr, act, out_kind, tiles_n, tiles_m, nwg, group_m, skew;
+    int m_slab;                 // rows per slab plane (the host-side M, never the clamped live count)
+    int splits, kt_per_split;   // 128x128 kernel only: blockIdx.y owns k-tiles [y*kt_per_split, ...) and writes a raw fp32 slab
+    float* slab;                // [splits, M, N] partial sums when splits > 1
+    DropArgs drop;
+    char* xb_out; float* stat_part; const float* row_stat; const float* col_sum;   // LayerNorm folding (GemmArgs)
+};
+
+__device__ __forceinline__ void glds16(const char* g, OFX_LDS char* l) {
+    __builtin_amdgcn_global_load_lds((const OFX_GLB void*)g, (OFX_LDS void*)l, 16, 0, 0);
+}
+
+
+// One wave drains its 64x64 fp32 sub-tile from LDS as whole row segments: 16 lanes x 16 B per row.
+template <typename T, int ACT>
+__device__ __forceinline__ void epilogue(const KArgs& p, OFX_LDS float* ep, int gm0, int gn0, int lane) {
+    typedef typename OpT<T>::v4 v4;
+    const int col = (lane & 15) * 4;
+    const int gn = gn0 + col;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias4 = *(const f32x4*)(p.bias + gn);
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int row = it * 4 + (lane >> 4);
+        const int gm = gm0 + row;
+        f32x4 v = *(OFX_LDS f32x4*)(ep + row * EPI_STRIDE + col);
+        if (gm < p.M) {
+            if (p.row_stat) {
+                const float mu = p.row_stat[2 * (size_t)gm], rs = p.row_stat[2 * (size_t)gm + 1];
+                v = (v - *(const f32x4*)(p.col_sum + gn) * mu) * rs + bias4;
+            } else v += bias4;
+            if (p.aux_out) *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn) = v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (ACT == OFX_ACT_QUICK_GELU) v[e] = act_quick_gelu(v[e]);
+                else if (ACT == OFX_ACT_GELU) v[e] = act_gelu(v[e]);
+                else if (ACT == OFX_ACT_MISH) v[e] = act_mish(v[e]);
+            }
+            if (p.drop.thresh) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= drop_mul(p.drop, gm, gn + e);
+            }
+            if (p.resid) {
+                const f32x4 rr = *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn);
+                if (ACT == OFX_ACT_MISH_GRAD) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= act_mish_grad(rr[e]);
+                } else v += rr;
+            }
+            if (p.out_kind == 0) {
+                *(f32x4*)(p.C + ((size_t)gm * p.ldc + gn) * 4) = v;
+                if (p.xb_out) {
+                    v4 hb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hb[e] = (T)v[e];
+                    *(v4*)((T*)p.xb_out + (size_t)gm * p.N + gn) = hb;
+                }
+                if (p.stat_part) {          // gm is uniform over the 16 lanes that share this row
+                    const float ssum = row16_sum_to_lane15((v[0] + v[1]) + (v[2] + v[3]));
+                    const float ssq = row16_sum_to_lane15((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+                    if ((lane & 15) == 15) *(f32x2*)(p.stat_part + ((size_t)gm * (p.N >> 6) + (gn0 >> 6)) * 2) = f32x2{ssum, ssq};
+                }
+            } else {
+                v4 hi;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hi[e] = (T)v[e];
+                T* crow = (T*)p.C + (size_t)gm * p.ldc + gn;
+                *(v4*)crow = hi;
+                if (p.out_kind == 2) {
+                    v4 lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) lo[e] = (T)(v[e] - (float)hi[e]);
+                    *(v4*)(crow + p.N) = lo;
+                    *(v4*)(crow + 2 * p.N) = hi;
+                }
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// v2: 256x256x64 tile, 512 threads = 8 waves (2 x 4), wave tile 128x64 = 8x4 MFMA tiles x 2 k-steps.
+// Half the LDS-fill bytes and two thirds of the LDS fragment reads per FLOP of the 128^2 kernel
+// (the ablation in DESIGN.md §4 shows the fill path, not the MFMA pipe, bounds that kernel).
+// Per k-tile: [vmcnt -> barrier -> 24 ds_read_b128 into registers -> barrier] frees the stage at
+// once, so the LDS-DMA of k-tile t+2 is issued before the 64 MFMAs of k-tile t and two k-tiles
+// (128 KiB per CU) stay in flight.  LDS: 2 stages x 64 KiB + 32 KiB epilogue staging = 160 KiB.
+constexpr int EPI2_BYTES_PER_WAVE = 16 * 64 * 4;       // 16 rows x 64 fp32, XOR-swizzled, no padding
+
+// Epilogue of the 128x64 wave tile: 8 passes of 16 rows through the wave's private LDS staging (XOR-swizzled
+// 16-B chunks), leaving as whole 128/256-byte row segments with 16-byte stores (the store tail is issue-bound:
+// guide T21).  fp32 output: 16 lanes x 4 columns per row, the fp32 residual of pass i+2 requested while pass i is
+// written out.  bf16/f16 output: 8 lanes x 8 columns per row -> one dwordx4 store per lane instead of two dwordx2.
+template <typename T, int ACT>
+__device__ __forceinline__ float act_apply(float v) {
+    if (ACT == OFX_ACT_QUICK_GELU) return act_quick_gelu(v);
+    if (ACT == OFX_ACT_GELU) return act_gelu(v);
+    if (ACT == OFX_ACT_MISH) return act_mish(v);
+    return v;
+}
+
+// FOLD (LayerNorm folding, compile-time so the common path keeps its registers): 0 none, 1 producer (fp32 output + operand copy
+// + per-segment statistics), 2 consumer (row statistics + column sums applied to the accumulator).
+template <typename T, int ACT, int FOLD = 0>
+__device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x4 (&acc)[8][4], int gm0, int gn0, int lane) {
+    typedef typename OpT<T>::v8 v8;
+    const int fr = lane & 15, fq = lane >> 4;
+    if (p.out_kind == 0) {
+        constexpr int DEPTH = 2;
+        const int chunk = lane & 15, rsub = lane >> 4;
+        const int gn = gn0 + chunk * 4;
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias4 = *(const f32x4*)(p.bias + gn);
+        const bool has_res = p.resid != nullptr;
+        f32x4 res[DEPTH + 1][4];
+        auto fetch = [&](int pass, f32x4 (&dst)[4]) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int gm = gm0 + pass * 16 + it * 4 + rsub;
+                dst[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (has_res && gm < p.M) dst[it] = *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn);
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) fetch(d, res[d]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i + DEPTH < 8) fetch(i + DEPTH, res[(i + DEPTH) % (DEPTH + 1)]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(OFX_LDS f32x4*)(ep + fr * 256 + (((j * 4 + fq) ^ (fr & 7)) << 4)) = acc[i][j];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 4 + rsub;
+                const int gm = gm0 + i * 16 + row;
+                f32x4 v = *(OFX_LDS f32x4*)(ep + row * 256 + ((chunk ^ (row & 7)) << 4));
+                if (gm < p.M) {
+                    if (FOLD == 2) {
+                        const float mu = p.row_stat[2 * (size_t)gm], rs = p.row_stat[2 * (size_t)gm + 1];
+                        v = (v - *(const f32x4*)(p.col_sum + gn) * mu) * rs + bias4;
+                    } else v += bias4;
+                    if (FOLD == 0 && p.aux_out) *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn) = v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_apply<T, ACT>(v[e]);
+                    if (FOLD == 0 && p.drop.thresh) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= drop_mul(p.drop, gm, gn + e);
+                    }
+                    if (ACT == OFX_ACT_MISH_GRAD) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= act_mish_grad(res[i % (DEPTH + 1)][it][e]);
+                    } else v += res[i % (DEPTH + 1)][it];
+                    *(f32x4*)(p.C + ((size_t)gm * p.ldc + gn) * 4) = v;
+                    if (FOLD == 1 && p.xb_out) {
+                        typename OpT<T>::v4 hb;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hb[e] = (T)v[e];
+                        *(typename OpT<T>::v4*)((T*)p.xb_out + (size_t)gm * p.N + gn) = hb;
+                    }
+                    if (FOLD == 1 && p.stat_part) {      // gm is uniform over the 16 lanes (same rsub) that share this row
+                        const float ssum = row16_sum_to_lane15((v[0] + v[1]) + (v[2] + v[3]));
+                        const float ssq = row16_sum_to_lane15((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+                        if (chunk == 15) *(f32x2*)(p.stat_part + ((size_t)gm * (p.N >> 6) + (gn0 >> 6)) * 2) = f32x2{ssum, ssq};
+                    }
+                }
+            }
+        }
+    } else {
+        const int c8 = lane & 7, rsub = lane >> 3;          // 8 columns per lane, 8 rows per wave-instruction
+        const int gn = gn0 + c8 * 8;
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+        if (p.bias) { b0 = *(const f32x4*)(p.bias + gn); b1 = *(const f32x4*)(p.bias + gn + 4); }
+        f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = cs0;
+        if (FOLD == 2) { cs0 = *(const f32x4*)(p.col_sum + gn); cs1 = *(const f32x4*)(p.col_sum + gn + 4); }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(OFX_LDS f32x4*)(ep + fr * 256 + (((j * 4 + fq) ^ (fr & 7)) << 4)) = acc[i][j];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = it * 8 + rsub;
+                const int gm = gm0 + i * 16 + row;
+                f32x4 v0 = *(OFX_LDS f32x4*)(ep + row * 256 + (((2 * c8) ^ (row & 7)) << 4));
+                f32x4 v1 = *(OFX_LDS f32x4*)(ep + row * 256 + (((2 * c8 + 1) ^ (row & 7)) << 4));
+                if (gm < p.M) {
+                    if (FOLD == 2) {
+                        const float mu = p.row_stat[2 * (size_t)gm], rs = p.row_stat[2 * (size_t)gm + 1];
+                        v0 = (v0 - cs0 * mu) * rs + b0; v1 = (v1 - cs1 * mu) * rs + b1;
+                    } else { v0 += b0; v1 += b1; }
+                    if (FOLD == 0 && p.aux_out) { *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn) = v0; *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn + 4) = v1; }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v0[e] = act_apply<T, ACT>(v0[e]); v1[e] = act_apply<T, ACT>(v1[e]); }
+                    if (FOLD == 0 && p.drop.thresh) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v0[e] *= drop_mul(p.drop, gm, gn + e); v1[e] *= drop_mul(p.drop, gm, gn + 4 + e); }
+                    }
+                    if (p.resid) {
+                        const f32x4 r0 = *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn), r1 = *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn + 4);
+                        if (ACT == OFX_ACT_MISH_GRAD) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { v0[e] *= act_mish_grad(r0[e]); v1[e] *= act_mish_grad(r1[e]); }
+                        } else { v0 += r0; v1 += r1; }
+                    }
+                    v8 hi;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { hi[e] = (T)v0[e]; hi[4 + e] = (T)v1[e]; }
+                    T* crow = (T*)p.C + (size_t)gm * p.ldc + gn;
+                    *(v8*)crow = hi;
+                    if (p.out_kind == 2) {
+                        v8 lo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { lo[e] = (T)(v0[e] - (float)hi[e]); lo[4 + e] = (T)(v1[e] - (float)hi[4 + e]); }
+                        *(v8*)(crow + p.N) = lo;
+                        *(v8*)(crow + 2 * p.N) = hi;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void epilogue2_dispatch(const KArgs& p, OFX_LDS char* ep, f32x4 (&acc)[8][4], int gm0, int gn0, int lane) {
+    if (p.row_stat) {                                  // LayerNorm-fold consumer: towers only (no residual, no dropout, no tape)
+        switch (p.act) {
+            case OFX_ACT_QUICK_GELU: epilogue2<T, OFX_ACT_QUICK_GELU, 2>(p, ep, acc, gm0, gn0, lane); break;
+            case OFX_ACT_GELU: epilogue2<T, OFX_ACT_GELU, 2>(p, ep, acc, gm0, gn0, lane); break;
+            default: epilogue2<T, OFX_ACT_NONE, 2>(p, ep, acc, gm0, gn0, lane); break;
+        }
+        return;
+    }
+    if (p.xb_out || p.stat_part) { epilogue2<T, OFX_ACT_NONE, 1>(p, ep, acc, gm0, gn0, lane); return; }
+    switch (p.act) {
+        case OFX_ACT_QUICK_GELU: epilogue2<T, OFX_ACT_QUICK_GELU>(p, ep, acc, gm0, gn0, lane); break;
+        case OFX_ACT_GELU: epilogue2<T, OFX_ACT_GELU>(p, ep, acc, gm0, gn0, lane); break;
+        case OFX_ACT_MISH: epilogue2<T, OFX_ACT_MISH>(p, ep, acc, gm0, gn0, lane); break;
+        case OFX_ACT_MISH_GRAD: epilogue2<T, OFX_ACT_MISH_GRAD>(p, ep, acc, gm0, gn0, lane); break;
+        default: epilogue2<T, OFX_ACT_NONE>(p, ep, acc, gm0, gn0, lane); break;
+    }
+}
+
+// Split-K second pass: out = epilogue( sum_s slab[s] ) in a fixed order (deterministic), 4 columns per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(KArgs p) {
+    typedef typename OpT<T>::v4 v4;
+    const int M = p.m_dev ? min(*p.m_dev, p.M) : p.M;
+    const int n4 = p.N / 4;
+    const size_t total = (size_t)M * n4, plane = (size_t)p.m_slab * p.N;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int gm = (int)(i / n4), gn = (int)(i % n4) * 4;
+        const float* sp = p.slab + (size_t)gm * p.N + gn;
+        f32x4 v = *(const f32x4*)sp;
+        for (int s = 1; s < p.splits; ++s) v += *(const f32x4*)(sp + s * plane);
+        if (p.bias) v += *(const f32x4*)(p.bias + gn);
+        if (p.aux_out) *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn) = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+        if (p.drop.thresh) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= drop_mul(p.drop, gm, gn + e);
+        }
+        if (p.resid) {
+            const f32x4 rr = *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn);
+            if (p.act == OFX_ACT_MISH_GRAD) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= act_mish_grad(rr[e]);
+            } else v += rr;
+        }
+        if (p.out_kind == 0) {
+            *(f32x4*)(p.C + ((size_t)gm * p.ldc + gn) * 4) = v;
+        } else {
+            v4 hi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hi[e] = (T)v[e];
+            T* crow = (T*)p.C + (size_t)gm * p.ldc + gn;
+            *(v4*)crow = hi;
+            if (p.out_kind == 2) {
+                v4 lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lo[e] = (T)(v[e] - (float)hi[e]);
+                *(v4*)(crow + p.N) = lo;
+                *(v4*)(crow + 2 * p.N) = hi;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// launchers implemented by the other translation units (KArgs travels as an opaque pointer: each unit sees the same definition)
+int ofx_gemm_launch_big(void* kargs, int kind, int ablate, int op_dtype, int M, int N, hipStream_t s);
+int ofx_gemm_launch_pp(void* kargs, int op_dtype, int M, int N, hipStream_t s);
