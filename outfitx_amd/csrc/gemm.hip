@@ -162,12 +162,18 @@ int ofx_gemm_splitk_plan(int M, int N, int K) {
     const long blocks = (long)((M + 127) / 128) * (N / 128);
     const int nk = K / 64;
     if (blocks >= 256 || nk < 16) return 1;
-    int s = (int)((512 + blocks - 1) / blocks);
-    if (s > 8) s = 8;
-    if (s > nk / 4) s = nk / 4;                       // at least 4 k-tiles per split
-    if (s < 2) return 1;
-    const int kps = (nk + s - 1) / s;
-    return (nk + kps - 1) / kps;                      // every split owns at least one k-tile
+    // cost model (us), measured on the 128x128 kernel (tools/_exp_small_m.py): ~1.06 us per k-tile and wave of 512 co-resident
+    // blocks; a split adds the slab written once and read once (~5 TB/s) and the reduce launch.  M = 2304 x N = 1024 (144
+    // blocks) is faster UNSPLIT (17 vs 26 us); M = 288 (24 blocks, K = 3072) wants 8 splits (51 -> 13 us).
+    int best = 1;
+    double best_t = (double)((blocks + 511) / 512) * nk * 1.06;
+    for (int s = 2; s <= 8 && s <= nk / 4; ++s) {
+        const int kps = (nk + s - 1) / s;
+        if ((nk + kps - 1) / kps != s) continue;          // every split owns at least one k-tile
+        const double t = (double)((blocks * s + 511) / 512) * kps * 1.06 + 2.0 * s * M * N * 4.0 / 5.0e6 + 3.0;
+        if (t < best_t) { best_t = t; best = s; }
+    }
+    return best;
 }
 size_t ofx_gemm_splitk_bytes(int M, int N, int K) {
     const int s = ofx_gemm_splitk_plan(M, N, K);
