@@ -75,7 +75,7 @@ size_t ofx_ln_bwd_part_floats(int D);
 int ofx_launch_row_map(const int* cu, int* map, int B, int M, hipStream_t s);
 int ofx_launch_ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* add, const int* add_map, float* dx_out, void* dx_op,
                       float* dgamma, float* dbeta, float* dcols, float* part, int D, const int* m_dev, int M, int op_dtype, const DropArgs& drop, hipStream_t s);
-int ofx_launch_set_attention_bwd(const float* qkv, const float* d_o, void* dqkv, const int* cu, int nseq, int n_head, int D, int max_len,
+int ofx_launch_set_attention_bwd(const void* qkv, const float* d_o, void* dqkv, const int* cu, int nseq, int n_head, int D, int max_len,
                                  float scale, int op_dtype, const DropArgs& drop, int only_row0, hipStream_t s);
 int ofx_launch_drop_rows(float* x, int rows, int cols, const DropArgs& d, hipStream_t s);
 int ofx_launch_focal_loss(const float* logits, const float* labels, int B, float alpha, float gamma, float upstream, float* loss, float* dlogits, hipStream_t s);
@@ -641,7 +641,7 @@ static bool d_outfit_act_is_mish(const ofx_handle* h) { return h->d.outfit_act =
 // Forward with a tape + backward of the CP path on precomputed embeddings.  Single-product operand precisions only
 // (bf16 / f16, like the reference's AMP training); dropout is NOT applied (the caller must use dropout = 0).
 namespace {
-struct TapeLayer { float* Xin; float* st1; char* H1; float* QKV; char* O; float* Xmid; float* st2; char* H2; float* Upre; char* A; };
+struct TapeLayer { float* Xin; float* st1; char* H1; char* QKV; char* O; float* Xmid; float* st2; char* H2; float* Upre; char* A; };
 struct Tape { int* cu; float* Xfinal; float* row0; float* prefix; char* row0b; char* pO; float* pX; std::vector<TapeLayer> L; size_t bytes; };
 size_t carve_tape(const ofx_handle* h, Bump& b, int B, int Lq, Tape* t) {
     const size_t M = (size_t)B * (Lq + 1), D = h->d.d_model, Fp = h->ot_ffn_pad, Mp = align_up(M, 64);   // operand copies: rows readable up to Mp (TN GEMM)
@@ -654,7 +654,7 @@ size_t carve_tape(const ofx_handle* h, Bump& b, int B, int Lq, Tape* t) {
     tp.pX = b.take<float>((size_t)B * D);                                 // last layer: layer input at the prefix rows (residual)
     tp.L.resize(h->d.n_layers);
     for (TapeLayer& l : tp.L) {
-        l.Xin = b.take<float>(M * D); l.st1 = b.take<float>(M * 2); l.H1 = b.take<char>(Mp * D * 2); l.QKV = b.take<float>(M * 3 * D);
+        l.Xin = b.take<float>(M * D); l.st1 = b.take<float>(M * 2); l.H1 = b.take<char>(Mp * D * 2); l.QKV = b.take<char>(M * 3 * D * 2);
         l.O = b.take<char>(Mp * D * 2); l.Xmid = b.take<float>(M * D); l.st2 = b.take<float>(M * 2); l.H2 = b.take<char>(Mp * D * 2);
         l.Upre = b.take<float>(M * Fp); l.A = b.take<char>(Mp * Fp * 2);
     }
@@ -769,11 +769,11 @@ static int cp_train_fwd_core(ofx_handle* h, const SetInput& in, int B, int L, fl
         LnArgs ln{t.Xin, nullptr, Ly.g1, Ly.be1, t.H1, M, D, D, OFX_OUT_OP, d.ln_eps}; ln.stats = t.st1;
         TRY(ofx_launch_layernorm_dev(ln, m_dev, dt, s));
         GemmArgs g1{}; g1.A = t.H1; g1.W = Ly.w_in; g1.C = t.QKV; g1.bias = Ly.b_in; g1.m_dev = m_dev; g1.M = M; g1.N = 3 * D; g1.K = D; g1.lda = D;
-        g1.ldc = 3 * D; g1.out_kind = OFX_OUT_F32; g1.slab = w.slab; g1.slab_bytes = w.slab_bytes;
+        g1.ldc = 3 * D; g1.out_kind = OFX_OUT_OP; g1.slab = w.slab; g1.slab_bytes = w.slab_bytes;      // q|k|v kept in the operand type
         TRY(ofx_launch_gemm(g1, dt, s));
         const bool last = l + 1 == d.n_layers;
         SetAttnArgs sa{t.QKV, t.O, T.cu, B, d.n_head, D, D, OFX_OUT_OP, L + 1, last ? 1 : 0, 0.125f};
-        sa.drop = make_drop(dropout_p, seed, 4 * l + 0);
+        sa.drop = make_drop(dropout_p, seed, 4 * l + 0); sa.qkv_op = 1;
         TRY(ofx_launch_set_attention(sa, dt, s));
         if (last) {
             // Only the prefix row of every outfit feeds the heads (outfit_x.py:142,170): out-proj, LayerNorm-2 and the FFN of the last

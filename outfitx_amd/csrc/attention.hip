@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnK a) {
 
 // ------------------------------------------------------------------------------------------------
 struct SetK {
-    const float* qkv;
+    const void* qkv;       // fp32, or the operand type when qkv_op
     char* out;
     const int* cu;
     int nseq, n_head, D, ldo, out_kind, only_row0;
@@ -183,7 +183,7 @@ struct SetK {
     DropArgs drop;
 };
 
-template <typename T, int SMAX>
+template <typename T, int SMAX, typename TI = float>      // TI: element type of qkv (float: scoring path; T: training tape)
 __global__ __launch_bounds__(64) void set_attention_kernel(SetK a) {
     constexpr int STR = 68;                         // floats per staged row: 16-B slots of consecutive rows differ
     __shared__ __attribute__((aligned(16))) float qs[SMAX * STR];
@@ -201,10 +201,10 @@ __global__ __launch_bounds__(64) void set_attention_kernel(SetK a) {
     for (int j = 0; j < SMAX; ++j) {
         vreg[j] = 0.f;
         if (j < S) {
-            const float* rp = a.qkv + (size_t)(r0 + j) * 3 * D + h * 64 + lane;
-            if (j < nq) qs[j * STR + lane] = rp[0];
-            ks[j * STR + lane] = rp[D];
-            vreg[j] = rp[2 * D];
+            const TI* rp = (const TI*)a.qkv + (size_t)(r0 + j) * 3 * D + h * 64 + lane;
+            if (j < nq) qs[j * STR + lane] = (float)rp[0];
+            ks[j * STR + lane] = (float)rp[D];
+            vreg[j] = (float)rp[2 * D];
         }
     }
     __syncthreads();
@@ -280,7 +280,8 @@ int ofx_launch_set_attention(const SetAttnArgs& g, int op_dtype, hipStream_t s) 
     k.out_kind = g.out_kind; k.only_row0 = g.only_row0; k.scale = g.scale; k.drop = g.drop;
     const int grid = g.nseq * g.n_head;
     ProfScope prof(PROF_ATTN, s);
-#define SA(T, N) hipLaunchKernelGGL((set_attention_kernel<T, N>), dim3(grid), dim3(64), 0, s, k)
+#define SA(T, N) do { if (g.qkv_op) hipLaunchKernelGGL((set_attention_kernel<T, N, T>), dim3(grid), dim3(64), 0, s, k); \
+                      else hipLaunchKernelGGL((set_attention_kernel<T, N, float>), dim3(grid), dim3(64), 0, s, k); } while (0)
     if (op_dtype == OFX_F16) { if (g.max_len <= 20) SA(f16_t, 20); else SA(f16_t, 32); }
     else { if (g.max_len <= 20) SA(bf16_t, 20); else SA(bf16_t, 32); }
 #undef SA

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const floa
 // ---- fp32 set-attention backward, one wave per (outfit, head): recompute P = softmax(q k^T * scale), then
 // dV = P^T dO, dP = dO V^T, dS = P * (dP - rowsum(dP * P)), dQ = dS K * scale, dK = dS^T Q * scale.
 struct SetBwdK {
-    const float* qkv;   // [rows, 3D]
+    const void* qkv;    // [rows, 3D] operand type (the tape keeps q|k|v as the GEMM wrote them)
     const float* d_o;   // [rows, D]
     void* dqkv;         // [rows, 3D] operand type (feeds the dgrad / wgrad GEMMs directly)
     const int* cu;
@@ -173,10 +173,10 @@ __global__ __launch_bounds__(64) void set_attention_bwd_kernel(SetBwdK a) {
     int S = a.cu[b + 1] - r0;
     S = S < SMAX ? S : SMAX;
     for (int j = 0; j < S; ++j) {
-        const float* rp = a.qkv + (size_t)(r0 + j) * 3 * D + h * 64 + lane;
-        qs[j * STR + lane] = rp[0];
-        ks[j * STR + lane] = rp[D];
-        vs[j * STR + lane] = rp[2 * D];
+        const T* rp = (const T*)a.qkv + (size_t)(r0 + j) * 3 * D + h * 64 + lane;
+        qs[j * STR + lane] = (float)rp[0];
+        ks[j * STR + lane] = (float)rp[D];
+        vs[j * STR + lane] = (float)rp[2 * D];
         gs[j * STR + lane] = a.only_row0 ? (j == 0 ? a.d_o[(size_t)b * D + h * 64 + lane] : 0.f) : a.d_o[(size_t)(r0 + j) * D + h * 64 + lane];
     }
     __syncthreads();
@@ -371,7 +371,7 @@ int ofx_launch_ln_bwd(const float* dy, const float* x, const float* stats, const
     return OFX_OK;
 }
 
-int ofx_launch_set_attention_bwd(const float* qkv, const float* d_o, void* dqkv, const int* cu, int nseq, int n_head, int D, int max_len,
+int ofx_launch_set_attention_bwd(const void* qkv, const float* d_o, void* dqkv, const int* cu, int nseq, int n_head, int D, int max_len,
                                  float scale, int op_dtype, const DropArgs& drop, int only_row0, hipStream_t s) {
     OFX_REQUIRE(D == n_head * 64 && max_len >= 1 && max_len <= 32, OFX_ESHAPE, "set_attention_bwd: bad shape");
     SetBwdK k{qkv, d_o, dqkv, cu, n_head, D, scale, drop, only_row0};

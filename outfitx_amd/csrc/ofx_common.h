@@ -243,7 +243,7 @@ struct AttnArgs {
 int ofx_launch_attention_mfma(const AttnArgs& a, int op_dtype, hipStream_t s);
 
 struct SetAttnArgs {
-    const float* qkv;      // [rows, 3D] fp32 (q|k|v)
+    const void* qkv;       // [rows, 3D] (q|k|v): fp32, or the operand type when qkv_op (training tape)
     void* out;             // [rows, ldo]: out_kind 0 fp32 | 1 op | 2 split3
     const int* cu_seqlens; // [nseq+1] device row offsets
     int nseq, n_head, D, ldo, out_kind;
@@ -251,5 +251,6 @@ struct SetAttnArgs {
     int only_row0;         // compute query row 0 of every set only (last layer)
     float scale;
     DropArgs drop;         // attention-probability dropout (row = set * n_head + head, col = query * 32 + key)
+    int qkv_op = 0;
 };
 int ofx_launch_set_attention(const SetAttnArgs& a, int op_dtype, hipStream_t s);

@@ -6,8 +6,9 @@ loss, logits, per-parameter gradient norms, full small gradients, strided sample
 post-AdamW parameters (oracle/gen_golden.py §8).
 
 Tolerances: the step computes with single-product MFMA operands like the reference's autocast training.
-  f16  : per-parameter ||g - g_ref|| / ||g_ref|| <= 5e-3, loss 1e-3
-  bf16 : per-parameter                           <= 3e-2, loss 1e-2
+  f16  : per-parameter ||g - g_ref|| / ||g_ref|| <= 5e-3, loss / logits 2e-3
+  bf16 : per-parameter                           <= 3e-2, loss / logits 1e-2
+(q|k|v stay in the operand type between the in_proj GEMM and the attention, as under torch autocast.)
 """
 import warnings
 
@@ -46,7 +47,7 @@ def nrm(a):
     return float(np.sqrt((np.asarray(a, np.float64) ** 2).sum()))
 
 
-@pytest.mark.parametrize("prec,gtol,ltol", [("f16", 5e-3, 1e-3), ("bf16", 3e-2, 1e-2)])
+@pytest.mark.parametrize("prec,gtol,ltol", [("f16", 5e-3, 2e-3), ("bf16", 3e-2, 1e-2)])
 @pytest.mark.parametrize("fused_loss", [True, False])
 def test_cp_train_step_vs_reference_golden(prec, gtol, ltol, fused_loss):
     from src.losses import FocalLoss
@@ -284,7 +285,7 @@ def test_training_guards():
         m(task=CP, outfit_embedding=cu(emb), outfit_mask=cu(mask))
 
 
-@pytest.mark.parametrize("prec,gtol,ltol", [("f16", 5e-3, 1e-3), ("bf16", 3e-2, 1e-2)])
+@pytest.mark.parametrize("prec,gtol,ltol", [("f16", 5e-3, 2e-3), ("bf16", 3e-2, 1e-2)])
 def test_cir_train_step_vs_reference_golden(prec, gtol, ltol):
     """CIR trainer step (complementary_item_retrieval_trainer.py:73-92): y_hat = model(CIR batch) in train() mode,
     SetWiseRankingLoss(margin 2), backward — against the reference's own loss / y_hat / gradients (dropout 0)."""
