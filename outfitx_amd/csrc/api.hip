@@ -658,7 +658,7 @@ size_t carve_tape(const ofx_handle* h, Bump& b, int B, int Lq, Tape* t) {
         l.O = b.take<char>(Mp * D * 2); l.Xmid = b.take<float>(M * D); l.st2 = b.take<float>(M * 2); l.H2 = b.take<char>(Mp * D * 2);
         l.Upre = b.take<float>(M * Fp); l.A = b.take<char>(Mp * Fp * 2);
     }
-    tp.Xfinal = b.take<float>(M * D);
+    tp.Xfinal = nullptr;                   // the pruned last layer writes the prefix rows straight into row0
     tp.bytes = align_up(b.off, 256);
     if (t) *t = tp;
     return tp.bytes;
@@ -765,7 +765,7 @@ static int cp_train_fwd_core(ofx_handle* h, const SetInput& in, int B, int L, fl
     for (int l = 0; l < d.n_layers; ++l) {
         const OutfitLayer& Ly = h->ol[l];
         TapeLayer& t = T.L[l];
-        float* Xnext = l + 1 < d.n_layers ? T.L[l + 1].Xin : T.Xfinal;
+        float* Xnext = l + 1 < d.n_layers ? T.L[l + 1].Xin : nullptr;          // the last layer never reaches the full-row FFN (pruned below)
         LnArgs ln{t.Xin, nullptr, Ly.g1, Ly.be1, t.H1, M, D, D, OFX_OUT_OP, d.ln_eps}; ln.stats = t.st1;
         TRY(ofx_launch_layernorm_dev(ln, m_dev, dt, s));
         GemmArgs g1{}; g1.A = t.H1; g1.W = Ly.w_in; g1.C = t.QKV; g1.bias = Ly.b_in; g1.m_dev = m_dev; g1.M = M; g1.N = 3 * D; g1.K = D; g1.lda = D;

@@ -346,3 +346,43 @@ def test_cir_training_with_dropout_and_indexed_input_runs_and_is_reproducible():
     with torch.no_grad():
         y_eval = m(task=FITB, item_index=idx, cu_seqlens=cu_items, target_item_text_embedding=txt)
     assert not torch.equal(y_eval, outs[0][0])          # dropout was really applied in train mode
+
+
+def test_training_step_properties_at_config5_size():
+    """Size-independent properties at BASELINE config 5's per-GPU batch (256 outfits x 8 items), where no CPU reference is
+    affordable: (1) the backward is linear in the upstream gradient - doubling d loss / d logits doubles every parameter gradient
+    EXACTLY (powers of two commute with every rounding); (2) gradients of a batch = sum of the gradients of its two halves
+    (outfits are independent), to fp32 accumulation-order rounding - checked with split-K off, because a different K
+    partition re-associates the fp32 sums, which flips a few bf16 roundings of the activations, and single-product bf16 then
+    differs at its own 1e-2 noise level between batch compositions (tools/_dbg_halves2.py); (3) two runs are bit-identical
+    (deterministic reductions)."""
+    from outfitx_amd import _lib as L
+    from src.models.datatypes import OutfitCompatibilityPredictionTask as CP
+    B = 256
+    emb, mask = synth.outfit_batch(2024, B, 16, synth.ragged_lengths(2024, B, 1, 16))
+    m = make_model("bf16")
+    x, k = cu(emb), cu(mask)
+    up = torch.linspace(-1.0, 1.0, B).cuda()
+
+    def grads(sl, scale):
+        m.zero_grad(set_to_none=True)
+        y = m(task=CP, outfit_embedding=x[sl], outfit_mask=k[sl]).squeeze(-1)
+        (y * up[sl] * scale).sum().backward()
+        return {n: p.grad.clone() for n, p in trainable(m).items() if p.grad is not None}
+
+    full, full2, again = grads(slice(0, B), 1.0), grads(slice(0, B), 2.0), grads(slice(0, B), 1.0)
+    for n in full:
+        assert torch.equal(full[n], again[n]), n
+        assert torch.equal(full[n] * 2, full2[n]), n
+    L.load().ofx_tune(5, 0)
+    try:
+        full = grads(slice(0, B), 1.0)
+        lo, hi = grads(slice(0, B // 2), 1.0), grads(slice(B // 2, B), 1.0)
+    finally:
+        L.load().ofx_tune(5, 1)
+    for n in full:
+        ref = full[n].double()
+        if float(ref.norm()) < 1e-6:
+            continue                    # sum_b up_b = 0 makes the last layer's linear2 bias gradient vanish identically
+        err = float((lo[n].double() + hi[n].double() - ref).norm() / ref.norm())
+        assert err < 1e-4, (n, err)
