@@ -6,6 +6,8 @@
 
 #include <algorithm>
 #include <vector>
+#include <mutex>
+#include <cstring>
 
 #include "ofx_common.h"
 
@@ -92,12 +94,13 @@ namespace {
 
 struct Arena {                                      // library-owned HBM for packed weights
     char* base = nullptr; size_t cap = 0, off = 0;
+    bool fresh = true;                              // newly allocated: zero padding has to be written (it survives re-packs)
     int reserve(size_t bytes) {
         if (base && cap >= bytes) { off = 0; return OFX_OK; }
         if (base) (void)hipFree(base);
         base = nullptr; cap = 0; off = 0;
         OFX_HIP(hipMalloc((void**)&base, bytes));
-        cap = bytes;
+        cap = bytes; fresh = true;
         return OFX_OK;
     }
     template <typename T> T* take(size_t n) {
@@ -175,7 +178,43 @@ extern "C" void ofx_destroy(ofx_handle* h) {
 }
 
 // ------------------------------------------------------------------------------------------ pack
+// The ~60 small fp32 tensors of a pack (biases, LayerNorm parameters, tokens) travel in ONE kernel launch instead of one
+// hipMemcpyAsync each: training re-packs after every optimizer step, and 60 x 3 us of copy launches were 0.2 ms of a 4 ms step.
+// Entries are collected while a CopyBatch is active on this thread and flushed at the end of the pack call.
+int ofx_launch_multi_copy(const void* table_dev, int n, hipStream_t s);
+namespace {
+struct CopyEntry { const float* src; float* dst; long long n; };
+struct CopyBatch;
+thread_local CopyBatch* g_copy_batch = nullptr;
+struct CopyStage { char* host = nullptr; char* dev = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; std::mutex mu; };
+CopyStage g_copy_stage;
+struct CopyBatch {
+    std::vector<CopyEntry> e;
+    CopyBatch() { g_copy_batch = this; }
+    ~CopyBatch() { g_copy_batch = nullptr; }
+    int flush(hipStream_t s) {
+        g_copy_batch = nullptr;
+        if (e.empty()) return OFX_OK;
+        std::lock_guard<std::mutex> lk(g_copy_stage.mu);
+        const size_t nb = e.size() * sizeof(CopyEntry);
+        if (!g_copy_stage.ev) OFX_HIP(hipEventCreateWithFlags(&g_copy_stage.ev, hipEventDisableTiming));
+        else OFX_HIP(hipEventSynchronize(g_copy_stage.ev));           // the previous flush has consumed the staging area
+        if (g_copy_stage.cap < nb) {
+            if (g_copy_stage.host) { (void)hipHostFree(g_copy_stage.host); (void)hipFree(g_copy_stage.dev); }
+            g_copy_stage.cap = nb * 2;
+            OFX_HIP(hipHostMalloc((void**)&g_copy_stage.host, g_copy_stage.cap, hipHostMallocDefault));
+            OFX_HIP(hipMalloc((void**)&g_copy_stage.dev, g_copy_stage.cap));
+        }
+        memcpy(g_copy_stage.host, e.data(), nb);
+        OFX_HIP(hipMemcpyAsync(g_copy_stage.dev, g_copy_stage.host, nb, hipMemcpyHostToDevice, s));
+        const int rc = ofx_launch_multi_copy(g_copy_stage.dev, (int)e.size(), s);
+        OFX_HIP(hipEventRecord(g_copy_stage.ev, s));
+        return rc;
+    }
+};
+}  // namespace
 static int copy_f32(float* dst, const void* src, size_t n, hipStream_t s) {
+    if (g_copy_batch) { g_copy_batch->e.push_back({(const float*)src, dst, (long long)n}); return OFX_OK; }
     OFX_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     return OFX_OK;
 }
@@ -191,6 +230,8 @@ extern "C" int ofx_pack_outfit_weights(ofx_handle* h, const void* const* P, int 
     const size_t per_layer_t = km == 1 ? 2 * (3 * D * D + D * D + 2 * Fp * D) + 8 * 256 : 0;
     TRY(h->a_out.reserve((per_layer + per_layer_t) * d.n_layers + 2 * (km + 1) * D * D + 4 * (3 * D + 8) + 16 * 256));
     Arena& A = h->a_out;
+    const bool zero_pad = A.fresh;                  // padding written once per allocation
+    CopyBatch copies;
     const int dt = h->ot_dtype, mode = km == 3 ? 2 : 0;
     h->outfit_token = A.take<float>(D); TRY(copy_f32(h->outfit_token, P[0], D, s));
     h->tgt_img_emb = A.take<float>(D / 2); TRY(copy_f32(h->tgt_img_emb, P[1], D / 2, s));
@@ -208,7 +249,7 @@ extern "C" int ofx_pack_outfit_weights(ofx_handle* h, const void* const* P, int 
         L.w_out = A.take<char>(2 * km * D * D); TRY(ofx_launch_pack_rows((const float*)q[2], L.w_out, D, D, D, D, D, mode, dt, s));
         L.b_out = A.take<float>(D); TRY(copy_f32(L.b_out, q[3], D, s));
         L.w_1 = A.take<char>(2 * km * Fp * D); TRY(ofx_launch_pack_rows((const float*)q[4], L.w_1, F, Fp, D, D, D, mode, dt, s));
-        L.b_1 = A.take<float>(Fp); OFX_HIP(hipMemsetAsync(L.b_1, 0, Fp * 4, s)); TRY(copy_f32(L.b_1, q[5], F, s));
+        L.b_1 = A.take<float>(Fp); if (zero_pad) OFX_HIP(hipMemsetAsync(L.b_1, 0, Fp * 4, s)); TRY(copy_f32(L.b_1, q[5], F, s));
         L.w_2 = A.take<char>(2 * km * D * Fp); TRY(ofx_launch_pack_rows((const float*)q[6], L.w_2, D, D, F, Fp, F, mode, dt, s));
         L.b_2 = A.take<float>(D); TRY(copy_f32(L.b_2, q[7], D, s));
         L.g1 = A.take<float>(D); TRY(copy_f32(L.g1, q[8], D, s));
@@ -219,13 +260,15 @@ extern "C" int ofx_pack_outfit_weights(ofx_handle* h, const void* const* P, int 
         if (km == 1) {      // W^T copies for the backward dgrad GEMMs: [K_w, N_w] operand, zero padded
             L.w_in_t = A.take<char>(2 * D * 3 * D); TRY(ofx_launch_transpose_cast((const float*)q[0], L.w_in_t, (int)(3 * D), (int)D, (int)(3 * D), dt, s));
             L.w_out_t = A.take<char>(2 * D * D); TRY(ofx_launch_transpose_cast((const float*)q[2], L.w_out_t, (int)D, (int)D, (int)D, dt, s));
-            L.w_1_t = A.take<char>(2 * D * Fp); OFX_HIP(hipMemsetAsync(L.w_1_t, 0, 2 * D * Fp, s));      // [D, Fp], columns F.. stay zero
+            L.w_1_t = A.take<char>(2 * D * Fp); if (zero_pad) OFX_HIP(hipMemsetAsync(L.w_1_t, 0, 2 * D * Fp, s));      // [D, Fp], columns F.. stay zero
             TRY(ofx_launch_transpose_cast((const float*)q[4], L.w_1_t, (int)F, (int)D, (int)Fp, dt, s));
-            L.w_2_t = A.take<char>(2 * Fp * D); OFX_HIP(hipMemsetAsync(L.w_2_t, 0, 2 * Fp * D, s));      // [Fp, D], rows F.. stay zero
+            L.w_2_t = A.take<char>(2 * Fp * D); if (zero_pad) OFX_HIP(hipMemsetAsync(L.w_2_t, 0, 2 * Fp * D, s));      // [Fp, D], rows F.. stay zero
             TRY(ofx_launch_transpose_cast((const float*)q[6], L.w_2_t, (int)D, (int)F, (int)D, dt, s));
         }
     }
     OFX_REQUIRE(A.off <= A.cap, OFX_ESTATE, "pack_outfit: arena overflow");
+    TRY(copies.flush(s));
+    A.fresh = false;
     h->out_ready = true;
     return OFX_OK;
 }
@@ -254,11 +297,11 @@ static int pack_clip_layer(Arena& A, ClipLayer& L, const void* const* q, size_t 
     char* wf = A.take<char>(2 * 3 * W * W);
     L.w_qkv_f = wf; L.cs_qkv = A.take<float>(3 * W); L.bf_qkv = A.take<float>(3 * W);
     const int Wi = (int)W;
-    TRY(ofx_launch_fold_pack((const float*)q[4], L.g1, L.be1, (const float*)q[5], wf, L.cs_qkv, L.bf_qkv, Wi, Wi, dt, s));
-    TRY(ofx_launch_fold_pack((const float*)q[0], L.g1, L.be1, (const float*)q[1], wf + 2 * W * W, L.cs_qkv + W, L.bf_qkv + W, Wi, Wi, dt, s));
-    TRY(ofx_launch_fold_pack((const float*)q[2], L.g1, L.be1, (const float*)q[3], wf + 4 * W * W, L.cs_qkv + 2 * W, L.bf_qkv + 2 * W, Wi, Wi, dt, s));
+    TRY(ofx_launch_fold_pack((const float*)q[4], (const float*)q[8], (const float*)q[9], (const float*)q[5], wf, L.cs_qkv, L.bf_qkv, Wi, Wi, dt, s));
+    TRY(ofx_launch_fold_pack((const float*)q[0], (const float*)q[8], (const float*)q[9], (const float*)q[1], wf + 2 * W * W, L.cs_qkv + W, L.bf_qkv + W, Wi, Wi, dt, s));
+    TRY(ofx_launch_fold_pack((const float*)q[2], (const float*)q[8], (const float*)q[9], (const float*)q[3], wf + 4 * W * W, L.cs_qkv + 2 * W, L.bf_qkv + 2 * W, Wi, Wi, dt, s));
     L.w_fc1_f = A.take<char>(2 * MLP * W); L.cs_fc1 = A.take<float>(MLP); L.bf_fc1 = A.take<float>(MLP);
-    TRY(ofx_launch_fold_pack((const float*)q[10], L.g2, L.be2, (const float*)q[11], L.w_fc1_f, L.cs_fc1, L.bf_fc1, (int)MLP, Wi, dt, s));
+    TRY(ofx_launch_fold_pack((const float*)q[10], (const float*)q[14], (const float*)q[15], (const float*)q[11], L.w_fc1_f, L.cs_fc1, L.bf_fc1, (int)MLP, Wi, dt, s));
     return OFX_OK;
 }
 static size_t clip_layer_bytes(size_t W, size_t MLP) { return 2 * (4 * W * W + 2 * W * MLP) + 4 * (9 * W + MLP) + 2 * (3 * W * W + W * MLP) + 4 * (6 * W + 2 * MLP) + 32 * 256; }
@@ -272,6 +315,7 @@ extern "C" int ofx_pack_vision_weights(ofx_handle* h, const void* const* P, int 
     const size_t W = d.vit_width, MLP = d.vit_mlp, KP = 3 * (size_t)d.vit_patch * d.vit_patch, g = d.vit_image / d.vit_patch, S = g * g + 1, PD = d.proj_dim;
     TRY(h->a_vis.reserve(clip_layer_bytes(W, MLP) * d.vit_layers + 2 * W * KP + 2 * PD * W + 4 * (W + S * W + 4 * W) + 16 * 256));
     Arena& A = h->a_vis;
+    CopyBatch copies;
     const int dt = h->tw_dtype;
     h->v_cls = A.take<float>(W); TRY(copy_f32(h->v_cls, P[0], W, s));
     h->v_patch_w = A.take<char>(2 * W * KP); TRY(ofx_launch_pack_rows((const float*)P[1], h->v_patch_w, W, W, KP, KP, KP, 0, dt, s));
@@ -285,6 +329,7 @@ extern "C" int ofx_pack_vision_weights(ofx_handle* h, const void* const* P, int 
     h->v_post_b = A.take<float>(W); TRY(copy_f32(h->v_post_b, t[1], W, s));
     h->v_proj_w = A.take<char>(2 * PD * W); TRY(ofx_launch_pack_rows((const float*)t[2], h->v_proj_w, PD, PD, W, W, W, 0, dt, s));
     OFX_REQUIRE(A.off <= A.cap, OFX_ESTATE, "pack_vision: arena overflow");
+    TRY(copies.flush(s));
     h->vis_ready = true;
     return OFX_OK;
 }
@@ -298,6 +343,7 @@ extern "C" int ofx_pack_text_weights(ofx_handle* h, const void* const* P, int n,
     const size_t W = d.txt_width, MLP = d.txt_mlp, V = d.txt_vocab, NP = d.txt_max_pos, PD = d.proj_dim;
     TRY(h->a_txt.reserve(clip_layer_bytes(W, MLP) * d.txt_layers + 4 * (V * W + NP * W + 2 * W) + 2 * PD * W + 16 * 256));
     Arena& A = h->a_txt;
+    CopyBatch copies;
     const int dt = h->tw_dtype;
     h->t_tok = A.take<float>(V * W); TRY(copy_f32(h->t_tok, P[0], V * W, s));
     h->t_pos = A.take<float>(NP * W); TRY(copy_f32(h->t_pos, P[1], NP * W, s));
@@ -308,6 +354,7 @@ extern "C" int ofx_pack_text_weights(ofx_handle* h, const void* const* P, int n,
     h->t_fin_b = A.take<float>(W); TRY(copy_f32(h->t_fin_b, t[1], W, s));
     h->t_proj_w = A.take<char>(2 * PD * W); TRY(ofx_launch_pack_rows((const float*)t[2], h->t_proj_w, PD, PD, W, W, W, 0, dt, s));
     OFX_REQUIRE(A.off <= A.cap, OFX_ESTATE, "pack_text: arena overflow");
+    TRY(copies.flush(s));
     h->txt_ready = true;
     return OFX_OK;
 }

@@ -390,6 +390,13 @@ __global__ __launch_bounds__(256) void fold_pack_kernel(const float* Wsrc, const
     }
 }
 
+// table[i] = {src, dst, n floats}: block i copies entry i (pack time: every small fp32 tensor of a model in one launch)
+struct MultiCopyEntry { const float* src; float* dst; long long n; };
+__global__ __launch_bounds__(256) void multi_copy_kernel(const MultiCopyEntry* table) {
+    const MultiCopyEntry e = table[blockIdx.x];
+    for (long long i = threadIdx.x; i < e.n; i += 256) e.dst[i] = e.src[i];
+}
+
 // logits[b] = row0[b] . w + bias    (fp32, exact-order independent of B)
 __global__ __launch_bounds__(256) void cp_head_kernel(const float* row0, const float* w, const float* bias, float* logits, int B, int D) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -492,6 +499,11 @@ int ofx_launch_fold_pack(const float* Wsrc, const float* gamma, const float* bet
                          int N, int K, int op_dtype, hipStream_t s) {
     if (op_dtype == OFX_F16) hipLaunchKernelGGL(fold_pack_kernel<f16_t>, dim3(rows_grid(N)), dim3(256), 0, s, Wsrc, gamma, beta, bias, (f16_t*)Wf, col_sum, bias_f, N, K);
     else hipLaunchKernelGGL(fold_pack_kernel<bf16_t>, dim3(rows_grid(N)), dim3(256), 0, s, Wsrc, gamma, beta, bias, (bf16_t*)Wf, col_sum, bias_f, N, K);
+    OFX_LAUNCH_CHECK();
+    return OFX_OK;
+}
+int ofx_launch_multi_copy(const void* table_dev, int n, hipStream_t s) {
+    hipLaunchKernelGGL(multi_copy_kernel, dim3(n), dim3(256), 0, s, (const MultiCopyEntry*)table_dev);
     OFX_LAUNCH_CHECK();
     return OFX_OK;
 }
