@@ -151,13 +151,6 @@ class OutfitX(nn.Module):
         s["_engines"] = {}
         return s
 
-    def mark_weights_changed(self) -> None:
-        """Force a re-pack of the operand copies on the next call.  Needed when the parameters' STORAGE is written through
-        another tensor (trainer.FlatGrads.flatten_params_: the optimizer steps one flat tensor that aliases every parameter),
-        which does not bump the parameters' own version counters that `_engine` watches."""
-        for eng in self._engines.values():
-            eng.signature["outfit"] = None
-
     def _outfit_tensors(self) -> List[torch.Tensor]:
         out = [self.outfit_token, self.target_item_image_emb, self.cp_ffn[1].weight, self.cp_ffn[1].bias, self.cir_ffn[0].weight]
         for l in self.transformer_encoder.layers:

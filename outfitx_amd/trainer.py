@@ -44,7 +44,6 @@ class CPTrainConfig:
     div_factor: float = 25.0
     final_div_factor: float = 1e4
     fused_optimizer: bool = True      # torch.optim.AdamW(fused=True): one multi-tensor kernel per step
-    flat_parameters: bool = True      # parameters re-homed into one contiguous buffer; the optimizer steps a single tensor
 
 
 class FlatGrads:
@@ -61,21 +60,6 @@ class FlatGrads:
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         for p, o in zip(self.params, self.offsets):
             p.grad = self.flat[o:o + p.numel()].view_as(p)
-
-    def flatten_params_(self) -> torch.Tensor:
-        """Move the parameters themselves into ONE contiguous fp32 buffer (same offsets as the gradient arena): every
-        p.data becomes a view of it, so the optimizer can treat the whole model as a single tensor (`flat_param` with
-        `.grad` = the arena) - one fused AdamW kernel over 51 M elements instead of a 75-tensor multi-tensor launch.
-        Parameter objects, names, shapes and state_dict() are unchanged."""
-        buf = torch.empty_like(self.flat)
-        buf.zero_()
-        for p, o in zip(self.params, self.offsets):
-            view = buf[o:o + p.numel()].view_as(p)
-            view.copy_(p.data)
-            p.data = view
-        self.flat_param = torch.nn.Parameter(buf, requires_grad=True)
-        self.flat_param.grad = self.flat
-        return self.flat_param
 
     def zero_(self):
         self.flat.zero_()
@@ -160,8 +144,7 @@ class CPTrainer:
         self.loss_fn = loss_fn
         dev = self.grads.flat.device
         fused = c.fused_optimizer and dev.type == "cuda"
-        opt_params = [self.grads.flatten_params_()] if c.flat_parameters else self.grads.params
-        self.optimizer = torch.optim.AdamW(opt_params, lr=c.learning_rate, **({"fused": True} if fused else {}))
+        self.optimizer = torch.optim.AdamW(self.grads.params, lr=c.learning_rate, **({"fused": True} if fused else {}))
         self.scheduler = torch.optim.lr_scheduler.OneCycleLR(
             optimizer=self.optimizer, max_lr=c.learning_rate, epochs=c.n_epochs,
             steps_per_epoch=math.ceil(steps_per_epoch / c.accumulation_steps), pct_start=c.pct_start, anneal_strategy="cos",
@@ -185,8 +168,6 @@ class CPTrainer:
             self.optimizer.step()
             self.scheduler.step()
             self.grads.zero_()
-            if self.cfg.flat_parameters:         # the step wrote the parameters through the flat alias: version counters did not move
-                getattr(self.model, "mark_weights_changed", lambda: None)()
         return loss.detach(), y_hat.detach(), labels
 
     def train_epoch(self, batches: Iterable[dict]) -> Dict[str, float]:
