@@ -173,6 +173,13 @@ int ofx_cir_train_fwd(ofx_handle* h, const float* x, const uint8_t* pad_mask, co
                       size_t tape_bytes, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream);
 int ofx_cir_train_bwd(ofx_handle* h, void* tape, size_t tape_bytes, const float* dy, int B, int L, float* grads, size_t grad_floats,
                       void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream);
+/* The same backward passes writing every gradient straight into a caller tensor of the PARAMETER's own shape (linear1 [d_ffn, D],
+ * linear2 [D, d_ffn], ...): grad_ptrs = host array of 5 + 12 * n_layers device pointers in pack order (entries of tensors that are
+ * not on the path are ignored); accumulate != 0 adds to the existing contents - torch's p.grad += g without the extra kernels. */
+int ofx_cp_train_bwd_into(ofx_handle* h, void* tape, size_t tape_bytes, const float* dlogits, int B, int L, float* const* grad_ptrs,
+                          int n_ptrs, int accumulate, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream);
+int ofx_cir_train_bwd_into(ofx_handle* h, void* tape, size_t tape_bytes, const float* dy, int B, int L, float* const* grad_ptrs,
+                           int n_ptrs, int accumulate, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream);
 /* out[rows, cols] fp32 = keep-mask / (1 - p) of dropout site `site` (layer l: 4l + {0 attention [B*heads, 32*i + j], 1 dropout1,
  * 2 FFN, 3 dropout2}; 4 * n_layers = head), exactly as the kernels compute it.  Test / debugging aid. */
 int ofx_dropout_mask(float dropout_p, unsigned seed, int site, int rows, int cols, float* out, ofx_stream stream);

@@ -66,6 +66,8 @@ SIGNATURES = {
     "ofx_cp_train_bwd": (_i, [_vp, _vp, _sz, _vp, _i, _i, _vp, _sz, _vp, _sz, _f, C.c_uint, _vp]),
     "ofx_cir_train_fwd": (_i, [_vp, _vp, _vp, _vp, _i, C.c_longlong, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp, _sz, _f, C.c_uint, _vp]),
     "ofx_cir_train_bwd": (_i, [_vp, _vp, _sz, _vp, _i, _i, _vp, _sz, _vp, _sz, _f, C.c_uint, _vp]),
+    "ofx_cp_train_bwd_into": (_i, [_vp, _vp, _sz, _vp, _i, _i, C.POINTER(_vp), _i, _i, _vp, _sz, _f, C.c_uint, _vp]),
+    "ofx_cir_train_bwd_into": (_i, [_vp, _vp, _sz, _vp, _i, _i, C.POINTER(_vp), _i, _i, _vp, _sz, _f, C.c_uint, _vp]),
     "ofx_dropout_mask": (_i, [_f, C.c_uint, _i, _i, _i, _vp, _vp]),
     "ofx_focal_loss": (_i, [_vp, _vp, _i, _f, _f, _f, _vp, _vp, _vp]),
     "ofx_profile_enable": (None, [_i]),

@@ -72,17 +72,18 @@ extern "C" int ofx_profile_read(double* ms, double* flops, long long* launches) 
 int ofx_launch_transpose_cast(const float* src, void* dst, int R, int C, int ldd, int op_dtype, hipStream_t s);
 size_t ofx_colsum_part_floats(int C);
 int ofx_launch_colsum(const void* x, int x_kind, int ld, const int* gather, const float* row_scale, float* out0, float* out1, float* out2, int seg,
-                      float* part, int C, const int* m_dev, int M, int op_dtype, hipStream_t s);
+                      float* part, int C, const int* m_dev, int M, int op_dtype, hipStream_t s, int valid = 0, int accumulate = 0);
 size_t ofx_ln_bwd_part_floats(int D);
 int ofx_launch_row_map(const int* cu, int* map, int B, int M, hipStream_t s);
 int ofx_launch_ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* add, const int* add_map, float* dx_out, void* dx_op,
-                      float* dgamma, float* dbeta, float* dcols, float* part, int D, const int* m_dev, int M, int op_dtype, const DropArgs& drop, hipStream_t s);
+                      float* dgamma, float* dbeta, float* dcols, float* part, int D, const int* m_dev, int M, int op_dtype, const DropArgs& drop, hipStream_t s,
+                      int accumulate = 0);
 int ofx_launch_set_attention_bwd(const void* qkv, const float* d_o, void* dqkv, const int* cu, int nseq, int n_head, int D, int max_len,
                                  float scale, int op_dtype, const DropArgs& drop, int only_row0, hipStream_t s);
 int ofx_launch_drop_rows(float* x, int rows, int cols, const DropArgs& d, hipStream_t s);
 int ofx_launch_focal_loss(const float* logits, const float* labels, int B, float alpha, float gamma, float upstream, float* loss, float* dlogits, hipStream_t s);
 int ofx_launch_cp_head_bwd(const float* dlogits, const float* w_or_rows, const int* cu, float* dX, void* dXb, float* db, int B, int D, int op_dtype,
-                           const DropArgs& head, const DropArgs& below, hipStream_t s);
+                           const DropArgs& head, const DropArgs& below, hipStream_t s, int accumulate = 0);
 int ofx_launch_fitb(const float* y, const float* cand, int B, int C, int D, int64_t* idx, float* dist, hipStream_t s);
 int ofx_launch_l2_topk(const float* Q, const float* P, int nq, int np, int D, int k, int64_t index_base, int64_t* idx,
                        float* dist, void* ws, size_t ws_bytes, hipStream_t s);
@@ -868,8 +869,12 @@ static int cp_train_fwd_core(ofx_handle* h, const SetInput& in, int B, int L, fl
     return ofx_launch_cp_head(T.row0, h->cp_w, h->cp_b, logits, B, D, s);
 }
 
+// grads != NULL: one flat buffer in the library's padded layout (ofx_cp_train_grad_floats), overwritten.
+// grad_ptrs != NULL: one destination per packed tensor in the PARAMETER's own shape (linear1 [F, D], linear2 [D, F], ...), NULL
+// entries skipped; accumulate != 0 adds to what is there (p.grad of a torch parameter).
 static int set_train_bwd_core(ofx_handle* h, void* tape_mem, size_t tape_bytes, const float* dlogits, int B, int L, float* grads,
-                              size_t grad_floats, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream, int head);
+                              size_t grad_floats, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream, int head,
+                              float* const* grad_ptrs = nullptr, int accumulate = 0);
 extern "C" int ofx_cp_train_bwd(ofx_handle* h, void* tape_mem, size_t tape_bytes, const float* dlogits, int B, int L, float* grads,
                                 size_t grad_floats, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream) {
     return set_train_bwd_core(h, tape_mem, tape_bytes, dlogits, B, L, grads, grad_floats, ws, ws_bytes, dropout_p, seed, stream, 0);
@@ -878,10 +883,21 @@ extern "C" int ofx_cir_train_bwd(ofx_handle* h, void* tape_mem, size_t tape_byte
                                  size_t grad_floats, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream) {
     return set_train_bwd_core(h, tape_mem, tape_bytes, dy, B, L, grads, grad_floats, ws, ws_bytes, dropout_p, seed, stream, 1);
 }
+extern "C" int ofx_cp_train_bwd_into(ofx_handle* h, void* tape_mem, size_t tape_bytes, const float* dlogits, int B, int L, float* const* grad_ptrs,
+                                     int n_ptrs, int accumulate, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream) {
+    OFX_REQUIRE(h && grad_ptrs && n_ptrs == 5 + 12 * h->d.n_layers, OFX_EINVAL, "cp_train_bwd_into: expected %d destinations", h ? 5 + 12 * h->d.n_layers : 0);
+    return set_train_bwd_core(h, tape_mem, tape_bytes, dlogits, B, L, nullptr, 0, ws, ws_bytes, dropout_p, seed, stream, 0, grad_ptrs, accumulate);
+}
+extern "C" int ofx_cir_train_bwd_into(ofx_handle* h, void* tape_mem, size_t tape_bytes, const float* dy, int B, int L, float* const* grad_ptrs,
+                                      int n_ptrs, int accumulate, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream) {
+    OFX_REQUIRE(h && grad_ptrs && n_ptrs == 5 + 12 * h->d.n_layers, OFX_EINVAL, "cir_train_bwd_into: expected %d destinations", h ? 5 + 12 * h->d.n_layers : 0);
+    return set_train_bwd_core(h, tape_mem, tape_bytes, dy, B, L, nullptr, 0, ws, ws_bytes, dropout_p, seed, stream, 1, grad_ptrs, accumulate);
+}
 static int set_train_bwd_core(ofx_handle* h, void* tape_mem, size_t tape_bytes, const float* dlogits, int B, int L, float* grads,
-                              size_t grad_floats, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream, int head) {
+                              size_t grad_floats, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream, int head,
+                              float* const* grad_ptrs, int accumulate) {
     OFX_REQUIRE(h && h->out_ready && h->ot_kmul == 1, OFX_ESTATE, "cp_train_bwd: needs packed single-product weights");
-    OFX_REQUIRE(tape_mem && dlogits && grads && ws && B > 0, OFX_EINVAL, "cp_train_bwd: bad argument");
+    OFX_REQUIRE(tape_mem && dlogits && (grads || grad_ptrs) && ws && B > 0, OFX_EINVAL, "cp_train_bwd: bad argument");
     OFX_REQUIRE(d_outfit_act_is_mish(h), OFX_ESTATE, "cp_train_bwd: only the Mish activation has a backward epilogue");
     const ofx_model_desc& d = h->d;
     hipStream_t s = (hipStream_t)stream;
@@ -895,10 +911,13 @@ static int set_train_bwd_core(ofx_handle* h, void* tape_mem, size_t tape_bytes, 
     OFX_REQUIRE(wb.ok, OFX_EWORKSPACE, "cp_train_bwd: workspace %zu < %zu bytes", ws_bytes, wb.off);
     std::vector<size_t> off; size_t total;
     grad_offsets(h, off, &total);
-    OFX_REQUIRE(grad_floats >= total, OFX_EWORKSPACE, "cp_train_bwd: gradient buffer %zu < %zu floats", grad_floats, total);
-    const int D = d.d_model, Fp = h->ot_ffn_pad, dt = h->ot_dtype, M = B * (L + 1);
+    OFX_REQUIRE(grad_ptrs || grad_floats >= total, OFX_EWORKSPACE, "cp_train_bwd: gradient buffer %zu < %zu floats", grad_floats, total);
+    const int D = d.d_model, Fp = h->ot_ffn_pad, dt = h->ot_dtype, M = B * (L + 1), F = d.d_ffn;
     const int* m_dev = T.cu + B;
-    auto G = [&](int i) { return grads + off[i]; };
+    const int acc = grad_ptrs ? accumulate : 0;
+    // destination of packed tensor i; in the per-parameter form the FFN tensors have their real (unpadded) extents
+    auto G = [&](int i) -> float* { return grad_ptrs ? grad_ptrs[i] : grads + off[i]; };
+    const int Fv = grad_ptrs ? F : Fp;                 // valid rows of dW1 / entries of db1 / columns of dW2
     auto dgrad = [&](const void* A, int lda, const void* W, void* C, int ldc, int n, int k, int out_kind, int act, const float* resid, int ldr, const DropArgs& drop) {
         GemmArgs g{}; g.A = A; g.W = W; g.C = C; g.M = M; g.N = n; g.K = k; g.lda = lda; g.ldc = ldc; g.out_kind = out_kind; g.act = act; g.resid = resid; g.ldr = ldr;
         g.m_dev = m_dev; g.slab = w.slab; g.slab_bytes = w.slab_bytes; g.drop = drop;
@@ -907,8 +926,12 @@ static int set_train_bwd_core(ofx_handle* h, void* tape_mem, size_t tape_bytes, 
     auto site = [&](int l, int k) { return make_drop(dropout_p, seed, 4 * l + k); };
     const DropArgs nodrop;
     // dW[n_w, k_w] = dY[rows, n_w]^T X[rows, k_w], contraction over the live rows
-    auto wgrad = [&](const void* dY, int n_w, const void* X, int k_w, float* out) {
-        return ofx_launch_gemm_tn(dY, n_w, X, k_w, out, k_w, n_w, k_w, M, m_dev, w.slab, w.slab_bytes, dt, s);
+    // out[:mv, :nv] (row pitch ldc) of dW[n_w, k_w] = dY^T X; the per-parameter form stores only the real FFN extent
+    auto wgrad_rows = [&](int rows, const int* md, const void* dY, int n_w, const void* X, int k_w, float* out, int ldc = 0, int mv = 0, int nv = 0) {
+        return ofx_launch_gemm_tn(dY, n_w, X, k_w, out, ldc ? ldc : k_w, n_w, k_w, rows, md, w.slab, w.slab_bytes, dt, s, mv, nv, acc);
+    };
+    auto wgrad = [&](const void* dY, int n_w, const void* X, int k_w, float* out, int ldc = 0, int mv = 0, int nv = 0) {
+        return wgrad_rows(M, m_dev, dY, n_w, X, k_w, out, ldc, mv, nv);
     };
     // rows == M with m_dev: the pad-free live rows; rows == B with md == nullptr: the compacted prefix rows of the pruned last layer
     auto dgrad_rows = [&](int rows, const int* md, const void* A, int lda, const void* W, void* C, int ldc, int n, int k, int out_kind, int act, const float* resid,
@@ -917,73 +940,70 @@ static int set_train_bwd_core(ofx_handle* h, void* tape_mem, size_t tape_bytes, 
         g.m_dev = md; g.slab = w.slab; g.slab_bytes = w.slab_bytes; g.drop = drop;
         return ofx_launch_gemm(g, dt, s);
     };
-    auto wgrad_rows = [&](int rows, const int* md, const void* dY, int n_w, const void* X, int k_w, float* out) {
-        return ofx_launch_gemm_tn(dY, n_w, X, k_w, out, k_w, n_w, k_w, rows, md, w.slab, w.slab_bytes, dt, s);
-    };
     float* dX = w.dXa; float* dX2 = w.dXb_f;
     const int lastl = d.n_layers - 1;
     // ---- heads -> d row0 [B, D] (fp32, w.d_row0) and its operand copy times the last layer's dropout2 mask (w.gXb rows 0..B)
     if (head == 1) {
         // y = row0 Wc^T:  dWc = dy^T row0 (TN GEMM over the B rows), d row0 = dy Wc
         TRY(ofx_launch_pack_rows(dlogits, w.dyb, B, B, D, D, D, 0, dt, s));
-        TRY(ofx_launch_gemm_tn(w.dyb, D, T.row0b, D, G(4), D, D, D, B, nullptr, w.slab, w.slab_bytes, dt, s));
+        TRY(ofx_launch_gemm_tn(w.dyb, D, T.row0b, D, G(4), D, D, D, B, nullptr, w.slab, w.slab_bytes, dt, s, 0, 0, acc));
         GemmArgs g{}; g.A = w.dyb; g.W = h->cir_w_t; g.C = w.d_row0; g.M = B; g.N = D; g.K = D; g.lda = D; g.ldc = D; g.out_kind = OFX_OUT_F32;
         g.slab = w.slab; g.slab_bytes = w.slab_bytes;
         TRY(ofx_launch_gemm(g, dt, s));
         TRY(ofx_launch_cp_head_bwd(nullptr, w.d_row0, nullptr, w.d_row0, w.gXb, nullptr, B, D, dt, nodrop, site(lastl, 3), s));
     } else {
-        TRY(ofx_launch_cp_head_bwd(dlogits, h->cp_w, nullptr, w.d_row0, w.gXb, G(3), B, D, dt, site(d.n_layers, 0), site(lastl, 3), s));
-        TRY(ofx_launch_colsum(T.row0, 0, D, nullptr, dlogits, G(2), nullptr, nullptr, D, w.part, D, nullptr, B, dt, s));             // d cp_w = sum_b dlogit_b (row0_b . m_head)
+        TRY(ofx_launch_cp_head_bwd(dlogits, h->cp_w, nullptr, w.d_row0, w.gXb, G(3), B, D, dt, site(d.n_layers, 0), site(lastl, 3), s, acc));
+        TRY(ofx_launch_colsum(T.row0, 0, D, nullptr, dlogits, G(2), nullptr, nullptr, D, w.part, D, nullptr, B, dt, s, 0, acc));             // d cp_w = sum_b dlogit_b (row0_b . m_head)
     }
     TRY(ofx_launch_row_map(T.cu, w.rowmap, B, M, s));
     {   // ---- last layer: FFN, LayerNorm-2 and out-proj only saw the B prefix rows (compacted, static count)
         const OutfitLayer& Ly = h->ol[lastl];
         const TapeLayer& t = T.L[lastl];
         const int g0 = 5 + 12 * lastl;
-        TRY(ofx_launch_colsum(w.gXb, 1, D, nullptr, nullptr, G(g0 + 7), nullptr, nullptr, D, w.part, D, nullptr, B, dt, s));                      // db2
-        TRY(wgrad_rows(B, nullptr, w.gXb, D, t.A, Fp, G(g0 + 6)));                                                                    // dW2
+        TRY(ofx_launch_colsum(w.gXb, 1, D, nullptr, nullptr, G(g0 + 7), nullptr, nullptr, D, w.part, D, nullptr, B, dt, s, 0, acc));                      // db2
+        TRY(wgrad_rows(B, nullptr, w.gXb, D, t.A, Fp, G(g0 + 6), Fv, D, Fv));                                                                    // dW2
         TRY(dgrad_rows(B, nullptr, w.gXb, D, Ly.w_2_t, w.dU, Fp, Fp, D, OFX_OUT_OP, OFX_ACT_MISH_GRAD, t.Upre, Fp, site(lastl, 2)));  // dU
-        TRY(ofx_launch_colsum(w.dU, 1, Fp, nullptr, nullptr, G(g0 + 5), nullptr, nullptr, Fp, w.part, Fp, nullptr, B, dt, s));                    // db1
-        TRY(wgrad_rows(B, nullptr, w.dU, Fp, t.H2, D, G(g0 + 4)));                                                                    // dW1
+        TRY(ofx_launch_colsum(w.dU, 1, Fp, nullptr, nullptr, G(g0 + 5), nullptr, nullptr, Fp, w.part, Fp, nullptr, B, dt, s, Fv, acc));                    // db1
+        TRY(wgrad_rows(B, nullptr, w.dU, Fp, t.H2, D, G(g0 + 4), D, Fv, D));                                                                    // dW1
         TRY(dgrad_rows(B, nullptr, w.dU, Fp, Ly.w_1_t, w.dH, D, D, Fp, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nodrop));               // dH2
         TRY(ofx_launch_ln_bwd(w.dH, t.Xmid, t.st2, Ly.g2, w.d_row0, nullptr, dX2, w.gXb, G(g0 + 10), G(g0 + 11), G(g0 + 3), w.part, D, nullptr, B, dt,
-                              site(lastl, 1), s));                                                                                    // dXmid (B rows) + dbo
+                              site(lastl, 1), s, acc));                                                                                    // dXmid (B rows) + dbo
         TRY(wgrad_rows(B, nullptr, w.gXb, D, T.pO, D, G(g0 + 2)));                                                                    // dWo
         TRY(dgrad_rows(B, nullptr, w.gXb, D, Ly.w_out_t, w.dO, D, D, D, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nodrop));              // dO (B rows)
         TRY(ofx_launch_set_attention_bwd(t.QKV, w.dO, w.gQb, T.cu, B, d.n_head, D, L + 1, 0.125f, dt, site(lastl, 0), 1, s));         // all rows get dK, dV
-        TRY(ofx_launch_colsum(w.gQb, 1, 3 * D, nullptr, nullptr, G(g0 + 1), nullptr, nullptr, 3 * D, w.part, 3 * D, m_dev, M, dt, s));
+        TRY(ofx_launch_colsum(w.gQb, 1, 3 * D, nullptr, nullptr, G(g0 + 1), nullptr, nullptr, 3 * D, w.part, 3 * D, m_dev, M, dt, s, 0, acc));
         TRY(wgrad_rows(M, m_dev, w.gQb, 3 * D, t.H1, D, G(g0 + 0)));
         TRY(dgrad_rows(M, m_dev, w.gQb, 3 * D, Ly.w_in_t, w.dH, D, D, 3 * D, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nodrop));
         // dXin = LayerNorm-1 backward + (dXmid at the prefix rows); its column sums = bias gradient of the layer below's linear2
         TRY(ofx_launch_ln_bwd(w.dH, t.Xin, t.st1, Ly.g1, dX2, w.rowmap, dX, w.gXb, G(g0 + 8), G(g0 + 9), lastl > 0 ? G(g0 - 12 + 7) : nullptr, w.part, D, m_dev, M, dt,
-                              lastl > 0 ? site(lastl - 1, 3) : nodrop, s));
+                              lastl > 0 ? site(lastl - 1, 3) : nodrop, s, acc));
     }
     for (int l = lastl - 1; l >= 0; --l) {
         const OutfitLayer& Ly = h->ol[l];
         const TapeLayer& t = T.L[l];
         const int g0 = 5 + 12 * l;                    // Win, bin, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2
         // ---- FFN branch: Xout = Xmid + mish(H2 W1^T + b1) W2^T + b2        (gXb = operand copy of dX)
-        TRY(wgrad(w.gXb, D, t.A, Fp, G(g0 + 6)));                                                                   // dW2 [D, Fp]
+        TRY(wgrad(w.gXb, D, t.A, Fp, G(g0 + 6), Fv, D, Fv));                                                                   // dW2 [D, Fp]
         TRY(dgrad(w.gXb, D, Ly.w_2_t, w.dU, Fp, Fp, D, OFX_OUT_OP, OFX_ACT_MISH_GRAD, t.Upre, Fp, site(l, 2)));                 // dU = (dX W2) * mish'(Upre)
-        TRY(ofx_launch_colsum(w.dU, 1, Fp, nullptr, nullptr, G(g0 + 5), nullptr, nullptr, Fp, w.part, Fp, m_dev, M, dt, s));   // db1
-        TRY(wgrad(w.dU, Fp, t.H2, D, G(g0 + 4)));                                                                   // dW1 [Fp, D]
+        TRY(ofx_launch_colsum(w.dU, 1, Fp, nullptr, nullptr, G(g0 + 5), nullptr, nullptr, Fp, w.part, Fp, m_dev, M, dt, s, Fv, acc));   // db1
+        TRY(wgrad(w.dU, Fp, t.H2, D, G(g0 + 4), D, Fv, D));                                                                   // dW1 [Fp, D]
         TRY(dgrad(w.dU, Fp, Ly.w_1_t, w.dH, D, D, Fp, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nodrop));                      // dH2
-        TRY(ofx_launch_ln_bwd(w.dH, t.Xmid, t.st2, Ly.g2, dX, nullptr, dX2, w.gXb, G(g0 + 10), G(g0 + 11), G(g0 + 3), w.part, D, m_dev, M, dt, site(l, 1), s));   // dXmid (+ dbo)
+        TRY(ofx_launch_ln_bwd(w.dH, t.Xmid, t.st2, Ly.g2, dX, nullptr, dX2, w.gXb, G(g0 + 10), G(g0 + 11), G(g0 + 3), w.part, D, m_dev, M, dt, site(l, 1), s, acc));   // dXmid (+ dbo)
         // ---- attention branch: Xmid = Xin + O Wo^T + bo
         TRY(wgrad(w.gXb, D, t.O, D, G(g0 + 2)));                                                                    // dWo [D, D]
         TRY(dgrad(w.gXb, D, Ly.w_out_t, w.dO, D, D, D, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nodrop));                     // dO
         TRY(ofx_launch_set_attention_bwd(t.QKV, w.dO, w.gQb, T.cu, B, d.n_head, D, L + 1, 0.125f, dt, site(l, 0), 0, s));
-        TRY(ofx_launch_colsum(w.gQb, 1, 3 * D, nullptr, nullptr, G(g0 + 1), nullptr, nullptr, 3 * D, w.part, 3 * D, m_dev, M, dt, s));   // dbin
+        TRY(ofx_launch_colsum(w.gQb, 1, 3 * D, nullptr, nullptr, G(g0 + 1), nullptr, nullptr, 3 * D, w.part, 3 * D, m_dev, M, dt, s, 0, acc));   // dbin
         TRY(wgrad(w.gQb, 3 * D, t.H1, D, G(g0 + 0)));                                                               // dWin [3D, D]
         TRY(dgrad(w.gQb, 3 * D, Ly.w_in_t, w.dH, D, D, 3 * D, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nodrop));              // dH1
         // dXin; its column sums are the bias gradient of the layer below's linear2
         TRY(ofx_launch_ln_bwd(w.dH, t.Xin, t.st1, Ly.g1, dX2, nullptr, dX, w.gXb, G(g0 + 8), G(g0 + 9), l > 0 ? G(g0 - 12 + 7) : nullptr, w.part, D, m_dev, M, dt,
-                              l > 0 ? site(l - 1, 3) : nodrop, s));
+                              l > 0 ? site(l - 1, 3) : nodrop, s, acc));
     }
     // CIR: the prefix is [target_item_image_emb | text]: d target_item_image_emb = sum_b dX0[cu[b]][:D/2]
-    if (head == 1) return ofx_launch_colsum(dX, 0, D, T.cu, nullptr, G(1), nullptr, nullptr, D / 2, w.part, D / 2, nullptr, B, dt, s);
+    if (head == 1) return ofx_launch_colsum(dX, 0, D, T.cu, nullptr, G(1), nullptr, nullptr, D / 2, w.part, D / 2, nullptr, B, dt, s, 0, acc);
     // shared prefix token: d outfit_token = sum_b dX0[cu[b]]
-    return ofx_launch_colsum(dX, 0, D, T.cu, nullptr, G(0), nullptr, nullptr, D, w.part, D, nullptr, B, dt, s);
+    return ofx_launch_colsum(dX, 0, D, T.cu, nullptr, G(0), nullptr, nullptr, D, w.part, D, nullptr, B, dt, s, 0, acc);
 }
 
 // mask * 1/(1-p) of a dropout site as the kernels compute it (tests build a torch reference with the same masks)

@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const TI* x, int ld
     *(f32x4*)(part + (size_t)blockIdx.y * C + col) = s;
 }
 // out_k[c % seg] for c in segment k = c / seg (up to three destinations: LayerNorm's dgamma | dbeta | column sums)
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* part, int C, int nchunk, float* out0, float* out1, float* out2, int seg) {
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* part, int C, int nchunk, float* out0, float* out1, float* out2, int seg, int valid,
+                                                           int accumulate) {
     __shared__ float red[16][17];
     const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;          // 16 columns x 16 row groups per block
     const int col = blockIdx.x * 16 + cx;
@@ -76,7 +77,8 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* part, in
 #pragma unroll
         for (int k = 0; k < 16; ++k) s += red[k][cx];
         float* o = col < seg ? out0 : (col < 2 * seg ? out1 : out2);
-        if (o) o[col % seg] = s;
+        const int c = col % seg;
+        if (o && c < valid) o[c] = accumulate ? o[c] + s : s;
     }
 }
 
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(256) void focal_loss_kernel(const float* logits, co
 // layer's dropout2 (mask row = global row), like the copies LayerNorm backward emits.
 template <typename T>
 __global__ __launch_bounds__(256) void cp_head_bwd_kernel(const float* dlogits, const float* w, const int* cu, float* dX, T* dXb, float* db, int B, int D,
-                                                         DropArgs head, DropArgs below) {
+                                                         DropArgs head, DropArgs below, int accumulate) {
     typedef typename OpT<T>::v4 v4;
     const int b = blockIdx.x;
     const int r = cu ? cu[b] : b;
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(256) void cp_head_bwd_kernel(const float* dlogits, 
         red[threadIdx.x] = s;
         __syncthreads();
         for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-        if (threadIdx.x == 0) db[0] = red[0];
+        if (threadIdx.x == 0) db[0] = accumulate ? db[0] + red[0] : red[0];
     }
 }
 
@@ -343,7 +345,8 @@ int ofx_launch_transpose_cast(const float* src, void* dst, int R, int C, int ldd
 constexpr int COLSUM_MAX_CHUNKS = 256;
 size_t ofx_colsum_part_floats(int C) { return (size_t)COLSUM_MAX_CHUNKS * C; }
 int ofx_launch_colsum(const void* x, int x_kind /*0 fp32 | 1 operand type*/, int ld, const int* gather, const float* row_scale, float* out0, float* out1,
-                      float* out2, int seg, float* part, int C, const int* m_dev, int M, int op_dtype, hipStream_t s) {
+                      float* out2, int seg, float* part, int C, const int* m_dev, int M, int op_dtype, hipStream_t s, int valid, int accumulate) {
+    if (valid <= 0) valid = seg;
     OFX_REQUIRE(C % 4 == 0 && M > 0 && (ld % 4 == 0), OFX_ESHAPE, "colsum: C=%d ld=%d", C, ld);
     int nchunk = M / 16; nchunk = nchunk < 1 ? 1 : (nchunk > COLSUM_MAX_CHUNKS ? COLSUM_MAX_CHUNKS : nchunk);
     ProfScope prof(PROF_OTHER, s);
@@ -351,7 +354,7 @@ int ofx_launch_colsum(const void* x, int x_kind /*0 fp32 | 1 operand type*/, int
     if (x_kind == 0) hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ld, gather, row_scale, part, C, m_dev, M, nchunk);
     else if (op_dtype == OFX_F16) hipLaunchKernelGGL(colsum_partial_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)x, ld, gather, row_scale, part, C, m_dev, M, nchunk);
     else hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, gather, row_scale, part, C, m_dev, M, nchunk);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, C, nchunk, out0, out1, out2, seg);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, C, nchunk, out0, out1, out2, seg, valid, accumulate);
     BWD_CHECK();
     return OFX_OK;
 }
@@ -359,14 +362,15 @@ int ofx_launch_colsum(const void* x, int x_kind /*0 fp32 | 1 operand type*/, int
 constexpr int LN_BWD_BLOCKS = 256;
 size_t ofx_ln_bwd_part_floats(int D) { return (size_t)LN_BWD_BLOCKS * 3 * D; }
 int ofx_launch_ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* add, const int* add_map, float* dx_out, void* dx_op,
-                      float* dgamma, float* dbeta, float* dcols, float* part, int D, const int* m_dev, int M, int op_dtype, const DropArgs& drop, hipStream_t s) {
+                      float* dgamma, float* dbeta, float* dcols, float* part, int D, const int* m_dev, int M, int op_dtype, const DropArgs& drop, hipStream_t s,
+                      int accumulate) {
     OFX_REQUIRE(D == 512 || D == 768 || D == 1024, OFX_ESHAPE, "ln_bwd: D=%d", D);
     ProfScope prof(PROF_NORM, s);
 #define LNB(NCH, T) hipLaunchKernelGGL((ln_bwd_kernel<NCH, T>), dim3(LN_BWD_BLOCKS), dim3(256), 0, s, dy, x, stats, gamma, add, add_map, dx_out, (T*)dx_op, part, m_dev, M, drop)
     if (op_dtype == OFX_F16) { if (D == 1024) LNB(4, f16_t); else if (D == 768) LNB(3, f16_t); else LNB(2, f16_t); }
     else { if (D == 1024) LNB(4, bf16_t); else if (D == 768) LNB(3, bf16_t); else LNB(2, bf16_t); }
 #undef LNB
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((3 * D + 15) / 16), dim3(256), 0, s, part, 3 * D, LN_BWD_BLOCKS, dgamma, dbeta, dcols, D);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((3 * D + 15) / 16), dim3(256), 0, s, part, 3 * D, LN_BWD_BLOCKS, dgamma, dbeta, dcols, D, D, accumulate);
     BWD_CHECK();
     return OFX_OK;
 }
@@ -390,10 +394,10 @@ int ofx_launch_focal_loss(const float* logits, const float* labels, int B, float
     return OFX_OK;
 }
 int ofx_launch_cp_head_bwd(const float* dlogits, const float* w, const int* cu, float* dX, void* dXb, float* db, int B, int D, int op_dtype,
-                           const DropArgs& head, const DropArgs& below, hipStream_t s) {
+                           const DropArgs& head, const DropArgs& below, hipStream_t s, int accumulate) {
     OFX_REQUIRE(D % 4 == 0, OFX_ESHAPE, "cp_head_bwd: D=%d", D);
-    if (op_dtype == OFX_F16) hipLaunchKernelGGL(cp_head_bwd_kernel<f16_t>, dim3(B), dim3(256), 0, s, dlogits, w, cu, dX, (f16_t*)dXb, db, B, D, head, below);
-    else hipLaunchKernelGGL(cp_head_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, s, dlogits, w, cu, dX, (bf16_t*)dXb, db, B, D, head, below);
+    if (op_dtype == OFX_F16) hipLaunchKernelGGL(cp_head_bwd_kernel<f16_t>, dim3(B), dim3(256), 0, s, dlogits, w, cu, dX, (f16_t*)dXb, db, B, D, head, below, accumulate);
+    else hipLaunchKernelGGL(cp_head_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, s, dlogits, w, cu, dX, (bf16_t*)dXb, db, B, D, head, below, accumulate);
     BWD_CHECK();
     return OFX_OK;
 }

@@ -203,7 +203,7 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
 #endif
     KArgs k;
     k.A = (const char*)g.A; k.W = (const char*)g.W; k.C = (char*)g.C; k.bias = g.bias; k.resid = g.resid; k.aux_out = g.aux_out; k.m_dev = g.m_dev; k.dbg = g_gemm_dbg; k.skew = g_gemm_skew; k.splits = 1; k.slab = nullptr; k.m_slab = g.M; k.kt_per_split = 0;
-    k.M = g.M; k.N = g.N; k.K = g.K; k.lda = g.lda; k.ldc = g.ldc; k.ldr = g.ldr; k.act = g.act; k.out_kind = g.out_kind; k.drop = g.drop;
+    k.M = g.M; k.N = g.N; k.K = g.K; k.lda = g.lda; k.ldc = g.ldc; k.ldr = g.ldr; k.act = g.act; k.out_kind = g.out_kind; k.drop = g.drop; k.n_valid = g.N;
     k.xb_out = (char*)g.xb_out; k.stat_part = g.stat_part; k.row_stat = g.row_stat; k.col_sum = g.col_sum;
     OFX_REQUIRE(!(g.xb_out || g.stat_part) || (g.out_kind == 0 && g.N % 64 == 0), OFX_EINVAL, "gemm: LayerNorm-fold producer outputs need an fp32 output");
     OFX_REQUIRE(!g.row_stat || g.col_sum, OFX_EINVAL, "gemm: row_stat needs col_sum");

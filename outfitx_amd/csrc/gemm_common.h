@@ -30,6 +30,7 @@ struct KArgs {
     float* slab;                // [splits, M, N] partial sums when splits > 1
     DropArgs drop;
     char* xb_out; float* stat_part; const float* row_stat; const float* col_sum;   // LayerNorm folding (GemmArgs)
+    int n_valid;                // columns >= n_valid are computed but not stored (fp32 outputs of the TN kernel; = N elsewhere)
 };
 
 __device__ __forceinline__ void glds16(const char* g, OFX_LDS char* l) {
@@ -144,7 +145,7 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
             for (int it = 0; it < 4; ++it) {
                 const int gm = gm0 + pass * 16 + it * 4 + rsub;
                 dst[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (has_res && gm < p.M) dst[it] = *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn);
+                if (has_res && gm < p.M && gn < p.n_valid) dst[it] = *(const f32x4*)(p.resid + (size_t)gm * p.ldr + gn);
             }
         };
 #pragma unroll
@@ -159,7 +160,7 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
                 const int row = it * 4 + rsub;
                 const int gm = gm0 + i * 16 + row;
                 f32x4 v = *(OFX_LDS f32x4*)(ep + row * 256 + ((chunk ^ (row & 7)) << 4));
-                if (gm < p.M) {
+                if (gm < p.M && gn < p.n_valid) {
                     if (FOLD == 2) {
                         const float mu = p.row_stat[2 * (size_t)gm], rs = p.row_stat[2 * (size_t)gm + 1];
                         v = (v - *(const f32x4*)(p.col_sum + gn) * mu) * rs + bias4;
@@ -273,6 +274,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(KArgs p) {
     const size_t total = (size_t)M * n4, plane = (size_t)p.m_slab * p.N;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int gm = (int)(i / n4), gn = (int)(i % n4) * 4;
+        if (gn >= p.n_valid) continue;
         const float* sp = p.slab + (size_t)gm * p.N + gn;
         f32x4 v = *(const f32x4*)sp;
         for (int s = 1; s < p.splits; ++s) v += *(const f32x4*)(sp + s * plane);

@@ -19,6 +19,7 @@ namespace {
 struct TnArgs {
     const char* A; const char* B; float* C; float* slab; const int* k_dev;
     int M, N, K, lda, ldb, ldc, splits, tiles_m, tiles_n, nwg, group_m;
+    int m_valid, n_valid, accumulate;      // store only C[:m_valid, :n_valid] (ldc may be < N); accumulate: C += result
 };
 
 template <typename T>
@@ -161,7 +162,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(TnArgs p) {
 
     KArgs q{};
     q.C = (char*)(p.splits > 1 ? p.slab + (size_t)split * p.M * p.N : p.C);
-    q.M = p.M; q.N = p.N; q.ldc = p.splits > 1 ? p.N : p.ldc; q.out_kind = 0;
+    q.M = p.splits > 1 ? p.M : p.m_valid; q.N = p.N; q.ldc = p.splits > 1 ? p.N : p.ldc; q.out_kind = 0;
+    q.n_valid = p.splits > 1 ? p.N : p.n_valid;
+    if (p.splits == 1 && p.accumulate) { q.resid = p.C; q.ldr = p.ldc; }
     OFX_LDS char* ep = lds + 2 * STAGE + wave * EPI2_BYTES_PER_WAVE;
     epilogue2<T, OFX_ACT_NONE>(q, ep, acc, m0 + wr * 128, n0 + wc * 64, lane);
 }
@@ -188,15 +191,18 @@ size_t ofx_gemm_tn_slab_bytes(int M, int N, int K) {
     return s > 1 ? (size_t)s * M * N * 4 : 0;
 }
 int ofx_launch_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K, const int* k_dev,
-                       void* slab, size_t slab_bytes, int op_dtype, hipStream_t s) {
+                       void* slab, size_t slab_bytes, int op_dtype, hipStream_t s, int m_valid, int n_valid, int accumulate) {
+    if (m_valid <= 0) m_valid = M;
+    if (n_valid <= 0) n_valid = N;
     OFX_REQUIRE(M > 0 && N > 0 && K > 0, OFX_ESHAPE, "gemm_tn: empty problem M=%d N=%d K=%d", M, N, K);
     OFX_REQUIRE(M % 256 == 0 && N % 256 == 0, OFX_ESHAPE, "gemm_tn: M=%d and N=%d must be multiples of 256", M, N);
-    OFX_REQUIRE(lda >= M && ldb >= N && lda % 8 == 0 && ldb % 8 == 0 && ldc >= N && ldc % 4 == 0, OFX_ESHAPE, "gemm_tn: bad leading dimension");
+    OFX_REQUIRE(lda >= M && ldb >= N && lda % 8 == 0 && ldb % 8 == 0 && ldc >= n_valid && ldc % 4 == 0 && n_valid % 4 == 0 && m_valid <= M && n_valid <= N, OFX_ESHAPE,
+                "gemm_tn: bad leading dimension / valid extent");
     OFX_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0), OFX_EINVAL, "gemm_tn: operands must be 16-byte aligned");
     OFX_REQUIRE(op_dtype == OFX_BF16 || op_dtype == OFX_F16, OFX_EINVAL, "gemm_tn: operand dtype must be bf16 or f16");
     TnArgs t;
     t.A = (const char*)A; t.B = (const char*)B; t.C = C; t.slab = (float*)slab; t.k_dev = k_dev;
-    t.M = M; t.N = N; t.K = K; t.lda = lda; t.ldb = ldb; t.ldc = ldc;
+    t.M = M; t.N = N; t.K = K; t.lda = lda; t.ldb = ldb; t.ldc = ldc; t.m_valid = m_valid; t.n_valid = n_valid; t.accumulate = accumulate;
     t.splits = slab ? ofx_gemm_tn_splits(M, N, K) : 1;
     if (t.splits > 1) OFX_REQUIRE(slab_bytes >= (size_t)t.splits * M * N * 4, OFX_EWORKSPACE, "gemm_tn: split-K slab too small");
     t.tiles_m = M / 256; t.tiles_n = N / 256; t.nwg = t.tiles_m * t.tiles_n * t.splits; t.group_m = 4;
@@ -212,7 +218,9 @@ int ofx_launch_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C,
     else hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, dim3(t.nwg), dim3(512), LDSB, s, t);
     if (t.splits > 1) {
         KArgs k{};
-        k.C = (char*)C; k.M = M; k.N = N; k.ldc = ldc; k.out_kind = 0; k.act = OFX_ACT_NONE; k.splits = t.splits; k.slab = (float*)slab; k.m_slab = M;
+        k.C = (char*)C; k.M = m_valid; k.N = N; k.ldc = ldc; k.out_kind = 0; k.act = OFX_ACT_NONE; k.splits = t.splits; k.slab = (float*)slab; k.m_slab = M;
+        k.n_valid = n_valid;
+        if (accumulate) { k.resid = C; k.ldr = ldc; }
         size_t tot = (size_t)M * (N / 4);
         int rg = (int)((tot + 255) / 256); if (rg > 2048) rg = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(rg), dim3(256), 0, s, k);

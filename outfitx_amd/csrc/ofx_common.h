@@ -206,7 +206,7 @@ struct LnArgs {
 int ofx_gemm_tn_splits(int M, int N, int K);
 size_t ofx_gemm_tn_slab_bytes(int M, int N, int K);
 int ofx_launch_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K, const int* k_dev,
-                       void* slab, size_t slab_bytes, int op_dtype, hipStream_t s);
+                       void* slab, size_t slab_bytes, int op_dtype, hipStream_t s, int m_valid = 0, int n_valid = 0, int accumulate = 0);
 int ofx_launch_layernorm(const LnArgs& a, int op_dtype, hipStream_t s);
 int ofx_launch_layernorm_dev(const LnArgs& a, const int* rows_dev, int op_dtype, hipStream_t s);
 int ofx_launch_pack_rows(const float* src, void* dst, int rows_src, int rows_dst, int K_src, int K_dst, int ld_src,

@@ -250,6 +250,19 @@ class Engine:
                                               _ptr(ws), ws.numel(), float(dropout_p), int(seed) & 0xFFFFFFFF, _stream(self.device)), "ofx_cp_train_bwd")
         return g
 
+    def train_bwd_into(self, head: str, tape: torch.Tensor, dhead: torch.Tensor, B: int, Lq: int, dests, accumulate: bool,
+                       dropout_p: float = 0.0, seed: int = 0) -> None:
+        """Backward of the CP ('cp') or CIR ('cir') path writing every gradient straight into `dests` (one fp32 contiguous
+        tensor of the parameter's shape per packed tensor, None for tensors off the path) - p.grad += g without the 75
+        accumulate kernels of autograd."""
+        ptrs = (C.c_void_p * len(dests))(*[None if t is None else t.data_ptr() for t in dests])
+        d = _f32c(dhead, self.device)
+        ws = self.workspace(int(self.lib.ofx_cp_train_ws_bytes(self.h, B, Lq)))
+        fn = self.lib.ofx_cp_train_bwd_into if head == "cp" else self.lib.ofx_cir_train_bwd_into
+        with torch.cuda.device(self.device):
+            L.check(fn(self.h, _ptr(tape), tape.numel(), _ptr(d), B, Lq, ptrs, len(dests), int(accumulate), _ptr(ws), ws.numel(),
+                       float(dropout_p), int(seed) & 0xFFFFFFFF, _stream(self.device)), f"ofx_{head}_train_bwd_into")
+
     # ---------------------------------------------------------------- towers
     def vit(self, pixels: torch.Tensor, out: torch.Tensor, col: int, normalize: bool) -> None:
         """pixels [N,3,H,W] fp32 pixel_values -> out[:, col:col+512] (out is [N, ld] fp32 contiguous)."""

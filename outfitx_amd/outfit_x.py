@@ -54,17 +54,38 @@ class _CPTrainFn(torch.autograd.Function):
             bl = (x.shape[0], x.shape[1])
         ctx.eng, ctx.tape, ctx.bl, ctx.F, ctx.drop = eng, tape, bl, F, drop
         ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.params = params if getattr(eng, "grad_sink", False) else None
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
         eng = ctx.eng
         B, Lq = ctx.bl
+        dests = _sink_dests(ctx.params, (1, 4)) if ctx.params is not None else None
+        if dests is not None:
+            eng.train_bwd_into("cp", ctx.tape, dlogits.contiguous(), B, Lq, dests, True, *ctx.drop)
+            ctx.tape = None
+            return (None,) * (5 + len(ctx.shapes))
         g = eng.cp_train_bwd(ctx.tape, dlogits.contiguous(), B, Lq, *ctx.drop)
         ctx.tape = None
         _, offs = eng.grad_layout()
         out = _grad_views(g, offs, ctx.shapes, eng.desc.d_model, ctx.F, skip=(1, 4))   # target_item_image_emb, cir_ffn: not on the CP path
         return (None, None, None, None, None, *out)
+
+
+def _sink_dests(params, skip):
+    """Gradient-sink mode (OutfitX.grad_sink, set by trainer.CPTrainer): every parameter on the path already owns a dense fp32
+    .grad on its own device -> the backward kernels add into those buffers directly."""
+    dests = []
+    for i, p in enumerate(params):
+        if i in skip:
+            dests.append(None)
+            continue
+        g = p.grad
+        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device or not p.requires_grad:
+            return None
+        dests.append(g)
+    return dests
 
 
 def _grad_views(g, offs, shapes, D, F, skip):
@@ -98,11 +119,17 @@ class _CIRTrainFn(torch.autograd.Function):
         y, tape, bl = eng.cir_train_fwd(setin, txt, *drop)
         ctx.eng, ctx.tape, ctx.bl, ctx.F, ctx.drop = eng, tape, bl, F, drop
         ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.params = params if getattr(eng, "grad_sink", False) else None
         return y
 
     @staticmethod
     def backward(ctx, dy):
         eng = ctx.eng
+        dests = _sink_dests(ctx.params, (0, 2, 3)) if ctx.params is not None else None
+        if dests is not None:
+            eng.train_bwd_into("cir", ctx.tape, dy.contiguous(), *ctx.bl, dests, True, *ctx.drop)
+            ctx.tape = None
+            return (None,) * (5 + len(ctx.shapes))
         g = eng.cir_train_bwd(ctx.tape, dy.contiguous(), *ctx.bl, *ctx.drop)
         ctx.tape = None
         _, offs = eng.grad_layout()
@@ -236,6 +263,7 @@ class OutfitX(nn.Module):
         if isinstance(outfit_embedding, torch.Tensor) and outfit_embedding.requires_grad:
             raise NotImplementedError("gradients w.r.t. the item embeddings (encoder fine-tuning) are not built")
         eng = self._engine(self.train_precision)
+        eng.grad_sink = bool(getattr(self, "grad_sink", False))
         # dropout masks are hash(seed, site, element); the seed is drawn from torch's global generator, so
         # torch.manual_seed() makes a run reproducible (same distribution as torch's dropout, not the same stream)
         p = float(t.dropout)
@@ -259,8 +287,9 @@ class OutfitX(nn.Module):
             p = float(t.dropout)
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0.0 else 0
             self.last_dropout = (p, seed)
-            return _CIRTrainFn.apply(self._engine(self.train_precision), setin, target_item_text_embedding, t.d_ffn, (p, seed),
-                                     *self._outfit_tensors())
+            eng = self._engine(self.train_precision)
+            eng.grad_sink = bool(getattr(self, "grad_sink", False))
+            return _CIRTrainFn.apply(eng, setin, target_item_text_embedding, t.d_ffn, (p, seed), *self._outfit_tensors())
         eng = self._engine()
         prefix = eng.cir_prefix(target_item_text_embedding)
         if item_index is not None:

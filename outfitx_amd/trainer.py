@@ -151,6 +151,10 @@ class CPTrainer:
             div_factor=c.div_factor, final_div_factor=c.final_div_factor)
         self.steps_per_epoch = steps_per_epoch
         self.last_grad_norm: Optional[torch.Tensor] = None
+        # outfitx_amd.OutfitX: let the backward kernels add straight into the arena views (no per-tensor accumulate kernels);
+        # valid because nothing here relies on autograd hooks (DDP would)
+        if hasattr(model, "_cp_train_forward"):
+            model.grad_sink = True
 
     def micro_step(self, batch: dict, step: int):
         """One micro-batch: forward, loss / accumulation_steps, backward; optimizer step on the accumulation boundary.

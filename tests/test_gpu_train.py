@@ -386,3 +386,40 @@ def test_training_step_properties_at_config5_size():
             continue                    # sum_b up_b = 0 makes the last layer's linear2 bias gradient vanish identically
         err = float((lo[n].double() + hi[n].double() - ref).norm() / ref.norm())
         assert err < 1e-4, (n, err)
+
+
+@pytest.mark.parametrize("task", ["cp", "cir"])
+def test_gradient_sink_equals_autograd_accumulation(task):
+    """trainer.FlatGrads + OutfitX.grad_sink: the backward kernels add straight into the arena views (parameter-shaped
+    destinations, real FFN extents, C += result in the GEMM / reduce epilogues) - bit-identical to letting autograd accumulate
+    the returned gradients, over two accumulated micro-batches with different batch shapes."""
+    from outfitx_amd.trainer import FlatGrads
+    from src.models.datatypes import OutfitCompatibilityPredictionTask as CP, OutfitComplementaryItemRetrievalTask as CIR
+    batches = []
+    for seed, n in ((61, [3, 9, 1, 16, 5]), (62, [8, 8, 2])):
+        emb, mask = synth.outfit_batch(seed, len(n), 16, np.array(n))
+        batches.append((cu(emb), cu(mask), cu(synth.unit_rows(seed, "t", len(n), 512)), torch.linspace(-1.0, 2.0, len(n)).cuda()))
+    results = []
+    for sink in (True, False):
+        m = make_model("bf16")
+        params = list(trainable(m).values())
+        if sink:
+            fg = FlatGrads(params)
+            m.grad_sink = True
+        for emb, mask, txt, up in batches:
+            if task == "cp":
+                (m(task=CP, outfit_embedding=emb, outfit_mask=mask).squeeze(-1) * up).sum().backward()
+            else:
+                (m(task=CIR, outfit_embedding=emb, outfit_mask=mask, target_item_text_embedding=txt) * up[:, None]).sum().backward()
+        results.append({k: (None if p.grad is None else p.grad.clone()) for k, p in trainable(m).items()})
+        if sink:
+            on_path = [k for k, p in trainable(m).items() if p.grad is not None and p.grad.abs().sum() > 0]
+            assert all(p.grad.data_ptr() >= fg.flat.data_ptr() for p in params)          # still the arena views
+    a, b = results
+    off_path = {"cp": ("target_item_image_emb", "cir_ffn.0.weight"), "cir": ("outfit_token", "cp_ffn.1.weight", "cp_ffn.1.bias")}[task]
+    for k in b:
+        if k in off_path:
+            assert b[k] is None and not a[k].any(), k                                    # untouched zeros in the arena
+        else:
+            assert torch.equal(a[k], b[k]), k
+    assert len(on_path) == len(b) - len(off_path)
