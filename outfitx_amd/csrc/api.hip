@@ -542,6 +542,7 @@ extern "C" int ofx_cir_prefix(ofx_handle* h, const float* txt, int B, float* out
 // ------------------------------------------------------------------------------------ CLIP towers
 // One CLIP encoder layer on `rows` rows.  When `pool_idx` is given (last layer) everything after the attention
 // runs only on the n pooled rows (CLS / EOS): they are the only ones the tower's output depends on.
+int g_train_mfma_attn = 1;   // ofx_tune(7, v): training forward uses the MFMA varlen attention (1) or the fp32 set kernel (0)
 int g_ln_fold = 1;      // ofx_tune(6, v): 0 = materialise every LayerNorm, 1 = fold the towers' LayerNorms into the GEMM epilogues
 
 // fold == true: on entry w.XB / w.S hold the operand copy and the (mean, rstd) of X; on exit (non-pooled layers) they hold
@@ -820,9 +821,15 @@ static int cp_train_fwd_core(ofx_handle* h, const SetInput& in, int B, int L, fl
         g1.ldc = 3 * D; g1.out_kind = OFX_OUT_OP; g1.slab = w.slab; g1.slab_bytes = w.slab_bytes;      // q|k|v kept in the operand type
         TRY(ofx_launch_gemm(g1, dt, s));
         const bool last = l + 1 == d.n_layers;
-        SetAttnArgs sa{t.QKV, t.O, T.cu, B, d.n_head, D, D, OFX_OUT_OP, L + 1, last ? 1 : 0, 0.125f};
-        sa.drop = make_drop(dropout_p, seed, 4 * l + 0); sa.qkv_op = 1;
-        TRY(ofx_launch_set_attention(sa, dt, s));
+        if (g_train_mfma_attn) {           // varlen MFMA attention on the operand-type q|k|v (probabilities rounded to the operand type, as autocast SDPA does)
+            AttnArgs at{t.QKV, t.O, nullptr, B, L + 1, d.n_head, 3 * D, D, D, 2 * D, 0, 0, 0.125f};
+            at.cu_seqlens = T.cu; at.only_row0 = last ? 1 : 0; at.drop = make_drop(dropout_p, seed, 4 * l + 0);
+            TRY(ofx_launch_attention_mfma(at, dt, s));
+        } else {
+            SetAttnArgs sa{t.QKV, t.O, T.cu, B, d.n_head, D, D, OFX_OUT_OP, L + 1, last ? 1 : 0, 0.125f};
+            sa.drop = make_drop(dropout_p, seed, 4 * l + 0); sa.qkv_op = 1;
+            TRY(ofx_launch_set_attention(sa, dt, s));
+        }
         if (last) {
             // Only the prefix row of every outfit feeds the heads (outfit_x.py:142,170): out-proj, LayerNorm-2 and the FFN of the last
             // layer run on those B rows (compacted: row b of the Xmid / st2 / H2 / Upre / A tape buffers; dropout rows = b).
@@ -1036,6 +1043,7 @@ extern "C" int ofx_tune(int knob, int value) {
         case 4: g_gemm_pref = value; return OFX_OK;
         case 5: g_gemm_splitk = value; return OFX_OK;
         case 6: g_ln_fold = value; return OFX_OK;
+        case 7: g_train_mfma_attn = value; return OFX_OK;
         default: ofx_set_error("ofx_tune: unknown knob %d", knob); return OFX_EINVAL;
     }
 }

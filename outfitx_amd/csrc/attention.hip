@@ -21,6 +21,9 @@ struct AttnK {
     const int64_t* key_mask;
     int nseq, S, n_head, ld, ldo, k_off, v_off, mask_ld, causal;
     float scale;
+    const int* cu;          // optional varlen mode (outfit sets): sequence b = rows cu[b] .. cu[b+1], at most 16 * NT of them
+    int only_row0;          // varlen mode: compute and store query row 0 only (pruned last layer)
+    DropArgs drop;          // varlen mode: attention-probability dropout (row = seq * n_head + head, col = query * 32 + key)
 };
 
 constexpr int V_ROW = 160;                 // bytes per V row in LDS (64 x 2 B + 32 pad): tr-read conflict-free
@@ -37,8 +40,9 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnK a) {
     const bool live = pair_raw < npairs;           // wave-uniform; dead waves recompute the last pair and store nothing
     const int pair = live ? pair_raw : npairs - 1;
     const int seq = pair / a.n_head, head = pair % a.n_head;
-    const int S = a.S;
-    const T* base = (const T*)a.qkv + (size_t)seq * S * a.ld + head * 64;
+    const int row_first = a.cu ? a.cu[seq] : seq * a.S;
+    const int S = a.cu ? min(a.cu[seq + 1] - row_first, 16 * NT) : a.S;
+    const T* base = (const T*)a.qkv + (size_t)row_first * a.ld + head * 64;
     const int r16 = lane & 15, q4 = lane >> 4;
 
     // ---- V -> LDS, zero rows beyond S (0 * garbage must stay 0)
@@ -122,6 +126,12 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnK a) {
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
+        if (a.drop.thresh) {            // dropout on the probabilities (training): same (row, col) counters as the fp32 set kernel
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[t][u][r] *= drop_mul(a.drop, pair, query * 32 + 16 * t + 4 * q4 + r);
+        }
         // P fragment of k-step ks: element j <-> key 16(2ks + (j>>2)) + 4q4 + (j&3)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
@@ -159,8 +169,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnK a) {
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
             const int query = 16 * u + r16;
-            if (query < S) {
-                T* op = (T*)a.out + (size_t)(seq * S + query) * a.ldo + head * 64 + 4 * q4;
+            if (query < (a.only_row0 ? 1 : S)) {
+                T* op = (T*)a.out + (size_t)(row_first + query) * a.ldo + head * 64 + 4 * q4;
 #pragma unroll
                 for (int nd = 0; nd < 4; ++nd) {
                     v4 o;
@@ -259,7 +269,7 @@ int ofx_launch_attention_mfma(const AttnArgs& g, int op_dtype, hipStream_t s) {
     AttnK k;
     k.qkv = (const char*)g.qkv; k.out = (char*)g.out; k.key_mask = g.key_mask; k.nseq = g.nseq; k.S = g.seq_len;
     k.n_head = g.n_head; k.ld = g.ld; k.ldo = g.ldo; k.k_off = g.k_off; k.v_off = g.v_off; k.mask_ld = g.mask_ld;
-    k.causal = g.causal; k.scale = g.scale;
+    k.causal = g.causal; k.scale = g.scale; k.cu = g.cu_seqlens; k.only_row0 = g.only_row0; k.drop = g.drop;
     const int grid = (g.nseq * g.n_head + 3) / 4;
     ProfScope prof(PROF_ATTN, s);
 #define AT(T, N) hipLaunchKernelGGL((attention_mfma_kernel<T, N>), dim3(grid), dim3(256), 0, s, k)

@@ -239,6 +239,10 @@ struct AttnArgs {
     int nseq, seq_len, n_head, ld, ldo, k_off, v_off, mask_ld;
     int causal;
     float scale;
+    // varlen mode (outfit sets, training): sequence b = rows cu_seqlens[b] .. cu_seqlens[b+1] (at most seq_len <= 32 of them)
+    const int* cu_seqlens = nullptr;
+    int only_row0 = 0;
+    DropArgs drop;
 };
 int ofx_launch_attention_mfma(const AttnArgs& a, int op_dtype, hipStream_t s);
 
