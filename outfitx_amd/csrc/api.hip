@@ -80,6 +80,8 @@ int ofx_launch_ln_bwd(const float* dy, const float* x, const float* stats, const
                       int accumulate = 0);
 int ofx_launch_set_attention_bwd(const void* qkv, const float* d_o, void* dqkv, const int* cu, int nseq, int n_head, int D, int max_len,
                                  float scale, int op_dtype, const DropArgs& drop, int only_row0, hipStream_t s);
+int ofx_launch_set_attention_bwd_mfma(const void* qkv, const float* d_o, void* dqkv, const int* cu, int nseq, int n_head, int D, int max_len,
+                                      float scale, int op_dtype, const DropArgs& drop, int only_row0, hipStream_t s);
 int ofx_launch_drop_rows(float* x, int rows, int cols, const DropArgs& d, hipStream_t s);
 int ofx_launch_focal_loss(const float* logits, const float* labels, int B, float alpha, float gamma, float upstream, float* loss, float* dlogits, hipStream_t s);
 int ofx_launch_cp_head_bwd(const float* dlogits, const float* w_or_rows, const int* cu, float* dX, void* dXb, float* db, int B, int D, int op_dtype,
@@ -977,7 +979,8 @@ static int set_train_bwd_core(ofx_handle* h, void* tape_mem, size_t tape_bytes, 
                               site(lastl, 1), s, acc));                                                                                    // dXmid (B rows) + dbo
         TRY(wgrad_rows(B, nullptr, w.gXb, D, T.pO, D, G(g0 + 2)));                                                                    // dWo
         TRY(dgrad_rows(B, nullptr, w.gXb, D, Ly.w_out_t, w.dO, D, D, D, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nodrop));              // dO (B rows)
-        TRY(ofx_launch_set_attention_bwd(t.QKV, w.dO, w.gQb, T.cu, B, d.n_head, D, L + 1, 0.125f, dt, site(lastl, 0), 1, s));         // all rows get dK, dV
+        TRY((g_train_mfma_attn ? ofx_launch_set_attention_bwd_mfma : ofx_launch_set_attention_bwd)(t.QKV, w.dO, w.gQb, T.cu, B, d.n_head, D, L + 1, 0.125f, dt,
+                                                                                                     site(lastl, 0), 1, s));    // all rows get dK, dV
         TRY(ofx_launch_colsum(w.gQb, 1, 3 * D, nullptr, nullptr, G(g0 + 1), nullptr, nullptr, 3 * D, w.part, 3 * D, m_dev, M, dt, s, 0, acc));
         TRY(wgrad_rows(M, m_dev, w.gQb, 3 * D, t.H1, D, G(g0 + 0)));
         TRY(dgrad_rows(M, m_dev, w.gQb, 3 * D, Ly.w_in_t, w.dH, D, D, 3 * D, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nodrop));
@@ -999,7 +1002,7 @@ static int set_train_bwd_core(ofx_handle* h, void* tape_mem, size_t tape_bytes, 
         // ---- attention branch: Xmid = Xin + O Wo^T + bo
         TRY(wgrad(w.gXb, D, t.O, D, G(g0 + 2)));                                                                    // dWo [D, D]
         TRY(dgrad(w.gXb, D, Ly.w_out_t, w.dO, D, D, D, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nodrop));                     // dO
-        TRY(ofx_launch_set_attention_bwd(t.QKV, w.dO, w.gQb, T.cu, B, d.n_head, D, L + 1, 0.125f, dt, site(l, 0), 0, s));
+        TRY((g_train_mfma_attn ? ofx_launch_set_attention_bwd_mfma : ofx_launch_set_attention_bwd)(t.QKV, w.dO, w.gQb, T.cu, B, d.n_head, D, L + 1, 0.125f, dt, site(l, 0), 0, s));
         TRY(ofx_launch_colsum(w.gQb, 1, 3 * D, nullptr, nullptr, G(g0 + 1), nullptr, nullptr, 3 * D, w.part, 3 * D, m_dev, M, dt, s, 0, acc));   // dbin
         TRY(wgrad(w.gQb, 3 * D, t.H1, D, G(g0 + 0)));                                                               // dWin [3D, D]
         TRY(dgrad(w.gQb, 3 * D, Ly.w_in_t, w.dH, D, D, 3 * D, OFX_OUT_F32, OFX_ACT_NONE, nullptr, 0, nodrop));              // dH1

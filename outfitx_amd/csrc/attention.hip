@@ -259,6 +259,229 @@ __global__ __launch_bounds__(64) void set_attention_kernel(SetK a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the varlen set attention on MFMA (training step).  One wave per (outfit, head), S <= 16 * NT rows.
+// Both orientations of the score tile are formed on the matrix core - T: [key][query] (as the forward), N: [query][key] -
+// because each of the three output products contracts over the ROW index of a C-layout tile (guide: "an accumulator tile as
+// the next MFMA's operand"):
+//   dQ^T[d][q] = sum_k  K^T[d][k]  dS^T[k][q]      (B operand = dS in T orientation,   A = K^T by transposed LDS reads)
+//   dK^T[d][k] = sum_q  Q^T[d][q]  dS  [q][k]      (B operand = dS in N orientation,   A = Q^T)
+//   dV^T[d][k] = sum_q dO^T[d][q]  P~  [q][k]      (B operand = dropped-out P in N,    A = dO^T)
+// with P = softmax(q k^T * scale), P~ = P . m (dropout mask), dP = (dO V^T) . m, dS = P . (dP - rowsum(P . dP)) * scale.
+// Per-query softmax statistics are computed once in the T orientation (in-lane + 2 shuffles) and permuted to the lanes that
+// own those queries in the N orientation.
+struct AttnBwdK {
+    const char* qkv;        // [rows, 3D] operand type (tape)
+    const float* d_o;       // [rows, D] fp32, or [nseq, D] when only_row0
+    char* dqkv;             // [rows, 3D] operand type
+    const int* cu;
+    int nseq, n_head, D, only_row0;
+    float scale;
+    DropArgs drop;
+};
+
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void set_attention_bwd_mfma_kernel(AttnBwdK a) {
+    typedef typename OpT<T>::v8 v8;
+    typedef typename OpT<T>::v4 v4;
+    constexpr int KS = (NT + 1) / 2, VROWS = 32 * KS, VT = VROWS * V_ROW;
+    __shared__ __attribute__((aligned(16))) char smem[4 * 3 * VT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int npairs = a.nseq * a.n_head;
+    const int pair_raw = blockIdx.x * 4 + wave;
+    const bool live = pair_raw < npairs;
+    const int pair = live ? pair_raw : npairs - 1;
+    const int seq = pair / a.n_head, head = pair % a.n_head;
+    const int D = a.D, ld = 3 * D;
+    const int row_first = a.cu[seq];
+    const int S = min(a.cu[seq + 1] - row_first, 16 * NT);
+    const T* base = (const T*)a.qkv + (size_t)row_first * ld + head * 64;
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const int n_go = a.only_row0 ? 1 : S;                         // queries that carry an upstream gradient
+
+    // ---- K, Q and dO (converted) -> LDS row images for the transposed reads; rows >= S (dO: >= n_go) are zero
+    OFX_LDS char* kl = (OFX_LDS char*)smem + wave * 3 * VT;
+    OFX_LDS char* ql = kl + VT;
+    OFX_LDS char* gl = ql + VT;
+#pragma unroll
+    for (int it = 0; it < VROWS / 8; ++it) {
+        const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+        v8 kv, qv, gv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { kv[e] = (T)0.0f; qv[e] = (T)0.0f; gv[e] = (T)0.0f; }
+        if (row < S) {
+            kv = *(const v8*)(base + (size_t)row * ld + D + c8);
+            qv = *(const v8*)(base + (size_t)row * ld + c8);
+        }
+        if (row < n_go) {
+            const float* gp = a.d_o + (size_t)(a.only_row0 ? seq : row_first + row) * D + head * 64 + c8;
+            const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { gv[e] = (T)g0[e]; gv[4 + e] = (T)g1[e]; }
+        }
+        *(OFX_LDS v8*)(kl + row * V_ROW + (lane & 7) * 16) = kv;
+        *(OFX_LDS v8*)(ql + row * V_ROW + (lane & 7) * 16) = qv;
+        *(OFX_LDS v8*)(gl + row * V_ROW + (lane & 7) * 16) = gv;
+    }
+
+    // ---- row fragments (A or B operand with k = feature): K, Q, V from global (rows clamped), dO converted, zero for dead queries
+    v8 kf[NT][2], qf[NT][2], vf[NT][2], gf[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int rowu = 16 * t + r16;
+        const int row = rowu < S ? rowu : S - 1;
+        const T* rp = base + (size_t)row * ld + q4 * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[t][ks] = *(const v8*)(rp + ks * 32);
+            kf[t][ks] = *(const v8*)(rp + D + ks * 32);
+            vf[t][ks] = *(const v8*)(rp + 2 * D + ks * 32);
+            v8 g;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = (T)0.0f;
+            if (rowu < n_go) {
+                const float* gp = a.d_o + (size_t)(a.only_row0 ? seq : row_first + rowu) * D + head * 64 + q4 * 8 + ks * 32;
+                const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { g[e] = (T)g0[e]; g[4 + e] = (T)g1[e]; }
+            }
+            gf[t][ks] = g;
+        }
+    }
+
+    // ---- scores and dP in both orientations
+    f32x4 sT[NT][NT], sN[NT][NT], pT[NT][NT], pN[NT][NT];       // sT[t][u]: row = key 16t+4q4+r, col = query 16u+r16; sN[u][t]: row = query, col = key
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            sT[t][u] = OpT<T>::mfma16(kf[t][1], qf[u][1], OpT<T>::mfma16(kf[t][0], qf[u][0], z));
+            sN[u][t] = OpT<T>::mfma16(qf[u][1], kf[t][1], OpT<T>::mfma16(qf[u][0], kf[t][0], z));
+            pT[t][u] = OpT<T>::mfma16(vf[t][1], gf[u][1], OpT<T>::mfma16(vf[t][0], gf[u][0], z));     // dP^T[key][query] = V . dO^T
+            pN[u][t] = OpT<T>::mfma16(gf[u][1], vf[t][1], OpT<T>::mfma16(gf[u][0], vf[t][0], z));     // dP[query][key]
+        }
+
+    // ---- T orientation: softmax per query column, dS^T; per-query statistics kept for the N orientation
+    const float sc = a.scale * 1.4426950408889634f;
+    float q_max[NT], q_inv[NT], q_dot[NT];                          // of query 16u + r16 (same value in the 4 lanes q4 = 0..3)
+    v8 dsT[NT][KS];                                                 // B operand (k = key, col = query) of dQ^T
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int query = 16 * u + r16;
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * t + 4 * q4 + r;
+                const float s = key < S ? sT[t][u][r] * sc : -INFINITY;
+                sT[t][u][r] = s;
+                m = fmaxf(m, s);
+            }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = exp2f(sT[t][u][r] - m); sT[t][u][r] = e; sum += e; }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        float dot = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float mk = a.drop.thresh ? drop_mul(a.drop, pair, query * 32 + 16 * t + 4 * q4 + r) : 1.0f;
+                const float p = sT[t][u][r] * inv;
+                const float dp = pT[t][u][r] * mk;
+                sT[t][u][r] = p; pT[t][u][r] = dp;
+                dot += p * dp;
+            }
+        dot += __shfl_xor(dot, 16, 64);
+        dot += __shfl_xor(dot, 32, 64);
+        q_max[u] = m; q_inv[u] = inv; q_dot[u] = dot;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int t = 2 * ks + (j >> 2);
+                dsT[u][ks][j] = t < NT ? (T)(sT[t % NT][u][j & 3] * (pT[t % NT][u][j & 3] - dot) * a.scale) : (T)0.0f;
+            }
+    }
+
+    // ---- N orientation: P~ and dS with the statistics of query 16u + 4q4 + r (they live in the lanes whose r16 equals 4q4 + r)
+    v8 dsN[NT][KS], pdN[NT][KS];                                   // B operands (k = query, col = key) of dK^T and dV^T
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        float mq[4], iq[4], dq[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int src = 4 * q4 + r;                              // any lane with r16 == 4q4 + r holds that query's statistics
+            mq[r] = __shfl(q_max[u], src, 64); iq[r] = __shfl(q_inv[u], src, 64); dq[r] = __shfl(q_dot[u], src, 64);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int query = 16 * u + 4 * q4 + r, key = 16 * t + r16;
+                const float mk = a.drop.thresh ? drop_mul(a.drop, pair, query * 32 + key) : 1.0f;
+                const float p = key < S ? exp2f(sN[u][t][r] * sc - mq[r]) * iq[r] : 0.f;
+                const float dp = pN[u][t][r] * mk;
+                sN[u][t][r] = p * mk;                                // dropped-out P
+                pN[u][t][r] = p * (dp - dq[r]) * a.scale;            // dS
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int u = 2 * ks + (j >> 2);
+                dsN[t][ks][j] = u < NT ? (T)pN[u % NT][t][j & 3] : (T)0.0f;
+                pdN[t][ks][j] = u < NT ? (T)sN[u % NT][t][j & 3] : (T)0.0f;
+            }
+
+    // ---- the three products; A operands by transposed LDS reads (EXEC all ones), stores as operand-type rows
+    T* obase = (T*)a.dqkv + (size_t)row_first * ld + head * 64;
+    auto product = [&](OFX_LDS char* img, v8 (&bop)[NT][KS], int col_off, int n_rows_out) {
+#pragma unroll
+        for (int nd = 0; nd < 4; ++nd) {
+            v8 af[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int row0 = 32 * ks + 16 * h2 + 4 * q4;
+                    OFX_LDS s16x4* ap = (OFX_LDS s16x4*)(img + (row0 + (r16 >> 2)) * V_ROW + (16 * nd + 4 * (r16 & 3)) * 2);
+                    const v4 trv = __builtin_bit_cast(v4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(ap));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) af[ks][4 * h2 + e] = trv[e];
+                }
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) c = OpT<T>::mfma16(af[ks], bop[u][ks], c);
+                const int orow = 16 * u + r16;                       // c[r] = out[orow][16nd + 4q4 + r]
+                if (live && orow < n_rows_out) {
+                    v4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (T)c[r];
+                    *(v4*)(obase + (size_t)orow * ld + col_off + 16 * nd + 4 * q4) = o;
+                }
+            }
+        }
+    };
+    product(kl, dsT, 0, S);            // dQ: contraction over keys   (A = K^T)
+    product(ql, dsN, D, S);            // dK: contraction over queries (A = Q^T)
+    product(gl, pdN, 2 * D, S);        // dV: contraction over queries (A = dO^T)
+}
+
 }  // namespace
 
 int ofx_launch_attention_mfma(const AttnArgs& g, int op_dtype, hipStream_t s) {
@@ -295,6 +518,20 @@ int ofx_launch_set_attention(const SetAttnArgs& g, int op_dtype, hipStream_t s) 
     if (op_dtype == OFX_F16) { if (g.max_len <= 20) SA(f16_t, 20); else SA(f16_t, 32); }
     else { if (g.max_len <= 20) SA(bf16_t, 20); else SA(bf16_t, 32); }
 #undef SA
+    OFX_LAUNCH_CHECK();
+    return OFX_OK;
+}
+
+int ofx_launch_set_attention_bwd_mfma(const void* qkv, const float* d_o, void* dqkv, const int* cu, int nseq, int n_head, int D, int max_len,
+                                      float scale, int op_dtype, const DropArgs& drop, int only_row0, hipStream_t s) {
+    OFX_REQUIRE(D == n_head * 64 && max_len >= 1 && max_len <= 32, OFX_ESHAPE, "set_attention_bwd_mfma: bad shape");
+    AttnBwdK k{(const char*)qkv, d_o, (char*)dqkv, cu, nseq, n_head, D, only_row0, scale, drop};
+    const int grid = (nseq * n_head + 3) / 4;
+    ProfScope prof(PROF_ATTN, s);
+#define AB(T, N) hipLaunchKernelGGL((set_attention_bwd_mfma_kernel<T, N>), dim3(grid), dim3(256), 0, s, k)
+    if (op_dtype == OFX_F16) { if (max_len <= 16) AB(f16_t, 1); else AB(f16_t, 2); }
+    else { if (max_len <= 16) AB(bf16_t, 1); else AB(bf16_t, 2); }
+#undef AB
     OFX_LAUNCH_CHECK();
     return OFX_OK;
 }
