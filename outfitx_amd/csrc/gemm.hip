@@ -20,8 +20,11 @@
 int g_gemm_splitk = 1;     // 0 disables split-K
 
 namespace {
-template <typename T, int ABL>   // ABL: 0 product kernel; 1 no LDS-DMA; 2 no MFMA; 3 no LDS fragment reads (diagnostics, wrong results)
+// MT = MFMA row tiles per wave: 4 -> the 128x128 block tile, 2 -> 64x128 (twice the blocks for grids that leave CUs idle: the
+// training step's M ~ 2k-row GEMMs with N = 1024; 48 KiB of LDS, three blocks per CU)
+template <typename T, int ABL, int MT = 4>   // ABL: 0 product kernel; 1 no LDS-DMA; 2 no MFMA; 3 no LDS fragment reads (diagnostics, wrong results)
 __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
+    constexpr int BMT = 32 * MT, STAGE_T = (BMT + BN) * BK * 2, EPI_T = 16 * MT * EPI_STRIDE * 4;
     typedef typename OpT<T>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     OFX_LDS char* lds = (OFX_LDS char*)smem;
@@ -47,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
         tm = first + r % gm;
         tn = r / gm;
     }
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BMT, n0 = tn * BN;
     if (p.m_dev) {                                      // block-uniform: whole tiles past the live rows leave
         const int m_live = *p.m_dev;
         p.M = m_live < p.M ? m_live : p.M;
@@ -56,41 +59,46 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
 
     // ---- LDS-DMA source addressing: each wave moves 4 A-chunks and 4 W-chunks of 1 KiB (8 rows) per k-tile
     const int lrow = lane >> 3, lchk = lane & 7;
-    const char* a_src[4];
+    const char* a_src[MT];
     const char* w_src[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = wave * 4 + i;                     // chunk 0..15 → rows c*8 .. c*8+7
         const int row = c * 8 + lrow;
         const int kch = lchk ^ ((row >> 1) & 7);        // logical 16-B chunk stored at physical slot lchk
-        int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
-        a_src[i] = p.A + ((size_t)gm * p.lda + kch * 8) * 2;
         w_src[i] = p.W + ((size_t)(n0 + row) * p.K + kch * 8) * 2;
     }
-    const int a_dst = wave * 4 * 1024, w_dst = BM * BK * 2 + wave * 4 * 1024;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int row = (wave * MT + i) * 8 + lrow;
+        const int kch = lchk ^ ((row >> 1) & 7);
+        int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
+        a_src[i] = p.A + ((size_t)gm * p.lda + kch * 8) * 2;
+    }
+    const int a_dst = wave * MT * 1024, w_dst = BMT * BK * 2 + wave * 4 * 1024;
 
     auto issue = [&](int kt, int stage) {
         if (ABL == 1) return;
-        OFX_LDS char* base = lds + stage * STAGE_BYTES;
+        OFX_LDS char* base = lds + stage * STAGE_T;
         const size_t koff = (size_t)kt * BK * 2;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(a_src[i] + koff, base + a_dst + i * 1024);
+        for (int i = 0; i < MT; ++i) glds16(a_src[i] + koff, base + a_dst + i * 1024);
 #pragma unroll
         for (int i = 0; i < 4; ++i) glds16(w_src[i] + koff, base + w_dst + i * 1024);
     };
 
     // ---- fragment read addressing (swizzled): row = tile*16 + (lane&15), logical chunk = ks*4 + (lane>>4)
     const int fr = lane & 15, fq = lane >> 4, fsw = fr >> 1;
-    const int a_frag = (wm * 64 + fr) * 128;
-    const int w_frag = BM * BK * 2 + (wn * 64 + fr) * 128;
+    const int a_frag = (wm * 16 * MT + fr) * 128;
+    const int w_frag = BMT * BK * 2 + (wn * 64 + fr) * 128;
 
-    f32x4 acc[4][4];
+    f32x4 acc[MT][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    v8 af[2][4], wf[2][4];
+    v8 af[2][MT], wf[2][4];
     const int kt0 = p.splits > 1 ? blockIdx.y * p.kt_per_split : 0;
     const int nk = p.splits > 1 ? min(p.K / BK, kt0 + p.kt_per_split) : p.K / BK;
     issue(kt0, kt0 & 1);
@@ -98,12 +106,13 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
             issue(kt + 1, cur ^ 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (MT == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        OFX_LDS char* base = lds + cur * STAGE_BYTES;
+        OFX_LDS char* base = lds + cur * STAGE_T;
         // all 16 fragment reads of the k-tile go out first; the MFMAs then wait on counted lgkmcnt
         static_assert(true, "");
 #pragma unroll
@@ -112,13 +121,13 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (ABL != 3 || kt == kt0) wf[ks][j] = *(OFX_LDS v8*)(base + w_frag + j * 16 * 128 + chk);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (ABL != 3 || kt == kt0) af[ks][i] = *(OFX_LDS v8*)(base + a_frag + i * 16 * 128 + chk);
+            for (int i = 0; i < MT; ++i) if (ABL != 3 || kt == kt0) af[ks][i] = *(OFX_LDS v8*)(base + a_frag + i * 16 * 128 + chk);
         }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (ABL == 2) { asm volatile("" :: "v"(wf[ks][j]), "v"(af[ks][i])); }
@@ -130,9 +139,9 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
     }
 
     // ---- epilogue: acc[i][j][r] = C[m = wm*64 + i*16 + (lane&15)][n = wn*64 + j*16 + (lane>>4)*4 + r]
-    OFX_LDS float* ep = (OFX_LDS float*)(lds + wave * EPI_BYTES_PER_WAVE);
+    OFX_LDS float* ep = (OFX_LDS float*)(lds + wave * EPI_T);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             *(OFX_LDS f32x4*)(ep + (i * 16 + fr) * EPI_STRIDE + j * 16 + fq * 4) = acc[i][j];
@@ -140,15 +149,15 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
     if (p.splits > 1) {                                  // raw partial sums; bias / activation / residual happen in splitk_reduce
         KArgs q = p;
         q.C = (char*)(p.slab + (size_t)blockIdx.y * p.m_slab * p.N); q.ldc = p.N; q.out_kind = 0; q.bias = nullptr; q.resid = nullptr; q.aux_out = nullptr; q.drop.thresh = 0;
-        epilogue<T, OFX_ACT_NONE>(q, ep, m0 + wm * 64, n0 + wn * 64, lane);
+        epilogue<T, OFX_ACT_NONE>(q, ep, m0 + wm * 16 * MT, n0 + wn * 64, lane, 16 * MT);
         return;
     }
     switch (p.act) {
-        case OFX_ACT_QUICK_GELU: epilogue<T, OFX_ACT_QUICK_GELU>(p, ep, m0 + wm * 64, n0 + wn * 64, lane); break;
-        case OFX_ACT_GELU: epilogue<T, OFX_ACT_GELU>(p, ep, m0 + wm * 64, n0 + wn * 64, lane); break;
-        case OFX_ACT_MISH: epilogue<T, OFX_ACT_MISH>(p, ep, m0 + wm * 64, n0 + wn * 64, lane); break;
-        case OFX_ACT_MISH_GRAD: epilogue<T, OFX_ACT_MISH_GRAD>(p, ep, m0 + wm * 64, n0 + wn * 64, lane); break;
-        default: epilogue<T, OFX_ACT_NONE>(p, ep, m0 + wm * 64, n0 + wn * 64, lane); break;
+        case OFX_ACT_QUICK_GELU: epilogue<T, OFX_ACT_QUICK_GELU>(p, ep, m0 + wm * 16 * MT, n0 + wn * 64, lane, 16 * MT); break;
+        case OFX_ACT_GELU: epilogue<T, OFX_ACT_GELU>(p, ep, m0 + wm * 16 * MT, n0 + wn * 64, lane, 16 * MT); break;
+        case OFX_ACT_MISH: epilogue<T, OFX_ACT_MISH>(p, ep, m0 + wm * 16 * MT, n0 + wn * 64, lane, 16 * MT); break;
+        case OFX_ACT_MISH_GRAD: epilogue<T, OFX_ACT_MISH_GRAD>(p, ep, m0 + wm * 16 * MT, n0 + wn * 64, lane, 16 * MT); break;
+        default: epilogue<T, OFX_ACT_NONE>(p, ep, m0 + wm * 16 * MT, n0 + wn * 64, lane, 16 * MT); break;
     }
 }
 
@@ -157,24 +166,26 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
 
 // Split-K plan for the 128x128 kernel: used when the tile grid leaves most of the chip idle and K is deep.
 // Returns the number of K splits (1 = none).  Shared by the launcher and the workspace sizing (api.hip).
-int ofx_gemm_splitk_plan(int M, int N, int K) {
-    if (g_gemm_splitk == 0 || N % 128 || K % 64) return 1;
+// cost model (us), measured on the 128x128 kernel (tools/_exp_small_m.py): ~1.06 us per k-tile and wave of 512 co-resident
+// blocks; a split adds the slab written once and read once (~5 TB/s) and the reduce launch.  M = 2304 x N = 1024 (144
+// blocks) is faster UNSPLIT (17 vs 26 us); M = 288 (24 blocks, K = 3072) wants 8 splits (51 -> 13 us).
+static int splitk_plan_cost(int M, int N, int K, double* cost) {
     const long blocks = (long)((M + 127) / 128) * (N / 128);
     const int nk = K / 64;
-    if (blocks >= 256 || nk < 16) return 1;
-    // cost model (us), measured on the 128x128 kernel (tools/_exp_small_m.py): ~1.06 us per k-tile and wave of 512 co-resident
-    // blocks; a split adds the slab written once and read once (~5 TB/s) and the reduce launch.  M = 2304 x N = 1024 (144
-    // blocks) is faster UNSPLIT (17 vs 26 us); M = 288 (24 blocks, K = 3072) wants 8 splits (51 -> 13 us).
     int best = 1;
     double best_t = (double)((blocks + 511) / 512) * nk * 1.06;
-    for (int s = 2; s <= 8 && s <= nk / 4; ++s) {
-        const int kps = (nk + s - 1) / s;
-        if ((nk + kps - 1) / kps != s) continue;          // every split owns at least one k-tile
-        const double t = (double)((blocks * s + 511) / 512) * kps * 1.06 + 2.0 * s * M * N * 4.0 / 5.0e6 + 3.0;
-        if (t < best_t) { best_t = t; best = s; }
+    if (g_gemm_splitk != 0 && N % 128 == 0 && K % 64 == 0 && blocks < 256 && nk >= 16) {
+        for (int s = 2; s <= 8 && s <= nk / 4; ++s) {
+            const int kps = (nk + s - 1) / s;
+            if ((nk + kps - 1) / kps != s) continue;          // every split owns at least one k-tile
+            const double t = (double)((blocks * s + 511) / 512) * kps * 1.06 + 2.0 * s * M * N * 4.0 / 5.0e6 + 3.0;
+            if (t < best_t) { best_t = t; best = s; }
+        }
     }
+    if (cost) *cost = best_t;
     return best;
 }
+int ofx_gemm_splitk_plan(int M, int N, int K) { return splitk_plan_cost(M, N, K, nullptr); }
 size_t ofx_gemm_splitk_bytes(int M, int N, int K) {
     const int s = ofx_gemm_splitk_plan(M, N, K);
     return s > 1 ? (size_t)s * M * N * 4 : 0;
@@ -215,6 +226,8 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
     if (!attr_set) {
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<bf16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<f16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+        OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<bf16_t, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM64_LDS_BYTES));
+        OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<f16_t, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM64_LDS_BYTES));
 #ifdef OFX_DIAG
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
@@ -231,6 +244,7 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
         else kind = 1;
     }
     if ((kind == 2 || kind == 4) && g.N % 256) kind = 1;
+    if (kind == 5 && g.N % 128) kind = 1;
     ProfScope prof(PROF_GEMM, s, 2.0 * g.M * g.N * g.K);
     if (kind == 2 || kind == 3 || kind == 4) {
         k.group_m = g_gemm_group_m > 0 ? g_gemm_group_m : (kind == 3 ? 4 : 8);
@@ -248,6 +262,27 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
         k.splits = splits; k.slab = (float*)g.slab; k.m_slab = g.M;
         k.kt_per_split = splits > 1 ? (g.K / BK + splits - 1) / splits : 0;
         if (splits > 1) OFX_REQUIRE(g.slab_bytes >= (size_t)splits * g.M * g.N * 4, OFX_EWORKSPACE, "gemm: split-K slab too small");
+        // 64-row tiles when the 128^2 grid would leave most CUs idle and no split-K is planned (the training step's M ~ 2k GEMMs with
+        // N = 1024: 144 -> 288 blocks; tools/_exp_small_m.py); kind 5 forces them
+        // (~0.65 us per k-tile and wave of 768 co-resident 64x128 blocks, measured) against the best 128^2 plan
+        const long blocks128 = (long)k.tiles_m * k.tiles_n;
+        bool use64 = kind == 5;
+        if (kind == 1 && g_gemm_kernel == 0 && blocks128 <= 384 && g.M > 64) {      // one wave of 768 co-resident 64-row blocks: never slower than 128^2 (measured)
+            double t128;
+            splitk_plan_cost(g.M, g.N, g.K, &t128);
+            if (splits == 1) t128 = (double)((blocks128 + 511) / 512) * (g.K / BK) * 1.06;
+            const long blocks64 = (long)((g.M + 63) / 64) * k.tiles_n;
+            use64 = (double)((blocks64 + 767) / 768) * (g.K / BK) * 0.65 + 1.0 < t128;
+        }
+        if (use64) {
+            k.splits = 1; k.kt_per_split = 0;
+            k.tiles_m = (g.M + 63) / 64; k.nwg = k.tiles_m * k.tiles_n; k.group_m = 2 * gm;
+            const dim3 grid64(k.nwg, 1);
+            if (op_dtype == OFX_F16) hipLaunchKernelGGL((gemm_128x128_kernel<f16_t, 0, 2>), grid64, dim3(256), GEMM64_LDS_BYTES, s, k);
+            else hipLaunchKernelGGL((gemm_128x128_kernel<bf16_t, 0, 2>), grid64, dim3(256), GEMM64_LDS_BYTES, s, k);
+            OFX_LAUNCH_CHECK();
+            return OFX_OK;
+        }
         const dim3 grid(k.nwg, splits > 1 ? splits : 1);
         if (op_dtype == OFX_F16) hipLaunchKernelGGL((gemm_128x128_kernel<f16_t, 0>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
 #ifdef OFX_DIAG

@@ -14,6 +14,7 @@ constexpr int STAGE_BYTES = (BM + BN) * BK * 2;        // 32 KiB
 constexpr int EPI_STRIDE = 68;                         // floats per staged output row (64 + 4 pad)
 constexpr int EPI_BYTES_PER_WAVE = 64 * EPI_STRIDE * 4;
 constexpr int GEMM_LDS_BYTES = 4 * EPI_BYTES_PER_WAVE > 2 * STAGE_BYTES ? 4 * EPI_BYTES_PER_WAVE : 2 * STAGE_BYTES;
+constexpr int GEMM64_LDS_BYTES = 2 * (64 + BN) * BK * 2;      // 64x128 variant: 48 KiB (stages) > 4 x 8.5 KiB (epilogue staging)
 
 struct KArgs {
     const char* A;
@@ -40,14 +41,14 @@ __device__ __forceinline__ void glds16(const char* g, OFX_LDS char* l) {
 
 // One wave drains its 64x64 fp32 sub-tile from LDS as whole row segments: 16 lanes x 16 B per row.
 template <typename T, int ACT>
-__device__ __forceinline__ void epilogue(const KArgs& p, OFX_LDS float* ep, int gm0, int gn0, int lane) {
+__device__ __forceinline__ void epilogue(const KArgs& p, OFX_LDS float* ep, int gm0, int gn0, int lane, int nrows = 64) {
     typedef typename OpT<T>::v4 v4;
     const int col = (lane & 15) * 4;
     const int gn = gn0 + col;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) bias4 = *(const f32x4*)(p.bias + gn);
 #pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < nrows / 4; ++it) {
         const int row = it * 4 + (lane >> 4);
         const int gm = gm0 + row;
         f32x4 v = *(OFX_LDS f32x4*)(ep + row * EPI_STRIDE + col);

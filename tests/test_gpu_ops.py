@@ -53,7 +53,7 @@ def test_gemm_plain(dt, M, N, K):
     assert rel_err(out.cpu().numpy(), want) < 2e-5
 
 
-@pytest.mark.parametrize("kern", [2, 3, 4])
+@pytest.mark.parametrize("kern", [2, 3, 4, 5])
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("M,N,K", [(1, 256, 64), (255, 256, 128), (257, 512, 768), (1000, 768, 3072), (5000, 256, 192)])
 def test_gemm_big_tile_kernels(kern, dt, M, N, K):

@@ -5,14 +5,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from outfitx_amd import _lib as L
 lib = L.load()
 st = lambda: torch.cuda.current_stream().cuda_stream
-shapes = [("qkv", 2304, 3072, 1024), ("out/dO", 2304, 1024, 1024), ("fc1/dU", 2304, 2048, 1024), ("fc2/dH2", 2304, 1024, 2048), ("dH1", 2304, 1024, 3072)]
+shapes = [("qkv", 2304, 3072, 1024), ("out/dO", 2304, 1024, 1024), ("fc1/dU", 2304, 2048, 1024), ("fc2/dH2", 2304, 1024, 2048), ("dH1", 2304, 1024, 3072),
+          ("out 4352", 4352, 1024, 1024), ("fc1 4352", 4352, 2048, 1024), ("fc2 4352", 4352, 1024, 2048), ("qkv 4352", 4352, 3072, 1024), ("out 6144", 6144, 1024, 1024)]
 for name, M, N, K in shapes:
     A = torch.randn(M, K, device="cuda").bfloat16(); W = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
     C = torch.zeros(M, N, device="cuda")
     nb = lib.ofx_gemm_splitk_ws(M, N, K)
     slab = torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
     res = {}
-    for tag, kind, split in (("k1", 1, 0), ("k1+splitK", 1, 1), ("k2", 2, 0), ("k3", 3, 0), ("k4", 4, 0)):
+    for tag, kind, split in (("k1", 1, 0), ("k1+splitK", 1, 1), ("k5 64x128", 5, 0), ("auto", 0, 1), ("k3", 3, 0)):
         if kind == 4 and K > 1024: continue
         lib.ofx_tune(2, kind)
         def run():
