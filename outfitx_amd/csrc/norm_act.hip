@@ -393,8 +393,8 @@ __global__ __launch_bounds__(256) void fold_pack_kernel(const float* Wsrc, const
 // table[i] = {src, dst, n floats}: block i copies entry i (pack time: every small fp32 tensor of a model in one launch)
 struct MultiCopyEntry { const float* src; float* dst; long long n; };
 __global__ __launch_bounds__(256) void multi_copy_kernel(const MultiCopyEntry* table) {
-    const MultiCopyEntry e = table[blockIdx.x];
-    for (long long i = threadIdx.x; i < e.n; i += 256) e.dst[i] = e.src[i];
+    const MultiCopyEntry e = table[blockIdx.x];            // blockIdx.y strides over the entry (the text tower's 101 MB token table is one entry)
+    for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < e.n; i += (long long)gridDim.y * 256) e.dst[i] = e.src[i];
 }
 
 // logits[b] = row0[b] . w + bias    (fp32, exact-order independent of B)
@@ -503,7 +503,7 @@ int ofx_launch_fold_pack(const float* Wsrc, const float* gamma, const float* bet
     return OFX_OK;
 }
 int ofx_launch_multi_copy(const void* table_dev, int n, hipStream_t s) {
-    hipLaunchKernelGGL(multi_copy_kernel, dim3(n), dim3(256), 0, s, (const MultiCopyEntry*)table_dev);
+    hipLaunchKernelGGL(multi_copy_kernel, dim3(n, 64), dim3(256), 0, s, (const MultiCopyEntry*)table_dev);
     OFX_LAUNCH_CHECK();
     return OFX_OK;
 }
