@@ -318,6 +318,7 @@ class CLIPTextEncoder(_TowerBase):
             freeze_model(self.model)
         self._tok_name = model_name_or_path
         self.tokenizer = None
+        self.dedup_texts = False      # opt-in: run the tower once per DISTINCT token row of a call (item texts are category names)
 
     def _desc(self) -> L.ModelDesc:
         d, c = L.default_desc(), self.model.config
@@ -362,26 +363,61 @@ class CLIPTextEncoder(_TowerBase):
         pos = ids.argmax(-1) if eos == 2 else (ids == eos).int().argmax(-1)
         return (pos + 1).tolist()
 
+    def _dedup(self, ids: torch.Tensor, att: Optional[torch.Tensor]):
+        """dedup_texts (the item texts are 132 category strings): host-side unique over the token rows ->
+        (unique ids, unique mask, inverse index) or None when nothing repeats / the ids are not on the host."""
+        if not self.dedup_texts or ids.device.type != "cpu" or ids.shape[0] < 2:
+            return None
+        a = ids.numpy()
+        key = a if att is None else a * 2 + att.numpy().astype(a.dtype)          # ids < 2^31: (id, mask bit) pairs stay distinct
+        w = getattr(self, "_hash_w", None)
+        if w is None or w.shape[0] != key.shape[1]:
+            w = np.random.default_rng(0x5EED).integers(1, 2 ** 62, key.shape[1], dtype=np.int64) | 1
+            self._hash_w = w
+        h = (key.astype(np.int64) * w).sum(1)                                      # wrap-around 64-bit row hash
+        _, first, inv = np.unique(h, return_index=True, return_inverse=True)
+        if first.shape[0] == key.shape[0] or not np.array_equal(key[first][inv], key):   # nothing repeats / a hash collision: plain path
+            return None
+        first_t = torch.from_numpy(first)
+        uniq_ids = ids.index_select(0, first_t)
+        uniq_att = None if att is None else att.index_select(0, first_t)
+        return uniq_ids.contiguous(), (None if uniq_att is None else uniq_att.contiguous()), torch.from_numpy(inv.astype(np.int64))
+
     @torch.no_grad()
     def prepare(self, texts, tokenizer_kargs=None):
-        """Host part of the text path (tokenise, EOS lengths, stage ids on the device).  ItemEncoder calls it before
-        the image tower is enqueued so no blocking copy sits in the middle of the step."""
+        """Host part of the text path (tokenise, optional de-duplication, EOS lengths, stage ids on the device).  ItemEncoder
+        calls it before the image tower is enqueued so no blocking copy sits in the middle of the step."""
         ids, att, b = self._ids(texts, tokenizer_kargs)
+        inverse = None
+        dd = self._dedup(ids, att)
+        if dd is not None:
+            ids, att, inverse = dd
+            inverse = inverse.to(self.device, non_blocking=True)
         lengths = self._lengths(ids)
         ids_d, att_d = self._engine("text").stage_tokens(ids, att)
-        return ids_d, att_d, lengths, b
+        return ids_d, att_d, lengths, b, inverse
+
+    def _run(self, ids, att, lengths, inverse, out: torch.Tensor, col: int, normalize: bool) -> None:
+        eng = self._engine("text")
+        if inverse is None:
+            eng.text(ids, att, out, col, normalize, lengths)
+            return
+        uniq = torch.empty(ids.shape[0], self.d_embed, dtype=torch.float32, device=self.device)     # the tower runs on the distinct texts only
+        eng.text(ids, att, uniq, 0, normalize, lengths)
+        out[:, col:col + self.d_embed] = uniq.index_select(0, inverse)
 
     @torch.no_grad()
     def encode_into(self, texts, out: torch.Tensor, col: int, normalize: bool, tokenizer_kargs=None, prepared=None) -> int:
-        ids, att, lengths, b = prepared if prepared is not None else self.prepare(texts, tokenizer_kargs)
-        self._engine("text").text(ids, att, out, col, normalize, lengths)
+        ids, att, lengths, b, inverse = prepared if prepared is not None else self.prepare(texts, tokenizer_kargs)
+        self._run(ids, att, lengths, inverse, out, col, normalize)
         return b
 
     @torch.no_grad()
     def forward(self, texts, normalize: bool = True, *args, **kwargs) -> torch.Tensor:
-        ids, att, b = self._ids(texts, kwargs.get("tokenizer_kargs"))
-        out = torch.empty(ids.shape[0], self.d_embed, dtype=torch.float32, device=self.device)
-        self._engine("text").text(ids, att, out, 0, normalize, self._lengths(ids))
+        ids, att, lengths, b, inverse = self.prepare(texts, kwargs.get("tokenizer_kargs"))
+        n = ids.shape[0] if inverse is None else inverse.shape[0]
+        out = torch.empty(n, self.d_embed, dtype=torch.float32, device=self.device)
+        self._run(ids, att, lengths, inverse, out, 0, normalize)
         return out.view(b, -1, self.d_embed)
 
 

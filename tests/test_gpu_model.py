@@ -375,3 +375,23 @@ def test_layernorm_folding_matches_the_materialised_path(model):
         for a, b in zip(*outs):
             assert not np.array_equal(a, b)                  # the two paths really differ in rounding
             assert rel_err(a, b) < 2e-2
+
+
+def test_text_dedup_runs_the_tower_on_distinct_rows_only(model):
+    """N2 (item texts are 132 category names): with dedup_texts the tower runs once per distinct token row of a call; the
+    embeddings equal the plain path to the operand-rounding floor and duplicates are bit-identical."""
+    enc = model.item_encoder.text_enc
+    base_ids, base_att = synth.token_batch(91, 7, 64, synth.ragged_lengths(91, 7, 2, 20))
+    pick = np.random.default_rng(4).integers(0, 7, 300)
+    tok = {"input_ids": torch.from_numpy(base_ids[pick]).view(300, 1, 64), "attention_mask": torch.from_numpy(base_att[pick]).view(300, 1, 64)}
+    with torch.no_grad():
+        plain = enc(tok).view(300, 512)
+        enc.dedup_texts = True
+        try:
+            dd = enc(tok).view(300, 512)
+        finally:
+            enc.dedup_texts = False
+    assert rel_err(dd.cpu().numpy(), plain.cpu().numpy()) < 2e-2
+    for k in range(7):
+        rows = dd[torch.from_numpy(pick == k)]
+        assert rows.shape[0] > 1 and torch.equal(rows, rows[:1].expand_as(rows))
