@@ -273,6 +273,25 @@ def test_c_abi_error_codes():
     eng.pack_outfit([torch.from_numpy(Wt[k]).cuda() for k in order])
     rc = lib.ofx_set_encoder_fwd(eng.h, x.data_ptr(), m.data_ptr(), None, 0, 2, 16, o.data_ptr(), ws.data_ptr(), 1024, s)
     assert rc == -4 and b"workspace" in lib.ofx_last_error()                      # OFX_EWORKSPACE
+    # the "next"-row entry points report the same way
+    logits = torch.zeros(2, 1, device="cuda"); tape = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    rc = lib.ofx_cp_train_fwd(eng.h, x.data_ptr(), m.data_ptr(), 2, 16, logits.data_ptr(), tape.data_ptr(), tape.numel(), ws.data_ptr(), ws.numel(), 0.0, 0, s)
+    assert rc == -5 and b"single-product" in lib.ofx_last_error()                 # the default engine is bf16x3: training refuses it
+    eng16 = Engine(torch.device("cuda", 0), precision="bf16")
+    eng16.pack_outfit([torch.from_numpy(Wt[k]).cuda() for k in order])
+    rc = lib.ofx_cp_train_fwd(eng16.h, x.data_ptr(), m.data_ptr(), 2, 16, logits.data_ptr(), tape.data_ptr(), 1024, ws.data_ptr(), ws.numel(), 0.0, 0, s)
+    assert rc == -4 and b"tape" in lib.ofx_last_error()
+    rc = lib.ofx_cp_train_fwd(eng16.h, x.data_ptr(), m.data_ptr(), 2, 16, logits.data_ptr(), tape.data_ptr(), tape.numel(), ws.data_ptr(), ws.numel(), 1.5, 0, s)
+    assert rc == -1 and b"dropout_p" in lib.ofx_last_error()                      # OFX_EINVAL
+    a16 = torch.zeros(64, 256, dtype=torch.bfloat16, device="cuda"); c32 = torch.zeros(256, 256, device="cuda")
+    rc = lib.ofx_gemm_tn(a16.data_ptr(), 256, a16.data_ptr(), 256, c32.data_ptr(), 256, 200, 256, 64, None, None, 0, 1, s)
+    assert rc != 0 and b"multiples of 256" in lib.ofx_last_error()
+    hs = (C.c_int * 1)(10); wsz = (C.c_int * 1)(10); offs = (C.c_longlong * 1)(0); mean = (C.c_float * 3)(0, 0, 0); std = (C.c_float * 3)(1, 1, 1)
+    img = torch.zeros(4096, dtype=torch.uint8, device="cuda"); px = torch.zeros(1, 3, 224, 224, device="cuda")
+    rc = lib.ofx_clip_preprocess(img.data_ptr(), offs, hs, wsz, 1, 2, 224, mean, std, px.data_ptr(), ws.data_ptr(), ws.numel(), s)
+    assert rc != 0 and b"channels" in lib.ofx_last_error()
+    rc = lib.ofx_clip_preprocess(img.data_ptr(), offs, hs, wsz, 1, 3, 224, mean, std, px.data_ptr(), ws.data_ptr(), 16, s)
+    assert rc == -4
     torch.cuda.synchronize()
 
 
