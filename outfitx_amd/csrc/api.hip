@@ -69,7 +69,7 @@ extern "C" int ofx_profile_read(double* ms, double* flops, long long* launches) 
     return OFX_OK;
 }
 
-int ofx_launch_transpose_cast(const float* src, void* dst, int R, int C, int ldd, int op_dtype, hipStream_t s);
+int ofx_launch_transpose_cast(const float* src, void* dst, int R, int C, int ldd, int op_dtype, hipStream_t s, void* row_dst = nullptr, int ld_row = 0);
 size_t ofx_colsum_part_floats(int C);
 int ofx_launch_colsum(const void* x, int x_kind, int ld, const int* gather, const float* row_scale, float* out0, float* out1, float* out2, int seg,
                       float* part, int C, const int* m_dev, int M, int op_dtype, hipStream_t s, int valid = 0, int accumulate = 0);
@@ -247,13 +247,18 @@ extern "C" int ofx_pack_outfit_weights(ofx_handle* h, const void* const* P, int 
     for (int l = 0; l < d.n_layers; ++l) {
         const void* const* q = P + 5 + 12 * l;
         OutfitLayer& L = h->ol[l];
-        L.w_in = A.take<char>(2 * km * 3 * D * D); TRY(ofx_launch_pack_rows((const float*)q[0], L.w_in, 3 * D, 3 * D, D, D, D, mode, dt, s));
+        const bool both = km == 1;          // single-product precisions: the row-major copy and W^T come out of ONE pass below
+        L.w_in = A.take<char>(2 * km * 3 * D * D); if (!both) TRY(ofx_launch_pack_rows((const float*)q[0], L.w_in, 3 * D, 3 * D, D, D, D, mode, dt, s));
         L.b_in = A.take<float>(3 * D); TRY(copy_f32(L.b_in, q[1], 3 * D, s));
-        L.w_out = A.take<char>(2 * km * D * D); TRY(ofx_launch_pack_rows((const float*)q[2], L.w_out, D, D, D, D, D, mode, dt, s));
+        L.w_out = A.take<char>(2 * km * D * D); if (!both) TRY(ofx_launch_pack_rows((const float*)q[2], L.w_out, D, D, D, D, D, mode, dt, s));
         L.b_out = A.take<float>(D); TRY(copy_f32(L.b_out, q[3], D, s));
-        L.w_1 = A.take<char>(2 * km * Fp * D); TRY(ofx_launch_pack_rows((const float*)q[4], L.w_1, F, Fp, D, D, D, mode, dt, s));
+        L.w_1 = A.take<char>(2 * km * Fp * D);
+        if (!both) TRY(ofx_launch_pack_rows((const float*)q[4], L.w_1, F, Fp, D, D, D, mode, dt, s));
+        else if (zero_pad) OFX_HIP(hipMemsetAsync(L.w_1, 0, 2 * Fp * D, s));                       // rows F.. stay zero
         L.b_1 = A.take<float>(Fp); if (zero_pad) OFX_HIP(hipMemsetAsync(L.b_1, 0, Fp * 4, s)); TRY(copy_f32(L.b_1, q[5], F, s));
-        L.w_2 = A.take<char>(2 * km * D * Fp); TRY(ofx_launch_pack_rows((const float*)q[6], L.w_2, D, D, F, Fp, F, mode, dt, s));
+        L.w_2 = A.take<char>(2 * km * D * Fp);
+        if (!both) TRY(ofx_launch_pack_rows((const float*)q[6], L.w_2, D, D, F, Fp, F, mode, dt, s));
+        else if (zero_pad) OFX_HIP(hipMemsetAsync(L.w_2, 0, 2 * D * Fp, s));                       // columns F.. stay zero
         L.b_2 = A.take<float>(D); TRY(copy_f32(L.b_2, q[7], D, s));
         L.g1 = A.take<float>(D); TRY(copy_f32(L.g1, q[8], D, s));
         L.be1 = A.take<float>(D); TRY(copy_f32(L.be1, q[9], D, s));
@@ -261,12 +266,12 @@ extern "C" int ofx_pack_outfit_weights(ofx_handle* h, const void* const* P, int 
         L.be2 = A.take<float>(D); TRY(copy_f32(L.be2, q[11], D, s));
         L.w_in_t = L.w_out_t = L.w_1_t = L.w_2_t = nullptr;
         if (km == 1) {      // W^T copies for the backward dgrad GEMMs: [K_w, N_w] operand, zero padded
-            L.w_in_t = A.take<char>(2 * D * 3 * D); TRY(ofx_launch_transpose_cast((const float*)q[0], L.w_in_t, (int)(3 * D), (int)D, (int)(3 * D), dt, s));
-            L.w_out_t = A.take<char>(2 * D * D); TRY(ofx_launch_transpose_cast((const float*)q[2], L.w_out_t, (int)D, (int)D, (int)D, dt, s));
+            L.w_in_t = A.take<char>(2 * D * 3 * D); TRY(ofx_launch_transpose_cast((const float*)q[0], L.w_in_t, (int)(3 * D), (int)D, (int)(3 * D), dt, s, L.w_in, (int)D));
+            L.w_out_t = A.take<char>(2 * D * D); TRY(ofx_launch_transpose_cast((const float*)q[2], L.w_out_t, (int)D, (int)D, (int)D, dt, s, L.w_out, (int)D));
             L.w_1_t = A.take<char>(2 * D * Fp); if (zero_pad) OFX_HIP(hipMemsetAsync(L.w_1_t, 0, 2 * D * Fp, s));      // [D, Fp], columns F.. stay zero
-            TRY(ofx_launch_transpose_cast((const float*)q[4], L.w_1_t, (int)F, (int)D, (int)Fp, dt, s));
+            TRY(ofx_launch_transpose_cast((const float*)q[4], L.w_1_t, (int)F, (int)D, (int)Fp, dt, s, L.w_1, (int)D));
             L.w_2_t = A.take<char>(2 * Fp * D); if (zero_pad) OFX_HIP(hipMemsetAsync(L.w_2_t, 0, 2 * Fp * D, s));      // [Fp, D], rows F.. stay zero
-            TRY(ofx_launch_transpose_cast((const float*)q[6], L.w_2_t, (int)D, (int)F, (int)D, dt, s));
+            TRY(ofx_launch_transpose_cast((const float*)q[6], L.w_2_t, (int)D, (int)F, (int)D, dt, s, L.w_2, (int)Fp));
         }
     }
     OFX_REQUIRE(A.off <= A.cap, OFX_ESTATE, "pack_outfit: arena overflow");

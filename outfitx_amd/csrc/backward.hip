@@ -17,14 +17,16 @@ template <> struct Ld4<f16_t> { static __device__ __forceinline__ f32x4 ld(const
 // ---- fp32 [R, C] -> operand-type transpose [C, ldd] (64 x 64 tiles through LDS).  Pack time only: the W^T copies the
 // dgrad GEMMs contract against.
 template <typename T>
-__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* src, T* dst, int R, int C, int ldd) {
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* src, T* dst, int R, int C, int ldd, T* row_dst, int ld_row) {
     __shared__ T tile[64][66];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int r = r0 + ty * 16 + i, c = c0 + tx;
-        tile[ty * 16 + i][tx] = (r < R && c < C) ? (T)src[(size_t)r * C + c] : (T)0.0f;
+        const T v = (r < R && c < C) ? (T)src[(size_t)r * C + c] : (T)0.0f;
+        tile[ty * 16 + i][tx] = v;
+        if (row_dst && r < R && c < C) row_dst[(size_t)r * ld_row + c] = v;        // the row-major operand copy in the same pass
     }
     __syncthreads();
 #pragma unroll
@@ -331,11 +333,11 @@ int ofx_launch_drop_rows(float* x, int rows, int cols, const DropArgs& d, hipStr
     return OFX_OK;
 }
 
-int ofx_launch_transpose_cast(const float* src, void* dst, int R, int C, int ldd, int op_dtype, hipStream_t s) {
-    OFX_REQUIRE(ldd >= R, OFX_ESHAPE, "transpose_cast: ldd=%d < R=%d", ldd, R);
+int ofx_launch_transpose_cast(const float* src, void* dst, int R, int C, int ldd, int op_dtype, hipStream_t s, void* row_dst, int ld_row) {
+    OFX_REQUIRE(ldd >= R && (!row_dst || ld_row >= C), OFX_ESHAPE, "transpose_cast: ldd=%d < R=%d", ldd, R);
     const dim3 grid((C + 63) / 64, (R + 63) / 64);
-    if (op_dtype == OFX_F16) hipLaunchKernelGGL(transpose_cast_kernel<f16_t>, grid, dim3(256), 0, s, src, (f16_t*)dst, R, C, ldd);
-    else hipLaunchKernelGGL(transpose_cast_kernel<bf16_t>, grid, dim3(256), 0, s, src, (bf16_t*)dst, R, C, ldd);
+    if (op_dtype == OFX_F16) hipLaunchKernelGGL(transpose_cast_kernel<f16_t>, grid, dim3(256), 0, s, src, (f16_t*)dst, R, C, ldd, (f16_t*)row_dst, ld_row);
+    else hipLaunchKernelGGL(transpose_cast_kernel<bf16_t>, grid, dim3(256), 0, s, src, (bf16_t*)dst, R, C, ldd, (bf16_t*)row_dst, ld_row);
     BWD_CHECK();
     return OFX_OK;
 }

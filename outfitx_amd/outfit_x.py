@@ -39,6 +39,25 @@ def _activation_id(act) -> int:
     raise NotImplementedError(f"transformer activation {act!r} has no fused epilogue (mish / gelu are built)")
 
 
+import weakref
+
+_LIVE_MODELS: "weakref.WeakSet" = weakref.WeakSet()
+
+
+def _after_any_optimizer_step(optimizer, args, kwargs):
+    """Global torch hook: whichever optimizer stepped may have rewritten an OutfitX's parameters (fused kernels do not bump
+    tensor versions), so the packed operand copies of every live model are re-made on its next forward."""
+    for m in list(_LIVE_MODELS):
+        m.mark_weights_changed()
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_hook
+    _reg_hook(_after_any_optimizer_step)
+except ImportError:                                   # older torch: CPTrainer / callers use mark_weights_changed() themselves
+    pass
+
+
 class _CPTrainFn(torch.autograd.Function):
     """CP path with a hand-written backward (libofx_hip.so: ofx_cp_train_fwd / ofx_cp_train_bwd).  Gradients flow to
     the outfit transformer, outfit_token and cp_ffn; the embeddings are data (cp_trainer feeds precomputed ones)."""
@@ -164,6 +183,7 @@ class OutfitX(nn.Module):
         if not t.norm_first:
             raise NotImplementedError("post-norm encoder layers are outside the scoring path (reference uses norm_first)")
         self.precision = precision
+        _LIVE_MODELS.add(self)
         self.train_precision = train_precision      # operand format of the training step (the reference trains under bf16 autocast)
         self.item_encoder.set_precision(tower_precision)
         self._engines: Dict[Any, Engine] = {}
@@ -177,6 +197,14 @@ class OutfitX(nn.Module):
         s = self.__dict__.copy()
         s["_engines"] = {}
         return s
+
+    def mark_weights_changed(self) -> None:
+        """Force a re-pack of the operand copies on the next call.  `_engine` notices parameter updates through the tensors'
+        version counters, which in-place torch ops bump - but FUSED optimizers (torch.optim.AdamW(fused=True)) write the
+        parameters without bumping them.  Every optimizer step therefore also lands here through the global post-step
+        hook below, and trainer.CPTrainer calls it explicitly."""
+        for eng in self._engines.values():
+            eng.signature["outfit"] = None
 
     def _outfit_tensors(self) -> List[torch.Tensor]:
         out = [self.outfit_token, self.target_item_image_emb, self.cp_ffn[1].weight, self.cp_ffn[1].bias, self.cir_ffn[0].weight]

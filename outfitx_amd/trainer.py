@@ -172,6 +172,7 @@ class CPTrainer:
             self.optimizer.step()
             self.scheduler.step()
             self.grads.zero_()
+            getattr(self.model, "mark_weights_changed", lambda: None)()     # fused optimizers do not bump tensor versions
         return loss.detach(), y_hat.detach(), labels
 
     def train_epoch(self, batches: Iterable[dict]) -> Dict[str, float]:

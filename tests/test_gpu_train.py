@@ -423,3 +423,41 @@ def test_gradient_sink_equals_autograd_accumulation(task):
         else:
             assert torch.equal(a[k], b[k]), k
     assert len(on_path) == len(b) - len(off_path)
+
+
+def test_trainer_overfits_a_small_batch():
+    """End-to-end sanity of the whole loop (tape forward, fused focal loss, sink backward, clip, fused AdamW, OneCycleLR, re-pack):
+    32 outfits with random labels are memorised - the focal loss falls by more than 10x and every outfit is classified."""
+    from outfitx_amd.trainer import CPTrainConfig, CPTrainer
+    from src.models.datatypes import OutfitCompatibilityPredictionTask as CP
+    emb, mask = synth.outfit_batch(77, 32, 16, synth.ragged_lengths(77, 32, 2, 12))
+    lab = torch.from_numpy((np.random.default_rng(7).random(32) < 0.5).astype(np.float32))
+    batch = {"input_dict": {"task": CP, "outfit_embedding": torch.from_numpy(emb), "outfit_mask": torch.from_numpy(mask)}, "label": lab}
+    m = make_model("bf16")
+    tr = CPTrainer(m, steps_per_epoch=120, cfg=CPTrainConfig(learning_rate=3e-4, accumulation_steps=1, n_epochs=1), params=list(trainable(m).values()))
+    losses = [float(tr.micro_step(batch, i)[0]) for i in range(120)]
+    m.eval()
+    with torch.no_grad():
+        y = m(task=CP, outfit_embedding=cu(emb), outfit_mask=cu(mask)).squeeze(-1).cpu()
+    assert losses[-1] < 0.1 * losses[0], (losses[0], losses[-1])
+    assert torch.equal((y > 0).float(), lab)
+
+
+def test_fused_optimizer_steps_are_noticed():
+    """torch.optim.AdamW(fused=True) rewrites the parameters without bumping their version counters; the global optimizer
+    post-step hook must still make the next forward re-pack the operand copies (reference-style loop, no CPTrainer)."""
+    from src.models.datatypes import OutfitCompatibilityPredictionTask as CP
+    emb, mask = synth.outfit_batch(12, 6, 16, synth.ragged_lengths(12, 6, 2, 9))
+    m = make_model("bf16")
+    opt = torch.optim.AdamW(list(trainable(m).values()), lr=1e-3, fused=True)
+    x, k = cu(emb), cu(mask)
+    y0 = m(task=CP, outfit_embedding=x, outfit_mask=k)
+    y0.sum().backward()
+    v0 = m.cp_ffn[1].weight._version
+    opt.step()
+    y1 = m(task=CP, outfit_embedding=x, outfit_mask=k)
+    assert not torch.equal(y0, y1), "stale packed weights after a fused optimizer step"
+    m.eval()
+    with torch.no_grad():
+        y2 = m(task=CP, outfit_embedding=x, outfit_mask=k)          # the scoring engine (bf16x3 copies) is re-packed too
+    assert float((y2 - y1).abs().max()) < 0.05 * float(y1.abs().max()) + 0.05
