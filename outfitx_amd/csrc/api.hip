@@ -602,11 +602,12 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
 }
 
 // All layers; the pooled rows end up compacted in w.XP [nseq, W].
+static bool clip_fold(int W) { return g_ln_fold != 0 && W % 64 == 0; }
 static int clip_layers(const std::vector<ClipLayer>& Ls, const ClipWs& w, int rows, int nseq, int S, int W, int MLP,
                        int heads, int act, float eps, int causal, const int64_t* key_mask, int mask_ld, int dt,
-                       const int* pool_idx, hipStream_t s) {
-    const bool fold = g_ln_fold != 0 && W % 64 == 0;
-    if (fold) TRY(ofx_launch_row_stats_cast(w.X, w.XB, w.S, rows, W, eps, dt, s));     // layer 0's LayerNorm-1 inputs
+                       const int* pool_idx, hipStream_t s, bool stats_ready = false) {
+    const bool fold = clip_fold(W);
+    if (fold && !stats_ready) TRY(ofx_launch_row_stats_cast(w.X, w.XB, w.S, rows, W, eps, dt, s));     // layer 0's LayerNorm-1 inputs
     for (size_t l = 0; l < Ls.size(); ++l)
         TRY(clip_layer(Ls[l], w, rows, nseq, S, W, MLP, heads, act, eps, causal, key_mask, mask_ld, dt,
                        l + 1 == Ls.size() ? pool_idx : nullptr, s, fold));
@@ -635,9 +636,11 @@ extern "C" int ofx_vit_b32_fwd(ofx_handle* h, const float* pixels, int N, float*
         GemmArgs gp{}; gp.A = w.U; gp.W = h->v_patch_w; gp.C = w.QKV; gp.M = n * g * g; gp.N = W; gp.K = KP; gp.lda = KP; gp.ldc = W;
         gp.act = OFX_ACT_NONE; gp.out_kind = OFX_OUT_F32;
         TRY(ofx_launch_gemm(gp, dt, s));
-        TRY(ofx_launch_vit_embed_ln((const float*)w.QKV, h->v_cls, h->v_pos, h->v_pre_g, h->v_pre_b, w.X, n, S, W, d.ln_eps, s));
+        const bool fold = clip_fold(W);                                  // the pre-LN kernel then also emits layer 0's operand copy + statistics
+        TRY(ofx_launch_vit_embed_ln((const float*)w.QKV, h->v_cls, h->v_pos, h->v_pre_g, h->v_pre_b, w.X, n, S, W, d.ln_eps, s, fold ? w.XB : nullptr,
+                                    fold ? w.S : nullptr, dt));
         TRY(ofx_launch_iota_rows(w.idx, n, S, s));                        // CLS rows
-        TRY(clip_layers(h->vl, w, rows, n, S, W, d.vit_mlp, d.vit_heads, d.vit_act, d.ln_eps, 0, nullptr, 0, dt, w.idx, s));
+        TRY(clip_layers(h->vl, w, rows, n, S, W, d.vit_mlp, d.vit_heads, d.vit_act, d.ln_eps, 0, nullptr, 0, dt, w.idx, s, fold));
         LnArgs ln{w.XP, nullptr, h->v_post_g, h->v_post_b, w.PL, n, W, W, OFX_OUT_OP, d.ln_eps};
         TRY(ofx_launch_layernorm(ln, dt, s));
         GemmArgs gj{}; gj.A = w.PL; gj.W = h->v_proj_w; gj.C = w.E; gj.M = n; gj.N = d.proj_dim; gj.K = W; gj.lda = W; gj.ldc = d.proj_dim;

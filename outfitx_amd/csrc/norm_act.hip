@@ -156,10 +156,12 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* px, T* out, 
 }
 
 // x[n*50 + t] = LN( (t == 0 ? cls : patch_out[n*49 + t-1]) + pos[t] )  -> fp32 residual stream
-template <int NCH>
+// Optionally (LayerNorm folding) also the operand-type copy of the output row and its (mean, rstd): layer 0's LayerNorm-1 inputs.
+template <int NCH, typename T>
 __global__ __launch_bounds__(256) void vit_embed_ln_kernel(const float* patch_out, const float* cls, const float* pos,
                                                           const float* gamma, const float* beta, float* x, int N, int S,
-                                                          float eps) {
+                                                          float eps, T* xb, float* stat) {
+    typedef typename OpT<T>::v4 v4;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int D = NCH * 256, rows = N * S;
     for (int r = blockIdx.x * 4 + w; r < rows; r += gridDim.x * 4) {
@@ -181,10 +183,27 @@ __global__ __launch_bounds__(256) void vit_embed_ln_kernel(const float* patch_ou
             q += v[c][0] * v[c][0] + v[c][1] * v[c][1] + v[c][2] * v[c][2] + v[c][3] * v[c][3];
         }
         const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+        float so = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int col = (lane + 64 * c) * 4;
-            *(f32x4*)(x + (size_t)r * D + col) = v[c] * rstd * *(const f32x4*)(gamma + col) + *(const f32x4*)(beta + col);
+            v[c] = v[c] * rstd * *(const f32x4*)(gamma + col) + *(const f32x4*)(beta + col);
+            *(f32x4*)(x + (size_t)r * D + col) = v[c];
+            so += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+        }
+        if (xb) {
+            const float mo = wave_sum(so) * (1.0f / D);
+            float qo = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int col = (lane + 64 * c) * 4;
+                v4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float dlt = v[c][e] - mo; qo += dlt * dlt; o[e] = (T)v[c][e]; }
+                *(v4*)(xb + (size_t)r * D + col) = o;
+            }
+            qo = wave_sum(qo);
+            if (lane == 0) { stat[2 * (size_t)r] = mo; stat[2 * (size_t)r + 1] = rsqrtf(qo * (1.0f / D) + eps); }
         }
     }
 }
@@ -426,13 +445,14 @@ int ofx_launch_patchify(const float* px, void* out, int N, int img, int patch, i
     return OFX_OK;
 }
 int ofx_launch_vit_embed_ln(const float* patch_out, const float* cls, const float* pos, const float* g, const float* b,
-                            float* x, int N, int S, int D, float eps, hipStream_t s) {
+                            float* x, int N, int S, int D, float eps, hipStream_t s, void* xb, float* stat, int op_dtype) {
     OFX_REQUIRE(D == 768 || D == 512 || D == 1024, OFX_ESHAPE, "vit_embed_ln: D=%d", D);
     const int grid = rows_grid(N * S);
     ProfScope prof(PROF_NORM, s);
-    if (D == 768) hipLaunchKernelGGL(vit_embed_ln_kernel<3>, dim3(grid), dim3(256), 0, s, patch_out, cls, pos, g, b, x, N, S, eps);
-    else if (D == 512) hipLaunchKernelGGL(vit_embed_ln_kernel<2>, dim3(grid), dim3(256), 0, s, patch_out, cls, pos, g, b, x, N, S, eps);
-    else hipLaunchKernelGGL(vit_embed_ln_kernel<4>, dim3(grid), dim3(256), 0, s, patch_out, cls, pos, g, b, x, N, S, eps);
+#define VEL(NCH, T) hipLaunchKernelGGL((vit_embed_ln_kernel<NCH, T>), dim3(grid), dim3(256), 0, s, patch_out, cls, pos, g, b, x, N, S, eps, (T*)xb, stat)
+    if (op_dtype == OFX_F16) { if (D == 768) VEL(3, f16_t); else if (D == 512) VEL(2, f16_t); else VEL(4, f16_t); }
+    else { if (D == 768) VEL(3, bf16_t); else if (D == 512) VEL(2, bf16_t); else VEL(4, bf16_t); }
+#undef VEL
     OFX_LAUNCH_CHECK();
     return OFX_OK;
 }

@@ -213,7 +213,7 @@ int ofx_launch_pack_rows(const float* src, void* dst, int rows_src, int rows_dst
                          int mode, int op_dtype, hipStream_t s);
 int ofx_launch_patchify(const float* px, void* out, int N, int img, int patch, int op_dtype, hipStream_t s);
 int ofx_launch_vit_embed_ln(const float* patch_out, const float* cls, const float* pos, const float* g, const float* b,
-                            float* x, int N, int S, int D, float eps, hipStream_t s);
+                            float* x, int N, int S, int D, float eps, hipStream_t s, void* xb = nullptr, float* stat = nullptr, int op_dtype = OFX_BF16);
 int ofx_launch_text_embed(const int64_t* ids, const float* tok, const float* pos, float* x, int N, int T, int Tc, int D,
                           int vocab, hipStream_t s);
 int ofx_launch_text_eos_index(const int64_t* ids, int* row_idx, int N, int T, int Tc, int eos_id, hipStream_t s);
