@@ -445,6 +445,8 @@ extern "C" size_t ofx_workspace_bytes(ofx_handle* h, int op, int n, int len) {
 
 // --------------------------------------------------------------------------- outfit transformer
 // The set input in either form: a padded [B, L, D] tensor + mask, or (indexed / varlen) item rows of a device-resident table.
+int g_train_mfma_attn = 1;   // ofx_tune(7, v): single-product precisions (training; scoring in bf16 / f16) use the MFMA varlen attention (1) or the fp32 set kernels (0)
+
 struct SetInput {
     const float* x = nullptr; const uint8_t* pad_mask = nullptr;                                   // dense
     const float* table = nullptr; int ld = 0; long long n_table = 0; const int* item_index = nullptr; const int* cu_items = nullptr;   // indexed
@@ -493,11 +495,21 @@ static int set_encoder_core(ofx_handle* h, const SetInput& in, const float* pref
         LnArgs ln{w.X, nullptr, Ly.g1, Ly.be1, w.H, M, D, km * D, okind, d.ln_eps};
         TRY(ofx_launch_layernorm_dev(ln, m_dev, dt, s));
         GemmArgs g1{}; g1.A = w.H; g1.W = Ly.w_in; g1.C = w.QKV; g1.bias = Ly.b_in; g1.resid = nullptr; g1.m_dev = m_dev;
-        g1.M = M; g1.N = 3 * D; g1.K = km * D; g1.lda = km * D; g1.ldc = 3 * D; g1.ldr = 0; g1.act = OFX_ACT_NONE; g1.out_kind = OFX_OUT_F32;
+        g1.M = M; g1.N = 3 * D; g1.K = km * D; g1.lda = km * D; g1.ldc = 3 * D; g1.ldr = 0; g1.act = OFX_ACT_NONE;
+        // single-product precisions: q|k|v stay in the operand type and the varlen MFMA attention runs (as in the training forward);
+        // bf16x3 keeps fp32 q|k|v and the fp32 set attention (1e-5 parity)
+        const bool mfma_attn = km == 1 && g_train_mfma_attn;
+        g1.out_kind = mfma_attn ? OFX_OUT_OP : OFX_OUT_F32;
         g1.slab = w.slab; g1.slab_bytes = w.slab_bytes;
         TRY(ofx_launch_gemm(g1, dt, s));
-        SetAttnArgs sa{w.QKV, w.H, w.cu, B, d.n_head, D, km * D, okind, L + 1, last ? 1 : 0, 0.125f};
-        TRY(ofx_launch_set_attention(sa, dt, s));
+        if (mfma_attn) {
+            AttnArgs at{w.QKV, w.H, nullptr, B, L + 1, d.n_head, 3 * D, D, D, 2 * D, 0, 0, 0.125f};
+            at.cu_seqlens = w.cu; at.only_row0 = last ? 1 : 0;
+            TRY(ofx_launch_attention_mfma(at, dt, s));
+        } else {
+            SetAttnArgs sa{w.QKV, w.H, w.cu, B, d.n_head, D, km * D, okind, L + 1, last ? 1 : 0, 0.125f};
+            TRY(ofx_launch_set_attention(sa, dt, s));
+        }
         float* X = w.X; char* H = w.H; char* U = w.U; int Ml = M; const int* md = m_dev;
         if (last) {
             TRY(ofx_launch_gather_rows(w.H, w.cu, w.HP, B, km * D * 2, km * D * 2, s));
@@ -549,7 +561,6 @@ extern "C" int ofx_cir_prefix(ofx_handle* h, const float* txt, int B, float* out
 // ------------------------------------------------------------------------------------ CLIP towers
 // One CLIP encoder layer on `rows` rows.  When `pool_idx` is given (last layer) everything after the attention
 // runs only on the n pooled rows (CLS / EOS): they are the only ones the tower's output depends on.
-int g_train_mfma_attn = 1;   // ofx_tune(7, v): training forward uses the MFMA varlen attention (1) or the fp32 set kernel (0)
 int g_ln_fold = 1;      // ofx_tune(6, v): 0 = materialise every LayerNorm, 1 = fold the towers' LayerNorms into the GEMM epilogues
 
 // fold == true: on entry w.XB / w.S hold the operand copy and the (mean, rstd) of X; on exit (non-pooled layers) they hold
