@@ -37,6 +37,9 @@ with torch.no_grad():
         f = lambda: model(task=CP, outfit_embedding=e, outfit_mask=m)
         t = timeit(f)
         rec = {"config": "cfg1" if B == 32 else f"cfg1-B{B}", "what": f"CP forward, {B} precomputed outfits (8 of 16 items), bf16x3", "ms": round(t * 1e3, 4), "outfits_per_s": round(B / t, 1)}
+        if B == 32:       # cfg1 is weight-stream bound - 51,155,313 weights x 2 B once per forward (x3 operand copies in bf16x3)
+            rec["weight_stream_GBps_bf16"] = round(51_155_313 * 2 / t / 1e9, 1)
+            rec["weight_stream_GBps_as_executed_x3"] = round(51_155_313 * 6 / t / 1e9, 1)
         # the same launch sequence captured in a hipGraph (launch-bound at small B)
         out = f(); torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()

@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--eager", action="store_true")
+    ap.add_argument("--polyvore", action="store_true", help="SURVEY.md §8d config 5 inputs: outfit lengths uniform{2..8} padded to 16, labels Bernoulli(0.5)")
     a = ap.parse_args()
     from src.losses import FocalLoss
     from src.models import OutfitX
@@ -60,9 +61,10 @@ def main():
     m = m.cuda().train()
     params = [v for k, v in m.named_parameters() if not k.startswith("item_encoder.")]
     opt = torch.optim.AdamW(params, lr=2e-5)
-    emb, mask = synth.outfit_batch(99, a.batch, a.pad, a.items)
+    n_items = synth.ragged_lengths(99, a.batch, 2, 8) if a.polyvore else a.items
+    emb, mask = synth.outfit_batch(99, a.batch, a.pad, n_items)
     emb, mask = torch.from_numpy(emb).cuda(), torch.from_numpy(mask).cuda()
-    labels = (torch.arange(a.batch) % 2).float().cuda()
+    labels = (torch.from_numpy(np.random.default_rng(99).random(a.batch) < 0.5).float() if a.polyvore else (torch.arange(a.batch) % 2).float()).cuda()
     loss_fn = FocalLoss(alpha=0.75, gamma=2, reduction="mean")
 
     def fwd_bwd():
@@ -81,7 +83,8 @@ def main():
         eng = m._engine(a.precision)
         eng.cp_train_fwd(emb, mask)
 
-    res = {"workload": f"CP trainer step, {a.batch} outfits x {a.items} items (padded {a.pad}), precomputed embeddings",
+    what = "2..8 items (uniform)" if a.polyvore else f"{a.items} items"
+    res = {"workload": f"CP trainer step, {a.batch} outfits x {what} (padded {a.pad}), precomputed embeddings",
            "precision": a.precision}
     res["ms_step"] = timed(step, a.steps, a.warmup)
     res["ms_fwd_bwd"] = timed(lambda: (opt.zero_grad(set_to_none=True), fwd_bwd()), a.steps, a.warmup)
@@ -103,7 +106,7 @@ def main():
         res["ms_step_dp" if acc == 1 else "ms_step_dp_accum4"] = timed(dp_step, a.steps if acc == 1 else 4 * max(a.steps // 4, 1), a.warmup if acc == 1 else 4)
     res["world"] = world
     res["outfits_per_s_dp"] = world * a.batch / res["ms_step_dp"] * 1e3
-    rows = a.batch * (a.items + 1)
+    rows = int(np.sum(n_items) + a.batch) if a.polyvore else a.batch * (a.items + 1)
     D, Fp = 1024, 2048
     res["gemm_tflop_per_step"] = 3 * 2 * rows * (4 * D * D + 2 * Fp * D) * 6 / 1e12
     res["tflops"] = res["gemm_tflop_per_step"] / (res["ms_fwd_bwd"] * 1e-3)
