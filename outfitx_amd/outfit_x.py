@@ -215,6 +215,7 @@ class OutfitX(nn.Module):
         return out
 
     def _engine(self, precision: Optional[str] = None) -> Engine:
+        _LIVE_MODELS.add(self)               # (also covers unpickled / deep-copied instances, whose __init__ never ran)
         dev = self.device
         precision = precision or self.precision
         key = (dev, precision)
