@@ -462,3 +462,32 @@ def test_fused_optimizer_steps_are_noticed():
     with torch.no_grad():
         y2 = m(task=CP, outfit_embedding=x, outfit_mask=k)          # the scoring engine (bf16x3 copies) is re-packed too
     assert float((y2 - y1).abs().max()) < 0.05 * float(y1.abs().max()) + 0.05
+
+
+def test_training_step_under_distributed_data_parallel():
+    """The reference wraps the model in DistributedDataParallel (distributed_trainer.py:315-329).  Our hand-written backward
+    reaches DDP's gradient hooks like any autograd node: a world-size-1 RCCL group, DDP(find_unused_parameters=True) as the
+    reference configures it, one step - gradients equal the unwrapped model's."""
+    import socket
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from src.models.datatypes import OutfitCompatibilityPredictionTask as CP
+    emb, mask = synth.outfit_batch(31, 6, 16, synth.ragged_lengths(31, 6, 1, 10))
+    up = torch.linspace(-1.0, 2.0, 6).cuda()
+    plain = make_model("bf16")
+    (plain(task=CP, outfit_embedding=cu(emb), outfit_mask=cu(mask)).squeeze(-1) * up).sum().backward()
+    want = {k: v.grad.clone() for k, v in trainable(plain).items() if v.grad is not None}
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        m = make_model("bf16")
+        ddp = DDP(m, device_ids=[0], find_unused_parameters=True, broadcast_buffers=True)
+        (ddp(task=CP, outfit_embedding=cu(emb), outfit_mask=cu(mask)).squeeze(-1) * up).sum().backward()
+        got = {k: v.grad.clone() for k, v in trainable(m).items() if v.grad is not None}
+    finally:
+        dist.destroy_process_group()
+    assert set(got) >= set(want)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
