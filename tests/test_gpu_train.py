@@ -491,3 +491,41 @@ def test_training_step_under_distributed_data_parallel():
     assert set(got) >= set(want)
     for k in want:
         assert torch.equal(got[k], want[k]), k
+
+
+def test_reference_trainer_step_verbatim():
+    """The reference's train_epoch body (compatibility_prediction_trainer.py:57-81) line for line against our model: autocast,
+    FocalLoss, /accumulation, GradScaler.scale(loss).backward(), unscale_, clip_grad_norm_, scaler.step, update, zero_grad,
+    OneCycleLR - two optimizer steps with accumulation 2 and dropout 0.3; the loss stays finite and the weights move."""
+    from torch.amp import GradScaler, autocast
+    from src.losses import FocalLoss
+    from src.models.datatypes import OutfitCompatibilityPredictionTask as CP
+    model = make_model("bf16", dropout=0.3)
+    params = [p for p in model.parameters() if p.requires_grad]
+    optimizer = torch.optim.AdamW(model.parameters(), lr=2e-5)
+    scheduler = torch.optim.lr_scheduler.OneCycleLR(optimizer=optimizer, max_lr=2e-5, epochs=1, steps_per_epoch=2, pct_start=0.3,
+                                                    anneal_strategy="cos", div_factor=25, final_div_factor=1e4)
+    scaler, loss_fn, accumulation_steps = GradScaler(), FocalLoss(alpha=0.75, gamma=2, reduction="mean"), 2
+    w0 = model.transformer_encoder.layers[0].linear1.weight.detach().clone()
+    optimizer.zero_grad()
+    losses = []
+    for step in range(4):
+        emb, mask = synth.outfit_batch(100 + step, 16, 16, synth.ragged_lengths(100 + step, 16, 1, 12))
+        input_dict = {"task": CP, "outfit_embedding": torch.from_numpy(emb).to(0), "outfit_mask": torch.from_numpy(mask).to(0)}
+        with autocast(enabled=True, device_type="cuda"):
+            y_hats = model(**input_dict).squeeze(dim=-1)
+            labels = (torch.arange(16) % 2).float().to(0)
+            loss = loss_fn(y_hat=y_hats, y_true=labels)
+            original_loss = loss.clone().detach()
+            loss = loss / accumulation_steps
+        scaler.scale(loss).backward()
+        if (step + 1) % accumulation_steps == 0:
+            scaler.unscale_(optimizer)
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+            scaler.step(optimizer)
+            scaler.update()
+            optimizer.zero_grad()
+            scheduler.step()
+        losses.append(float(original_loss))
+    assert all(np.isfinite(losses)) and len(params) == 77          # 75 on the CP path + target_item_image_emb + cir_ffn (no gradient here)
+    assert not torch.equal(model.transformer_encoder.layers[0].linear1.weight.detach(), w0)
