@@ -134,6 +134,14 @@ int ofx_topk_merge(const int64_t* idx_in, const float* dist_in, int parts, int n
 size_t ofx_clip_preprocess_ws(const int* heights, const int* widths, int N, int channels, int size);
 int ofx_clip_preprocess(const uint8_t* src, const long long* offsets, const int* heights, const int* widths, int N, int channels, int size,
                         const float* mean, const float* stdv, float* out, void* ws, size_t ws_bytes, ofx_stream stream);
+/* The two fused: decoded uint8 images -> image embeddings (clip_image_encoder.py:66-76 in one call).  The preprocessor's
+ * vertical pass writes the operand-type im2col rows of the patch-embedding GEMM directly, so neither the fp32 pixel_values
+ * tensor (0.6 MB / image) nor the patchify pass exists; results equal ofx_clip_preprocess + ofx_vit_b32_fwd bit for bit.
+ * mean / stdv: the processor's image_mean / image_std (host, 3 floats); size and patch come from the model descriptor. */
+size_t ofx_vit_b32_u8_ws_bytes(ofx_handle* h, const int* heights, const int* widths, int N, int channels);
+int ofx_vit_b32_fwd_u8(ofx_handle* h, const uint8_t* src, const long long* offsets, const int* heights, const int* widths, int N, int channels,
+                       const float* mean, const float* stdv, float* emb, int emb_ld, int emb_col, int normalize, void* ws, size_t ws_bytes,
+                       ofx_stream stream);
 
 /* ------------------------------------------------------------------ indexed (varlen) set input ("next" row N3) --- */
 /* The same encoder with the outfits given as ROW INDICES into a device-resident embedding table [n_table, ld] fp32

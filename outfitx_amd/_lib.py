@@ -57,6 +57,8 @@ SIGNATURES = {
     "ofx_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "ofx_clip_preprocess_ws": (_sz, [_vp, _vp, _i, _i, _i]),
     "ofx_clip_preprocess": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ofx_vit_b32_u8_ws_bytes": (_sz, [_vp, _vp, _vp, _i, _i]),
+    "ofx_vit_b32_fwd_u8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "ofx_set_encoder_fwd_indexed": (_i, [_vp, _vp, _i, C.c_longlong, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ofx_cp_train_fwd_indexed": (_i, [_vp, _vp, _i, C.c_longlong, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp, _sz, _f, C.c_uint, _vp]),
     "ofx_cp_train_tape_bytes": (_sz, [_vp, _i, _i]),

@@ -625,10 +625,16 @@ static int clip_layers(const std::vector<ClipLayer>& Ls, const ClipWs& w, int ro
     return OFX_OK;
 }
 
-extern "C" int ofx_vit_b32_fwd(ofx_handle* h, const float* pixels, int N, float* emb, int emb_ld, int emb_col,
-                               int normalize, void* ws, size_t ws_bytes, ofx_stream stream) {
+// Raw decoded images for the fused preprocess -> patch-embedding route (ofx_vit_b32_fwd_u8)
+struct RawImages {
+    const uint8_t* src; const long long* offsets; const int* heights; const int* widths; int channels; const float* mean; const float* stdv;
+    void* ws; size_t ws_bytes;
+};
+
+static int vit_core(ofx_handle* h, const float* pixels, const RawImages* raw, int N, float* emb, int emb_ld, int emb_col,
+                    int normalize, void* ws, size_t ws_bytes, ofx_stream stream) {
     OFX_REQUIRE(h && h->vis_ready, OFX_ESTATE, "vit_b32_fwd: vision weights not packed");
-    OFX_REQUIRE(pixels && emb && ws && N > 0, OFX_EINVAL, "vit_b32_fwd: bad argument");
+    OFX_REQUIRE((pixels || raw) && emb && ws && N > 0, OFX_EINVAL, "vit_b32_fwd: bad argument");
     const ofx_model_desc& d = h->d;
     OFX_REQUIRE(emb_ld >= emb_col + d.proj_dim && emb_ld % 4 == 0 && emb_col % 4 == 0, OFX_ESHAPE, "vit_b32_fwd: bad emb_ld/emb_col");
     hipStream_t s = (hipStream_t)stream;
@@ -643,7 +649,11 @@ extern "C" int ofx_vit_b32_fwd(ofx_handle* h, const float* pixels, int N, float*
         ClipWs w;
         vit_bytes(h, n, &w, ws, ws_bytes);
         const int rows = n * S;
-        TRY(ofx_launch_patchify(pixels + (size_t)n0 * px_per_img, w.U, n, d.vit_image, d.vit_patch, dt, s));
+        if (raw)      // resample + normalise straight into the GEMM operand: no fp32 pixel tensor, no patchify pass
+            TRY(ofx_preprocess_to(raw->src, raw->offsets + n0, raw->heights + n0, raw->widths + n0, n, raw->channels, d.vit_image, raw->mean, raw->stdv,
+                                  nullptr, w.U, d.vit_patch, dt, raw->ws, raw->ws_bytes, s));
+        else
+            TRY(ofx_launch_patchify(pixels + (size_t)n0 * px_per_img, w.U, n, d.vit_image, d.vit_patch, dt, s));
         GemmArgs gp{}; gp.A = w.U; gp.W = h->v_patch_w; gp.C = w.QKV; gp.M = n * g * g; gp.N = W; gp.K = KP; gp.lda = KP; gp.ldc = W;
         gp.act = OFX_ACT_NONE; gp.out_kind = OFX_OUT_F32;
         TRY(ofx_launch_gemm(gp, dt, s));
@@ -660,6 +670,28 @@ extern "C" int ofx_vit_b32_fwd(ofx_handle* h, const float* pixels, int N, float*
         TRY(ofx_launch_l2norm_store(w.E, emb + (size_t)n0 * emb_ld, n, d.proj_dim, emb_ld, emb_col, normalize, s));
     }
     return OFX_OK;
+}
+
+extern "C" int ofx_vit_b32_fwd(ofx_handle* h, const float* pixels, int N, float* emb, int emb_ld, int emb_col,
+                               int normalize, void* ws, size_t ws_bytes, ofx_stream stream) {
+    OFX_REQUIRE(pixels, OFX_EINVAL, "vit_b32_fwd: pixels is NULL");
+    return vit_core(h, pixels, nullptr, N, emb, emb_ld, emb_col, normalize, ws, ws_bytes, stream);
+}
+
+extern "C" size_t ofx_vit_b32_u8_ws_bytes(ofx_handle* h, const int* heights, const int* widths, int N, int channels) {
+    if (!h || N <= 0) return 0;
+    const size_t pre = ofx_clip_preprocess_ws(heights, widths, N, channels, h->d.vit_image);
+    return pre ? align_up(pre, 256) + vit_bytes(h, std::min(N, VIT_CHUNK_MAX), nullptr, nullptr, ~(size_t)0) : 0;
+}
+
+extern "C" int ofx_vit_b32_fwd_u8(ofx_handle* h, const uint8_t* src, const long long* offsets, const int* heights, const int* widths, int N, int channels,
+                                  const float* mean, const float* stdv, float* emb, int emb_ld, int emb_col, int normalize, void* ws, size_t ws_bytes,
+                                  ofx_stream stream) {
+    OFX_REQUIRE(h && src && offsets && heights && widths && mean && stdv && N > 0, OFX_EINVAL, "vit_b32_fwd_u8: bad argument");
+    const size_t pre = align_up(ofx_clip_preprocess_ws(heights, widths, N, channels, h->d.vit_image), 256);
+    OFX_REQUIRE(pre > 0 && pre < ws_bytes, OFX_EWORKSPACE, "vit_b32_fwd_u8: workspace %zu bytes, the preprocessor alone needs %zu", ws_bytes, pre);
+    RawImages raw{src, offsets, heights, widths, channels, mean, stdv, ws, pre};       // [preprocess scratch | ViT workspace]
+    return vit_core(h, nullptr, &raw, N, emb, emb_ld, emb_col, normalize, (char*)ws + pre, ws_bytes - pre, stream);
 }
 
 extern "C" int ofx_clip_text_fwd(ofx_handle* h, const int64_t* ids, const int64_t* attn_mask, const int* lengths_host,

@@ -224,6 +224,8 @@ int ofx_launch_set_build(const float* x, const uint8_t* mask, const float* prefi
 int ofx_launch_gather_rows(const void* src, const int* idx, void* dst, int rows, int row_bytes, int src_ld_bytes, hipStream_t s);
 int ofx_launch_set_build_indexed(const float* table, int ld, long long n_table, const int* idx, const int* cu_items, const float* prefix,
                                  int prefix_stride, int* cu_rows, float* X, int B, int D, hipStream_t s);
+int ofx_preprocess_to(const uint8_t* src, const long long* offsets, const int* heights, const int* widths, int N, int channels, int size,
+                      const float* mean, const float* stdv, float* out, void* patches, int patch, int op_dtype, void* ws, size_t ws_bytes, hipStream_t stream);
 int ofx_launch_row_stats_cast(const float* X, void* Xb, float* stat, int rows, int W, float eps, int op_dtype, hipStream_t s);
 int ofx_launch_stats_finalize(const float* part, int slots, int W, float eps, float* stat, int rows, hipStream_t s);
 int ofx_launch_fold_pack(const float* Wsrc, const float* gamma, const float* beta, const float* bias, void* Wf, float* col_sum, float* bias_f,

@@ -15,6 +15,7 @@
 #include <vector>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 #include "ofx_common.h"
 
@@ -108,7 +109,11 @@ __device__ __forceinline__ float mul_then_sub(float a, float b, float c) {
 // ---- vertical pass + rescale + normalise -> planar fp32 [N, 3, size, size].  float ops are individually rounded
 // (no fma contraction) so the result equals numpy's (a * f32(1/255) - mean) / std bit for bit.
 constexpr int ROWS_V = 8;
-__global__ __launch_bounds__(256) void resample_v_kernel(const ImgDesc* descs, const int* blob, const uint8_t* inter, float* out, int size,
+// TO = float: planar fp32 pixel_values [N, 3, size, size].  TO = bf16 / f16: the im2col operand of the ViT patch-embedding GEMM,
+// [N * (size/patch)^2, 3 * patch^2] with column c * patch^2 + ky * patch + kx (what patchify_kernel makes of the fp32 pixels) -
+// the fp32 pixel tensor is then never written.
+template <typename TO>
+__global__ __launch_bounds__(256) void resample_v_kernel(const ImgDesc* descs, const int* blob, const uint8_t* inter, TO* out, int size, int patch,
                                                          float m0, float m1, float m2, float s0d, float s1d, float s2d) {
     const ImgDesc d = descs[blockIdx.y];
     const int* plan = blob + d.vplan;
@@ -117,8 +122,9 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const ImgDesc* descs, c
     const int* coef = plan + 1 + 2 * size;
     const unsigned* in = (const unsigned*)(inter + d.inter_off);
     const float r255 = (float)(1.0 / 255.0);
-    float* o = out + (size_t)blockIdx.y * 3 * size * size;
-    const int total = size * size;
+    constexpr bool PATCHES = !std::is_same<TO, float>::value;
+    const int total = size * size, g = PATCHES ? size / patch : 1, pp = patch * patch;
+    TO* o = out + (size_t)blockIdx.y * 3 * size * size;          // both layouts hold 3 * size^2 elements per image
     for (int rr = 0; rr < ROWS_V; ++rr) {
         const int row = blockIdx.x * ROWS_V + rr;               // block-uniform: bounds and coefficients come through scalar loads
         if (row >= size) break;
@@ -133,10 +139,16 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const ImgDesc* descs, c
                 a0 += (int)(v & 255u) * kv; a1 += (int)((v >> 8) & 255u) * kv; a2 += (int)((v >> 16) & 255u) * kv;
             }
             const float v0 = (float)min(max(a0 >> PBITS, 0), 255), v1 = (float)min(max(a1 >> PBITS, 0), 255), v2 = (float)min(max(a2 >> PBITS, 0), 255);
-            const int p = row * size + col;
-            o[p] = __fdiv_rn(mul_then_sub(v0, r255, m0), s0d);
-            o[total + p] = __fdiv_rn(mul_then_sub(v1, r255, m1), s1d);
-            o[2 * total + p] = __fdiv_rn(mul_then_sub(v2, r255, m2), s2d);
+            const float f0 = __fdiv_rn(mul_then_sub(v0, r255, m0), s0d), f1 = __fdiv_rn(mul_then_sub(v1, r255, m1), s1d),
+                        f2 = __fdiv_rn(mul_then_sub(v2, r255, m2), s2d);
+            if (PATCHES) {
+                const int py = row / patch, ky = row - py * patch, pxi = col / patch, kx = col - pxi * patch;
+                TO* q = o + (size_t)(py * g + pxi) * 3 * pp + ky * patch + kx;
+                q[0] = (TO)f0; q[pp] = (TO)f1; q[2 * pp] = (TO)f2;
+            } else {
+                const int p = row * size + col;
+                o[p] = (TO)f0; o[total + p] = (TO)f1; o[2 * total + p] = (TO)f2;
+            }
         }
     }
 }
@@ -262,7 +274,15 @@ extern "C" size_t ofx_clip_preprocess_ws(const int* heights, const int* widths, 
 
 extern "C" int ofx_clip_preprocess(const uint8_t* src, const long long* offsets, const int* heights, const int* widths, int N, int channels, int size,
                                    const float* mean, const float* stdv, float* out, void* ws, size_t ws_bytes, ofx_stream stream) {
-    OFX_REQUIRE(src && offsets && heights && widths && mean && stdv && out && ws && N > 0, OFX_EINVAL, "clip_preprocess: NULL argument");
+    return ofx_preprocess_to(src, offsets, heights, widths, N, channels, size, mean, stdv, out, nullptr, 0, 0, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// out != NULL: fp32 pixel_values; patches != NULL: operand-type im2col rows of the patch-embedding GEMM (exactly one of the two)
+int ofx_preprocess_to(const uint8_t* src, const long long* offsets, const int* heights, const int* widths, int N, int channels, int size,
+                      const float* mean, const float* stdv, float* out, void* patches, int patch, int op_dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
+    OFX_REQUIRE((out != nullptr) != (patches != nullptr), OFX_EINVAL, "clip_preprocess: exactly one output");
+    OFX_REQUIRE(!patches || (patch > 0 && size % patch == 0), OFX_ESHAPE, "clip_preprocess: size=%d patch=%d", size, patch);
+    OFX_REQUIRE(src && offsets && heights && widths && mean && stdv && ws && N > 0, OFX_EINVAL, "clip_preprocess: NULL argument");
     OFX_REQUIRE((channels == 3 || channels == 1) && size > 0 && size <= 1024, OFX_ESHAPE, "clip_preprocess: channels=%d size=%d", channels, size);
     hipStream_t s = (hipStream_t)stream;
     Batch b;
@@ -293,8 +313,12 @@ extern "C" int ofx_clip_preprocess(const uint8_t* src, const long long* offsets,
     if (channels == 3 && b.max_ksize_h <= 8) hipLaunchKernelGGL(resample_h_kernel<8>, gh, dim3(256), 0, s, src, d_desc, d_blob, d_inter, size);
     else if (channels == 3 && b.max_ksize_h <= 16) hipLaunchKernelGGL(resample_h_kernel<16>, gh, dim3(256), 0, s, src, d_desc, d_blob, d_inter, size);
     else hipLaunchKernelGGL(resample_h_kernel<0>, gh, dim3(256), 0, s, src, d_desc, d_blob, d_inter, size);
-    hipLaunchKernelGGL(resample_v_kernel, dim3((size + ROWS_V - 1) / ROWS_V, N), dim3(256), 0, s, d_desc, d_blob, d_inter, out, size, mean[0], mean[1], mean[2], stdv[0],
-                       stdv[1], stdv[2]);
+    const dim3 gv((size + ROWS_V - 1) / ROWS_V, N);
+#define RV(TO, dst) hipLaunchKernelGGL(resample_v_kernel<TO>, gv, dim3(256), 0, s, d_desc, d_blob, d_inter, (TO*)(dst), size, patch, mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2])
+    if (out) RV(float, out);
+    else if (op_dtype == OFX_F16) RV(f16_t, patches);
+    else RV(bf16_t, patches);
+#undef RV
     OFX_LAUNCH_CHECK();
     return OFX_OK;
 }

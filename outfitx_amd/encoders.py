@@ -273,31 +273,44 @@ class CLIPImageEncoder(_TowerBase):
     def d_embed(self) -> int:
         return self.model.config.projection_dim
 
-    def _pixels(self, images) -> Tuple[torch.Tensor, int]:
+    def _pixels(self, images):
+        """-> (pixel_values tensor or None, list of uint8 arrays or None, B).  uint8 / PIL input on a HIP device is handed
+        to the GPU preprocessor as packed bytes; anything else goes through the host pipeline."""
         if isinstance(images, torch.Tensor):
             b = images.size(0)
-            return images.reshape(b * images.size(1), *images.shape[2:]), b
+            return images.reshape(b * images.size(1), *images.shape[2:]), None, b
         if len(set(len(seq) for seq in images)) != 1:
             raise ValueError("All sequences in images should have the same length.")
         flat = flatten_seq_to_one_dim(images)
         arrs = [np.asarray(im if not isinstance(im, Image.Image) or im.mode in ("RGB", "L") else im.convert("RGB")) for im in flat]
         if all(a.dtype == np.uint8 for a in arrs) and self.device.type == "cuda":
-            # resize / crop / normalise on the GPU from the packed uint8 bytes, bit-identical to the host pipeline
-            return self._engine("vision").clip_preprocess(arrs, self.model.config.image_size, CLIP_MEAN, CLIP_STD), len(images)
-        return clip_preprocess(flat, self.model.config.image_size), len(images)
+            return None, arrs, len(images)
+        return clip_preprocess(flat, self.model.config.image_size), None, len(images)
+
+    def _run(self, px, arrs, out: torch.Tensor, col: int, normalize: bool) -> None:
+        eng = self._engine("vision")
+        if arrs is None:
+            eng.vit(px, out, col, normalize)
+        elif self.fused_preprocess:      # resample -> patch-embedding operand, no pixel tensor (ofx_vit_b32_fwd_u8)
+            eng.vit_u8(arrs, CLIP_MEAN, CLIP_STD, out, col, normalize)
+        else:
+            eng.vit(eng.clip_preprocess(arrs, self.model.config.image_size, CLIP_MEAN, CLIP_STD), out, col, normalize)
+
+    fused_preprocess = True
 
     @torch.no_grad()
     def encode_into(self, images, out: torch.Tensor, col: int, normalize: bool) -> int:
         """Run the tower and write [N,512] into out[:, col:col+512]; returns the batch size B."""
-        px, b = self._pixels(images)
-        self._engine("vision").vit(px, out, col, normalize)
+        px, arrs, b = self._pixels(images)
+        self._run(px, arrs, out, col, normalize)
         return b
 
     @torch.no_grad()
     def forward(self, images, normalize: bool = True, *args, **kwargs) -> torch.Tensor:
-        px, b = self._pixels(images)
-        out = torch.empty(px.shape[0], self.d_embed, dtype=torch.float32, device=self.device)
-        self._engine("vision").vit(px, out, 0, normalize)
+        px, arrs, b = self._pixels(images)
+        n = px.shape[0] if arrs is None else len(arrs)
+        out = torch.empty(n, self.d_embed, dtype=torch.float32, device=self.device)
+        self._run(px, arrs, out, 0, normalize)
         return out.view(b, -1, self.d_embed)
 
 

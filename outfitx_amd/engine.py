@@ -274,10 +274,8 @@ class Engine:
             L.check(self.lib.ofx_vit_b32_fwd(self.h, _ptr(px), N, _ptr(out), out.stride(0), col, int(normalize),
                                              _ptr(ws), ws.numel(), _stream(self.device)), "ofx_vit_b32_fwd")
 
-    def clip_preprocess(self, images: Sequence, size: int, mean: Sequence[float], std: Sequence[float]) -> torch.Tensor:
-        """uint8 images ([H,W,3] or [H,W] numpy arrays, any sizes) -> normalised pixel_values [N,3,size,size] fp32 on the
-        device: the packed bytes travel once (0.27 MB per 300x300 image instead of 0.6 MB of fp32 pixels) and the resize /
-        crop / normalise run on the GPU, bit-identical to PIL + CLIPImageProcessor (ofx_clip_preprocess)."""
+    def _stage_images(self, images: Sequence):
+        """uint8 images -> (device byte buffer, host offsets / heights / widths): one pinned staging copy, one H2D."""
         import numpy as np
         arrs = []
         for a in images:
@@ -299,7 +297,16 @@ class Engine:
         buf = stage.numpy()
         for a, o, n in zip(arrs, offs, nbytes):
             buf[o:o + n] = a.reshape(-1)
-        src = stage[:total].to(self.device, non_blocking=True)
+        src = stage[:total + 4].to(self.device, non_blocking=True)    # + 4: RGB pixels are fetched as unaligned dwords
+        self._keep_px = src
+        return src, offs, hs, ws_
+
+    def clip_preprocess(self, images: Sequence, size: int, mean: Sequence[float], std: Sequence[float]) -> torch.Tensor:
+        """uint8 images ([H,W,3] or [H,W] numpy arrays, any sizes) -> normalised pixel_values [N,3,size,size] fp32 on the
+        device: the packed bytes travel once (0.27 MB per 300x300 image instead of 0.6 MB of fp32 pixels) and the resize /
+        crop / normalise run on the GPU, bit-identical to PIL + CLIPImageProcessor (ofx_clip_preprocess)."""
+        src, offs, hs, ws_ = self._stage_images(images)
+        N = len(hs)
         out = torch.empty(N, 3, size, size, dtype=torch.float32, device=self.device)
         I = C.POINTER(C.c_int); LL = C.POINTER(C.c_longlong)
         nb = int(self.lib.ofx_clip_preprocess_ws(hs.ctypes.data_as(I), ws_.ctypes.data_as(I), N, 3, size))
@@ -308,8 +315,23 @@ class Engine:
         with torch.cuda.device(self.device):
             L.check(self.lib.ofx_clip_preprocess(_ptr(src), offs.ctypes.data_as(LL), hs.ctypes.data_as(I), ws_.ctypes.data_as(I), N, 3, size,
                                                  m, sd, _ptr(out), _ptr(ws), ws.numel(), _stream(self.device)), "ofx_clip_preprocess")
-        self._keep_px = src
         return out
+
+    def vit_u8(self, images: Sequence, mean: Sequence[float], std: Sequence[float], out: torch.Tensor, col: int, normalize: bool) -> None:
+        """uint8 images -> out[:, col:col+512]: the GPU preprocessor feeds the patch-embedding GEMM directly
+        (ofx_vit_b32_fwd_u8); same result as clip_preprocess + vit without the fp32 pixel tensor in between."""
+        src, offs, hs, ws_ = self._stage_images(images)
+        N = len(hs)
+        I = C.POINTER(C.c_int); LL = C.POINTER(C.c_longlong)
+        nb = int(self.lib.ofx_vit_b32_u8_ws_bytes(self.h, hs.ctypes.data_as(I), ws_.ctypes.data_as(I), N, 3))
+        if nb == 0:
+            raise ValueError("ofx_vit_b32_u8_ws_bytes: bad image geometry")
+        ws = self.workspace(nb)
+        m = (C.c_float * 3)(*mean); sd = (C.c_float * 3)(*std)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ofx_vit_b32_fwd_u8(self.h, _ptr(src), offs.ctypes.data_as(LL), hs.ctypes.data_as(I), ws_.ctypes.data_as(I), N, 3,
+                                                m, sd, _ptr(out), out.stride(0), col, int(normalize), _ptr(ws), ws.numel(),
+                                                _stream(self.device)), "ofx_vit_b32_fwd_u8")
 
     def stage_tokens(self, ids: torch.Tensor, att: Optional[torch.Tensor]):
         """Token ids / mask -> device int64 (non-blocking from pinned memory).  Call this BEFORE enqueuing a long

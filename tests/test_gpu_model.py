@@ -360,17 +360,55 @@ def test_gpu_image_preprocessing_is_bit_identical_to_pil_pipeline(model):
 
 def test_item_encoder_takes_pil_images_through_the_gpu_preprocessor(model):
     """PIL / uint8 inputs (what the reference's PE script feeds, precompute_embedding_script.py:44) -> same embeddings as
-    host-preprocessed pixel tensors fed to the tower directly."""
+    host-preprocessed pixel tensors fed to the tower directly.  Default route = ofx_vit_b32_fwd_u8 (the preprocessor writes
+    the patch-embedding operand itself); the two-call route (pixel tensor in between) must agree bit for bit as well."""
     from PIL import Image
     from outfitx_amd.encoders import clip_preprocess
     g = np.random.default_rng(6)
-    ims = [[Image.fromarray(g.integers(0, 256, (h, w, 3), dtype=np.uint8))] for h, w in ((300, 300), (280, 350), (500, 400))]
+    shapes = [(300, 300, 3), (280, 350, 3), (500, 400, 3), (90, 130), (37, 53, 3), (224, 224, 3), (640, 480, 3)]
+    ims = [[Image.fromarray(g.integers(0, 256, s, dtype=np.uint8))] for s in shapes]
     enc = model.item_encoder.image_enc
+    assert enc.fused_preprocess
     with torch.no_grad():
         a = enc(ims)
-        px = clip_preprocess([r[0] for r in ims]).view(3, 1, 3, 224, 224).cuda()
+        px = clip_preprocess([r[0] for r in ims]).view(len(ims), 1, 3, 224, 224).cuda()
         b = enc(px)
+        enc.fused_preprocess = False
+        try:
+            c = enc(ims)
+        finally:
+            enc.fused_preprocess = True
+    assert torch.equal(a, b) and torch.equal(c, b)
+
+
+def test_fused_preprocess_spans_vit_chunks(model):
+    """More images than one ViT workspace chunk: the fused route preprocesses chunk by chunk (offset sub-arrays) and
+    matches the pixel route on every image; a short workspace is refused."""
+    import ctypes as C
+    from outfitx_amd import _lib as L
+    from outfitx_amd.encoders import CLIP_MEAN, CLIP_STD
+    g = np.random.default_rng(8)
+    n = 70
+    ims = [g.integers(0, 256, (64 + 3 * (i % 11), 80 + 5 * (i % 7), 3), dtype=np.uint8) for i in range(n)]
+    eng = model.item_encoder.image_enc._engine("vision")
+    a = torch.zeros(n, 512, device="cuda"); b = torch.zeros(n, 512, device="cuda")
+    src, offs, hs, ws_ = eng._stage_images(ims)
+    I = C.POINTER(C.c_int); LL = C.POINTER(C.c_longlong)
+    full = int(eng.lib.ofx_vit_b32_u8_ws_bytes(eng.h, hs.ctypes.data_as(I), ws_.ctypes.data_as(I), n, 3))
+    pre = int(eng.lib.ofx_clip_preprocess_ws(hs.ctypes.data_as(I), ws_.ctypes.data_as(I), n, 3, 224))
+    one = eng.ws_bytes(L.OP_VIT, 16, 0)                     # room for 16 images at a time -> 5 chunks
+    ws = torch.empty(pre + 256 + one, dtype=torch.uint8, device="cuda")
+    assert ws.numel() < full
+    m = (C.c_float * 3)(*CLIP_MEAN); sd = (C.c_float * 3)(*CLIP_STD)
+    rc = eng.lib.ofx_vit_b32_fwd_u8(eng.h, src.data_ptr(), offs.ctypes.data_as(LL), hs.ctypes.data_as(I), ws_.ctypes.data_as(I), n, 3, m, sd,
+                                    a.data_ptr(), 512, 0, 1, ws.data_ptr(), ws.numel(), None)
+    assert rc == 0, eng.lib.ofx_last_error()
+    eng.vit(eng.clip_preprocess(ims, 224, CLIP_MEAN, CLIP_STD), b, 0, True)
+    torch.cuda.synchronize()
     assert torch.equal(a, b)
+    rc = eng.lib.ofx_vit_b32_fwd_u8(eng.h, src.data_ptr(), offs.ctypes.data_as(LL), hs.ctypes.data_as(I), ws_.ctypes.data_as(I), n, 3, m, sd,
+                                    a.data_ptr(), 512, 0, 1, ws.data_ptr(), pre // 2, None)
+    assert rc == -4          # OFX_EWORKSPACE
 
 
 def test_layernorm_folding_matches_the_materialised_path(model):

@@ -28,6 +28,22 @@ out = eng.clip_preprocess(ims, 224, CLIP_MEAN, CLIP_STD); torch.cuda.synchronize
 t0 = time.perf_counter()
 for _ in range(3): out = eng.clip_preprocess(ims, 224, CLIP_MEAN, CLIP_STD)
 torch.cuda.synchronize(); res["ms_gpu_path_total"] = (time.perf_counter() - t0) / 3 * 1e3
+# the embedding pass: pixel route (preprocess -> fp32 pixels -> patchify -> tower) vs fused (preprocess writes the GEMM operand)
+if os.environ.get("OFX_BENCH_TOWER", "1") == "1":
+    import ctypes as C
+    from outfitx_amd.encoders import CLIPImageEncoder
+    enc = CLIPImageEncoder().cuda(); emb = torch.empty(a.n, 512, device="cuda")
+    e2 = enc._engine("vision")
+    def timed(fn, reps=3):
+        fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps): fn()
+        torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e3
+    res["ms_embed_two_calls"] = timed(lambda: e2.vit(e2.clip_preprocess(ims, 224, CLIP_MEAN, CLIP_STD), emb, 0, True))
+    ref = emb.clone()
+    res["ms_embed_fused_u8"] = timed(lambda: e2.vit_u8(ims, CLIP_MEAN, CLIP_STD, emb, 0, True))
+    res["fused_identical"] = bool(torch.equal(ref, emb))
+    px = e2.clip_preprocess(ims, 224, CLIP_MEAN, CLIP_STD)
+    res["ms_tower_from_pixels"] = timed(lambda: e2.vit(px, emb, 0, True))
 res["h2d_bytes_uint8"] = int(sum(i.nbytes for i in ims)); res["h2d_bytes_fp32"] = a.n * 3 * 224 * 224 * 4
 res["identical_to_host"] = bool(np.array_equal(out[:256].cpu().numpy(), host.numpy()))
 print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in res.items()}))
