@@ -61,8 +61,8 @@ def cpu_baseline(px, ids, att, mask, n_outfits, items):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--outfits", type=int, default=256, help="outfits per GPU per step")
     ap.add_argument("--items", type=int, default=8)
     ap.add_argument("--precision", default="bf16x3", help="outfit transformer MFMA operand format")

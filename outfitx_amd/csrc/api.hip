@@ -43,6 +43,19 @@ void ofx_prof_begin(int cat, hipStream_t s, double flops) {
 void ofx_prof_end(hipStream_t s) {
     if (!g_prof_over && g_prof_used < g_prof.size()) { (void)hipEventRecord(g_prof[g_prof_used].b, s); ++g_prof_used; }
 }
+hipEvent_t g_ofx_launch_e0 = nullptr, g_ofx_launch_e1 = nullptr;
+bool ofx_prof_ext_begin(int cat, double flops) {
+    if (g_prof_used == g_prof.size()) return false;
+    ProfRec& r = g_prof[g_prof_used];
+    r.cat = cat; r.flops = flops;
+    g_ofx_launch_e0 = r.a; g_ofx_launch_e1 = r.b;
+    return true;
+}
+void ofx_prof_ext_end() {
+    // a scope that returned before its last launch (error path) leaves its stop event unrecorded: drop the record
+    if (g_ofx_launch_e1 == nullptr && g_ofx_launch_e0 == nullptr) ++g_prof_used;
+    g_ofx_launch_e0 = g_ofx_launch_e1 = nullptr;
+}
 // on: 0 off; otherwise a bit mask of categories to time (1 GEMM, 2 norm/embed, 4 attention, 8 other; 15 = all)
 extern "C" void ofx_profile_enable(int on) {
     // create the event pool up front (never inside a timed region): room for 4096 bracketed launches
@@ -561,12 +574,14 @@ extern "C" int ofx_cir_prefix(ofx_handle* h, const float* txt, int B, float* out
 // ------------------------------------------------------------------------------------ CLIP towers
 // One CLIP encoder layer on `rows` rows.  When `pool_idx` is given (last layer) everything after the attention
 // runs only on the n pooled rows (CLS / EOS): they are the only ones the tower's output depends on.
+int g_prune_q = 1;      // ofx_tune(8, v): 1 = the ViT's last layer computes queries for the CLS rows only
 int g_ln_fold = 1;      // ofx_tune(6, v): 0 = materialise every LayerNorm, 1 = fold the towers' LayerNorms into the GEMM epilogues
 
 // fold == true: on entry w.XB / w.S hold the operand copy and the (mean, rstd) of X; on exit (non-pooled layers) they hold
 // those of the layer's output, produced by the fc2 epilogue.  No LayerNorm kernel runs on the full rows.
 static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, int S, int W, int MLP, int heads, int act,
-                      float eps, int causal, const int64_t* key_mask, int mask_ld, int dt, const int* pool_idx, hipStream_t s, bool fold = false) {
+                      float eps, int causal, const int64_t* key_mask, int mask_ld, int dt, const int* pool_idx, hipStream_t s, bool fold = false,
+                      bool pool_first = false) {
     GemmArgs g1{}; g1.C = w.QKV; g1.M = rows; g1.N = 3 * W; g1.K = W; g1.lda = W;
     g1.ldc = 3 * W; g1.act = OFX_ACT_NONE; g1.out_kind = OFX_OUT_OP;
     if (fold) {
@@ -576,7 +591,19 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
         TRY(ofx_launch_layernorm(ln, dt, s));
         g1.A = w.H; g1.W = L.w_qkv; g1.bias = L.b_qkv;
     }
-    TRY(ofx_launch_gemm(g1, dt, s));
+    if (pool_idx && pool_first && g_prune_q) {
+        // last layer, pooled row = first row of every sequence (ViT CLS): only those rows' queries are ever used.  K | V for all
+        // rows (weight rows W .. 3W), then Q for the nseq pooled rows through strided A / C / statistics.  The other rows' Q
+        // columns keep stale workspace bytes; their attention outputs are never read (the tail gathers the pooled rows only).
+        GemmArgs kv = g1;
+        kv.W = (const char*)g1.W + (size_t)W * W * 2; kv.bias = g1.bias + W; kv.C = (char*)w.QKV + (size_t)W * 2; kv.N = 2 * W;
+        if (fold) kv.col_sum = g1.col_sum + W;
+        TRY(ofx_launch_gemm(kv, dt, s));
+        GemmArgs q = g1;
+        q.M = nseq; q.N = W; q.lda = S * W; q.ldc = S * 3 * W; q.stat_ld = S;
+        TRY(ofx_launch_gemm(q, dt, s));
+    } else
+        TRY(ofx_launch_gemm(g1, dt, s));
     AttnArgs at{w.QKV, w.H, key_mask, nseq, S, heads, 3 * W, W, W, 2 * W, mask_ld, causal, 0.125f};
     TRY(ofx_launch_attention_mfma(at, dt, s));
     float* X = w.X; char* H = w.H; char* U = w.U; int M = rows;
@@ -616,12 +643,12 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
 static bool clip_fold(int W) { return g_ln_fold != 0 && W % 64 == 0; }
 static int clip_layers(const std::vector<ClipLayer>& Ls, const ClipWs& w, int rows, int nseq, int S, int W, int MLP,
                        int heads, int act, float eps, int causal, const int64_t* key_mask, int mask_ld, int dt,
-                       const int* pool_idx, hipStream_t s, bool stats_ready = false) {
+                       const int* pool_idx, hipStream_t s, bool stats_ready = false, bool pool_first = false) {
     const bool fold = clip_fold(W);
     if (fold && !stats_ready) TRY(ofx_launch_row_stats_cast(w.X, w.XB, w.S, rows, W, eps, dt, s));     // layer 0's LayerNorm-1 inputs
     for (size_t l = 0; l < Ls.size(); ++l)
         TRY(clip_layer(Ls[l], w, rows, nseq, S, W, MLP, heads, act, eps, causal, key_mask, mask_ld, dt,
-                       l + 1 == Ls.size() ? pool_idx : nullptr, s, fold));
+                       l + 1 == Ls.size() ? pool_idx : nullptr, s, fold, pool_first));
     return OFX_OK;
 }
 
@@ -661,7 +688,7 @@ static int vit_core(ofx_handle* h, const float* pixels, const RawImages* raw, in
         TRY(ofx_launch_vit_embed_ln((const float*)w.QKV, h->v_cls, h->v_pos, h->v_pre_g, h->v_pre_b, w.X, n, S, W, d.ln_eps, s, fold ? w.XB : nullptr,
                                     fold ? w.S : nullptr, dt));
         TRY(ofx_launch_iota_rows(w.idx, n, S, s));                        // CLS rows
-        TRY(clip_layers(h->vl, w, rows, n, S, W, d.vit_mlp, d.vit_heads, d.vit_act, d.ln_eps, 0, nullptr, 0, dt, w.idx, s, fold));
+        TRY(clip_layers(h->vl, w, rows, n, S, W, d.vit_mlp, d.vit_heads, d.vit_act, d.ln_eps, 0, nullptr, 0, dt, w.idx, s, fold, true));
         LnArgs ln{w.XP, nullptr, h->v_post_g, h->v_post_b, w.PL, n, W, W, OFX_OUT_OP, d.ln_eps};
         TRY(ofx_launch_layernorm(ln, dt, s));
         GemmArgs gj{}; gj.A = w.PL; gj.W = h->v_proj_w; gj.C = w.E; gj.M = n; gj.N = d.proj_dim; gj.K = W; gj.lda = W; gj.ldc = d.proj_dim;
@@ -1098,6 +1125,7 @@ extern "C" int ofx_tune(int knob, int value) {
         case 5: g_gemm_splitk = value; return OFX_OK;
         case 6: g_ln_fold = value; return OFX_OK;
         case 7: g_train_mfma_attn = value; return OFX_OK;
+        case 8: g_prune_q = value; return OFX_OK;
         default: ofx_set_error("ofx_tune: unknown knob %d", knob); return OFX_EINVAL;
     }
 }

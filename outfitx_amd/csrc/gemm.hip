@@ -215,15 +215,15 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
     KArgs k;
     k.A = (const char*)g.A; k.W = (const char*)g.W; k.C = (char*)g.C; k.bias = g.bias; k.resid = g.resid; k.aux_out = g.aux_out; k.m_dev = g.m_dev; k.dbg = g_gemm_dbg; k.skew = g_gemm_skew; k.splits = 1; k.slab = nullptr; k.m_slab = g.M; k.kt_per_split = 0;
     k.M = g.M; k.N = g.N; k.K = g.K; k.lda = g.lda; k.ldc = g.ldc; k.ldr = g.ldr; k.act = g.act; k.out_kind = g.out_kind; k.drop = g.drop; k.n_valid = g.N;
-    k.xb_out = (char*)g.xb_out; k.stat_part = g.stat_part; k.row_stat = g.row_stat; k.col_sum = g.col_sum;
+    k.xb_out = (char*)g.xb_out; k.stat_part = g.stat_part; k.row_stat = g.row_stat; k.col_sum = g.col_sum; k.stat_ld = g.stat_ld > 0 ? g.stat_ld : 1;
     OFX_REQUIRE(!(g.xb_out || g.stat_part) || (g.out_kind == 0 && g.N % 64 == 0), OFX_EINVAL, "gemm: LayerNorm-fold producer outputs need an fp32 output");
     OFX_REQUIRE(!g.row_stat || g.col_sum, OFX_EINVAL, "gemm: row_stat needs col_sum");
     OFX_REQUIRE(!(g.row_stat || g.xb_out || g.stat_part) || (!g.aux_out && !g.drop.thresh && g.act != OFX_ACT_MISH && g.act != OFX_ACT_MISH_GRAD), OFX_EINVAL,
                 "gemm: LayerNorm folding does not combine with the training epilogue features");
     OFX_REQUIRE(!g.row_stat || !g.resid, OFX_EINVAL, "gemm: a LayerNorm-fold consumer takes no residual");
     OFX_REQUIRE(!(g.xb_out || g.stat_part) || g.act == OFX_ACT_NONE, OFX_EINVAL, "gemm: a LayerNorm-fold producer has no activation");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    TRY(attr_set.run([]() -> int {
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<bf16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<f16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<bf16_t, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM64_LDS_BYTES));
@@ -233,8 +233,8 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<bf16_t, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
 #endif
-        attr_set = true;
-    }
+        return OFX_OK;
+    }));
     // big tiles when they still fill the chip, else the 128^2 kernel
     int kind = g_gemm_kernel;
     if (kind == 0) {   // measured crossover points (tools/gemm_bench.py, profiles/r01_gemm_variants.txt)
@@ -245,7 +245,7 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
     }
     if ((kind == 2 || kind == 4) && g.N % 256) kind = 1;
     if (kind == 5 && g.N % 128) kind = 1;
-    ProfScope prof(PROF_GEMM, s, 2.0 * g.M * g.N * g.K);
+    ProfScope prof(PROF_GEMM, s, 2.0 * g.M * g.N * g.K, true);      // events ride on the launches (OFX_PLAUNCH)
     if (kind == 2 || kind == 3 || kind == 4) {
         k.group_m = g_gemm_group_m > 0 ? g_gemm_group_m : (kind == 3 ? 4 : 8);
         int rc;
@@ -278,24 +278,25 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
             k.splits = 1; k.kt_per_split = 0;
             k.tiles_m = (g.M + 63) / 64; k.nwg = k.tiles_m * k.tiles_n; k.group_m = 2 * gm;
             const dim3 grid64(k.nwg, 1);
-            if (op_dtype == OFX_F16) hipLaunchKernelGGL((gemm_128x128_kernel<f16_t, 0, 2>), grid64, dim3(256), GEMM64_LDS_BYTES, s, k);
-            else hipLaunchKernelGGL((gemm_128x128_kernel<bf16_t, 0, 2>), grid64, dim3(256), GEMM64_LDS_BYTES, s, k);
+            if (op_dtype == OFX_F16) OFX_PLAUNCH(true, (gemm_128x128_kernel<f16_t, 0, 2>), grid64, dim3(256), GEMM64_LDS_BYTES, s, k);
+            else OFX_PLAUNCH(true, (gemm_128x128_kernel<bf16_t, 0, 2>), grid64, dim3(256), GEMM64_LDS_BYTES, s, k);
             OFX_LAUNCH_CHECK();
             return OFX_OK;
         }
         const dim3 grid(k.nwg, splits > 1 ? splits : 1);
-        if (op_dtype == OFX_F16) hipLaunchKernelGGL((gemm_128x128_kernel<f16_t, 0>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
+        const bool one = splits <= 1;
+        if (op_dtype == OFX_F16) OFX_PLAUNCH(one, (gemm_128x128_kernel<f16_t, 0>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
 #ifdef OFX_DIAG
-        else if (g_gemm_ablate == 1) hipLaunchKernelGGL((gemm_128x128_kernel<bf16_t, 1>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
-        else if (g_gemm_ablate == 2) hipLaunchKernelGGL((gemm_128x128_kernel<bf16_t, 2>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
-        else if (g_gemm_ablate == 3) hipLaunchKernelGGL((gemm_128x128_kernel<bf16_t, 3>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
+        else if (g_gemm_ablate == 1) OFX_PLAUNCH(one, (gemm_128x128_kernel<bf16_t, 1>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
+        else if (g_gemm_ablate == 2) OFX_PLAUNCH(one, (gemm_128x128_kernel<bf16_t, 2>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
+        else if (g_gemm_ablate == 3) OFX_PLAUNCH(one, (gemm_128x128_kernel<bf16_t, 3>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
 #endif
-        else hipLaunchKernelGGL((gemm_128x128_kernel<bf16_t, 0>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
+        else OFX_PLAUNCH(one, (gemm_128x128_kernel<bf16_t, 0>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
         if (splits > 1) {
             size_t tot = (size_t)g.M * (g.N / 4);
             int rg = (int)((tot + 255) / 256); if (rg > 2048) rg = 2048;
-            if (op_dtype == OFX_F16) hipLaunchKernelGGL(splitk_reduce_kernel<f16_t>, dim3(rg), dim3(256), 0, s, k);
-            else hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(rg), dim3(256), 0, s, k);
+            if (op_dtype == OFX_F16) OFX_PLAUNCH(true, splitk_reduce_kernel<f16_t>, dim3(rg), dim3(256), 0, s, k);
+            else OFX_PLAUNCH(true, splitk_reduce_kernel<bf16_t>, dim3(rg), dim3(256), 0, s, k);
         }
     }
     OFX_LAUNCH_CHECK();

@@ -157,13 +157,13 @@ template <typename T, int WR, int WC, int NST, int ABL = 0>
 static int launch_big(KArgs& k, int M, int N, hipStream_t s) {
     constexpr int TM = WR * 128, TN = WC * 64, NW = WR * WC;
     constexpr int LDSB = NST * (TM + TN) * BK * 2 + NW * EPI2_BYTES_PER_WAVE;
-    static bool attr = false;
-    if (!attr) {
+    static DeviceOnce attr;
+    TRY(attr.run([]() -> int {
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_big_kernel<T, WR, WC, NST, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
-        attr = true;
-    }
+        return OFX_OK;
+    }));
     k.tiles_n = N / TN; k.tiles_m = (M + TM - 1) / TM; k.nwg = k.tiles_m * k.tiles_n;
-    hipLaunchKernelGGL((gemm_big_kernel<T, WR, WC, NST, ABL>), dim3(k.nwg), dim3(64 * NW), LDSB, s, k);
+    OFX_PLAUNCH(true, (gemm_big_kernel<T, WR, WC, NST, ABL>), dim3(k.nwg), dim3(64 * NW), LDSB, s, k);
     return OFX_OK;
 }
 

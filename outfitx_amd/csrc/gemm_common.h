@@ -30,7 +30,7 @@ struct KArgs {
     int splits, kt_per_split;   // 128x128 kernel only: blockIdx.y owns k-tiles [y*kt_per_split, ...) and writes a raw fp32 slab
     float* slab;                // [splits, M, N] partial sums when splits > 1
     DropArgs drop;
-    char* xb_out; float* stat_part; const float* row_stat; const float* col_sum;   // LayerNorm folding (GemmArgs)
+    char* xb_out; float* stat_part; const float* row_stat; const float* col_sum; int stat_ld;   // LayerNorm folding (GemmArgs)
     int n_valid;                // columns >= n_valid are computed but not stored (fp32 outputs of the TN kernel; = N elsewhere)
 };
 
@@ -54,7 +54,7 @@ __device__ __forceinline__ void epilogue(const KArgs& p, OFX_LDS float* ep, int 
         f32x4 v = *(OFX_LDS f32x4*)(ep + row * EPI_STRIDE + col);
         if (gm < p.M) {
             if (p.row_stat) {
-                const float mu = p.row_stat[2 * (size_t)gm], rs = p.row_stat[2 * (size_t)gm + 1];
+                const float mu = p.row_stat[2 * (size_t)gm * p.stat_ld], rs = p.row_stat[2 * (size_t)gm * p.stat_ld + 1];
                 v = (v - *(const f32x4*)(p.col_sum + gn) * mu) * rs + bias4;
             } else v += bias4;
             if (p.aux_out) *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn) = v;
@@ -163,7 +163,7 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
                 f32x4 v = *(OFX_LDS f32x4*)(ep + row * 256 + ((chunk ^ (row & 7)) << 4));
                 if (gm < p.M && gn < p.n_valid) {
                     if (FOLD == 2) {
-                        const float mu = p.row_stat[2 * (size_t)gm], rs = p.row_stat[2 * (size_t)gm + 1];
+                        const float mu = p.row_stat[2 * (size_t)gm * p.stat_ld], rs = p.row_stat[2 * (size_t)gm * p.stat_ld + 1];
                         v = (v - *(const f32x4*)(p.col_sum + gn) * mu) * rs + bias4;
                     } else v += bias4;
                     if (FOLD == 0 && p.aux_out) *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn) = v;
@@ -211,7 +211,7 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
                 f32x4 v1 = *(OFX_LDS f32x4*)(ep + row * 256 + (((2 * c8 + 1) ^ (row & 7)) << 4));
                 if (gm < p.M) {
                     if (FOLD == 2) {
-                        const float mu = p.row_stat[2 * (size_t)gm], rs = p.row_stat[2 * (size_t)gm + 1];
+                        const float mu = p.row_stat[2 * (size_t)gm * p.stat_ld], rs = p.row_stat[2 * (size_t)gm * p.stat_ld + 1];
                         v0 = (v0 - cs0 * mu) * rs + b0; v1 = (v1 - cs1 * mu) * rs + b1;
                     } else { v0 += b0; v1 += b1; }
                     if (FOLD == 0 && p.aux_out) { *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn) = v0; *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn + 4) = v1; }

@@ -150,13 +150,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(KArgs p) {
 template <typename T>
 static int launch_pp(KArgs& k, int M, int N, hipStream_t s) {
     constexpr int LDSB = 2 * (256 + 256) * BK * 2 + 8 * EPI2_BYTES_PER_WAVE;
-    static bool attr = false;
-    if (!attr) {
+    static DeviceOnce attr;
+    TRY(attr.run([]() -> int {
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
-        attr = true;
-    }
+        return OFX_OK;
+    }));
     k.tiles_n = N / 256; k.tiles_m = (M + 255) / 256; k.nwg = k.tiles_m * k.tiles_n;
-    hipLaunchKernelGGL(gemm_pp_kernel<T>, dim3(k.nwg), dim3(512), LDSB, s, k);
+    OFX_PLAUNCH(true, gemm_pp_kernel<T>, dim3(k.nwg), dim3(512), LDSB, s, k);
     return OFX_OK;
 }
 

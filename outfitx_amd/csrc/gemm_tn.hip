@@ -207,12 +207,12 @@ int ofx_launch_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C,
     if (t.splits > 1) OFX_REQUIRE(slab_bytes >= (size_t)t.splits * M * N * 4, OFX_EWORKSPACE, "gemm_tn: split-K slab too small");
     t.tiles_m = M / 256; t.tiles_n = N / 256; t.nwg = t.tiles_m * t.tiles_n * t.splits; t.group_m = 4;
     constexpr int LDSB = 2 * 4 * 64 * 256 + 8 * EPI2_BYTES_PER_WAVE;
-    static bool attr = false;
-    if (!attr) {
+    static DeviceOnce attr;
+    TRY(attr.run([]() -> int {
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_tn_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
-        attr = true;
-    }
+        return OFX_OK;
+    }));
     ProfScope prof(PROF_GEMM, s, 2.0 * M * N * K);
     if (op_dtype == OFX_F16) hipLaunchKernelGGL(gemm_tn_kernel<f16_t>, dim3(t.nwg), dim3(512), LDSB, s, t);
     else hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, dim3(t.nwg), dim3(512), LDSB, s, t);

@@ -1,6 +1,8 @@
 // Internal helpers shared by the HIP translation units of libofx_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <mutex>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -120,15 +122,53 @@ extern bool g_ofx_prof_on;
 extern int g_ofx_prof_mask;   // bit per category
 void ofx_prof_begin(int cat, hipStream_t s, double flops);
 void ofx_prof_end(hipStream_t s);
+// ext = true: nothing is recorded on the stream; the scope's launches carry the two events themselves (OFX_PLAUNCH ->
+// hipExtLaunchKernelGGL start / stop events: the timestamps come from the dispatch packet's completion signal, so no marker
+// packets are put between the kernels).  The first launch of the scope takes the start event, the one flagged `last` the stop.
+bool ofx_prof_ext_begin(int cat, double flops);
+void ofx_prof_ext_end();
+extern hipEvent_t g_ofx_launch_e0, g_ofx_launch_e1;
 struct ProfScope {
-    hipStream_t s; bool on;
-    ProfScope(int cat, hipStream_t st, double flops = 0.0) : s(st), on(g_ofx_prof_on && ((g_ofx_prof_mask >> cat) & 1)) { if (on) ofx_prof_begin(cat, s, flops); }
-    ~ProfScope() { if (on) ofx_prof_end(s); }
+    hipStream_t s; bool on, ext;
+    ProfScope(int cat, hipStream_t st, double flops = 0.0, bool ext_ = false) : s(st), on(g_ofx_prof_on && ((g_ofx_prof_mask >> cat) & 1)), ext(ext_) {
+        if (on && ext) on = ofx_prof_ext_begin(cat, flops);
+        else if (on) ofx_prof_begin(cat, s, flops);
+    }
+    ~ProfScope() {
+        if (on && ext) ofx_prof_ext_end();
+        else if (on) ofx_prof_end(s);
+    }
 };
+#define OFX_PLAUNCH(last, kernel, grid, block, lds, stream, ...)                                                                  \
+    do {                                                                                                                          \
+        hipEvent_t pe0_ = g_ofx_launch_e0, pe1_ = (last) ? g_ofx_launch_e1 : nullptr;                                             \
+        g_ofx_launch_e0 = nullptr;                                                                                                \
+        if (last) g_ofx_launch_e1 = nullptr;                                                                                      \
+        if (pe0_ || pe1_) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, pe0_, pe1_, 0, __VA_ARGS__);                      \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                                   \
+    } while (0)
 
 // ---- internal launchers (defined in the .hip files, used by api.hip) ----
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int pad128(int v) { return (v + 127) / 128 * 128; }
+
+// hipFuncSetAttribute applies to the CURRENT device: raise a kernel's dynamic-LDS limit once per device (a process may hold
+// handles on several devices, and several host threads may launch concurrently).
+struct DeviceOnce {
+    std::mutex mu;
+    unsigned long long done = 0;
+    template <typename F>
+    int run(F&& f) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        const unsigned long long bit = 1ull << (dev & 63);
+        std::lock_guard<std::mutex> lk(mu);
+        if (done & bit) return OFX_OK;
+        const int rc = f();
+        if (rc == OFX_OK) done |= bit;
+        return rc;
+    }
+};
 
 struct Bump {                                       // carve a caller-provided workspace
     char* base; size_t cap, off = 0; bool ok = true;
@@ -186,6 +226,7 @@ struct GemmArgs {
     void* xb_out = nullptr;         // [M, N] operand type
     float* stat_part = nullptr;     // [M, N / 64, 2]
     const float* row_stat = nullptr;   // [M, 2] (mean, rstd)
+    int stat_ld = 1;                   // row m's statistics sit at row_stat[2 * m * stat_ld] (strided A rows)
     const float* col_sum = nullptr;    // [N] column sums of the (rounded) gamma-scaled weight rows
 };
 int ofx_launch_gemm(const GemmArgs& g, int op_dtype /*OFX_BF16|OFX_F16*/, hipStream_t s);

@@ -218,8 +218,7 @@ std::map<std::tuple<int, int, int, int>, std::vector<int>> g_plan_cache;
 const std::vector<int>& cached_plan(int in_size, int out_size, int crop0, int n_out) {
     auto key = std::make_tuple(in_size, out_size, crop0, n_out);
     auto it = g_plan_cache.find(key);
-    if (it == g_plan_cache.end()) {
-        if (g_plan_cache.size() > 4096) g_plan_cache.clear();
+    if (it == g_plan_cache.end()) {      // std::map: inserting never moves the plans already handed out
         it = g_plan_cache.emplace(key, plan_axis(in_size, out_size, crop0, n_out)).first;
     }
     return it->second;
@@ -239,6 +238,7 @@ struct Batch {
 };
 int plan_batch(const long long* offsets, const int* hs, const int* ws, int N, int channels, int size, Batch* b) {
     std::lock_guard<std::mutex> lk(g_plan_mu);
+    if (g_plan_cache.size() > 4096) g_plan_cache.clear();      // evict between batches only: the loop below holds pointers into the cache
     std::map<const std::vector<int>*, int> placed;
     b->descs.resize(N);
     for (int i = 0; i < N; ++i) {

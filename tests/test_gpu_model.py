@@ -411,6 +411,29 @@ def test_fused_preprocess_spans_vit_chunks(model):
     assert rc == -4          # OFX_EWORKSPACE
 
 
+def test_vit_last_layer_query_pruning_changes_nothing(model):
+    """The ViT's last layer computes K | V for every token but queries only for the CLS rows (ofx_tune(8, 1), default): the
+    image embeddings must not move versus the full QKV GEMM beyond the operand-rounding floor (the CLS queries come from a
+    different tile kernel, whose fp32 summation order flips a few bf16 roundings), with the LayerNorms folded or materialised,
+    for batches below and above one tile."""
+    from outfitx_amd import _lib as L
+    lib = L.load()
+    enc = model.item_encoder.image_enc
+    for n_img in (3, 200):
+        px = torch.from_numpy(synth.pixel_values(31, n_img)).view(n_img, 1, 3, 224, 224).cuda()
+        for fold in (1, 0):
+            outs = []
+            for prune in (1, 0):
+                lib.ofx_tune(6, fold); lib.ofx_tune(8, prune)
+                try:
+                    with torch.no_grad():
+                        outs.append(enc(px).cpu().numpy())
+                finally:
+                    lib.ofx_tune(6, 1); lib.ofx_tune(8, 1)
+            assert np.isfinite(outs[0]).all()
+            assert rel_err(outs[0], outs[1]) < 2e-3, (n_img, fold, rel_err(outs[0], outs[1]))
+
+
 def test_layernorm_folding_matches_the_materialised_path(model):
     """Towers with their LayerNorms folded into the GEMM epilogues (default) vs every LayerNorm materialised (ofx_tune(6, 0)):
     same embeddings within the operand-rounding floor, on a batch large enough for every tile kernel and on a tiny one."""

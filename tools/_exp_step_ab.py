@@ -1,5 +1,5 @@
 import sys, time, warnings, ctypes as C
-sys.path.insert(0, '/root/repo'); warnings.simplefilter('ignore')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))); warnings.simplefilter('ignore')
 import torch, numpy as np
 from outfitx_amd import synth, _lib as L
 from src.models import OutfitX
@@ -21,10 +21,10 @@ lib = L.load()
 for _ in range(3): step()
 torch.cuda.synchronize()
 for rnd in range(3):
-    for pref, gm in ((0, 0), (1, 0), (1, 4), (2, 0)):
-        lib.ofx_tune(4, pref); lib.ofx_tune(0, gm)
+    for knob, val in [tuple(int(x) for x in a.split("=")) for a in sys.argv[1:]] or [(8, 1), (8, 0)]:
+        lib.ofx_tune(knob, val)
         step(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(6): step()
         torch.cuda.synchronize()
-        print(f"profile pref {pref} group {gm}: {(time.perf_counter()-t0)/6*1e3:7.2f} ms/step", flush=True)
+        print(f"knob {knob} = {val}: {(time.perf_counter()-t0)/6*1e3:7.2f} ms/step", flush=True)
