@@ -29,7 +29,7 @@ struct AttnK {
 constexpr int V_ROW = 160;                 // bytes per V row in LDS (64 x 2 B + 32 pad): tr-read conflict-free
 
 template <typename T, int NT>   // NT = ceil(S / 16) in {1, 2, 4}: number of 16-row query / key tiles
-__global__ __launch_bounds__(256) void attention_mfma_kernel(AttnK a) {
+__global__ __launch_bounds__(256, 3) void attention_mfma_kernel(AttnK a) {      // 3 blocks per CU: <= 168 registers per lane
     typedef typename OpT<T>::v8 v8;
     typedef typename OpT<T>::v4 v4;
     constexpr int KS = (NT + 1) / 2, VROWS = 32 * KS, VT = VROWS * V_ROW;
@@ -71,8 +71,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnK a) {
         }
     }
 
-    // ---- dead-key bits for this lane's 16 keys (key = 16t + 4q4 + r), independent of the query
-    unsigned dead_bits = 0;
+    // ---- additive key mask for this lane's 16 keys (key = 16t + 4q4 + r), independent of the query: 0 or -inf
+    float neg[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnK a) {
             const int key = 16 * t + 4 * q4 + r;
             bool dead = key >= S;
             if (!dead && a.key_mask) dead = a.key_mask[(size_t)seq * a.mask_ld + key] == 0;
-            dead_bits |= (dead ? 1u : 0u) << (t * 4 + r);
+            neg[t][r] = dead ? -INFINITY : 0.f;
         }
 
     // ---- S^T[key][query]: st[t][u][r] = score(query 16u + r16, key 16t + 4q4 + r)
@@ -89,13 +89,23 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnK a) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
-            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            f32x4 c = {neg[t][0], neg[t][1], neg[t][2], neg[t][3]};      // the mask rides in as the accumulator: -inf + finite = -inf
             c = OpT<T>::mfma16(kf[t][0], qf[u][0], c);
             st[t][u] = OpT<T>::mfma16(kf[t][1], qf[u][1], c);
         }
+    if (a.causal) {                  // wave-uniform: the ViT never enters
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (16 * t + 4 * q4 + r > 16 * u + r16) st[t][u][r] = -INFINITY;
+    }
 
-    // ---- wavefront softmax per query column; P written back normalised
-    const float sc = a.scale * 1.4426950408889634f;        // exp(x) = exp2(x * log2 e)
+    // ---- wavefront softmax per query column on the raw scores: p = exp2(s * c - max(s) * c), c = scale * log2 e > 0
+    // (one max, then one fma + v_exp_f32 + add per element); P written back normalised
+    const float sc = a.scale * 1.4426950408889634f;
     v8 pf[NT][KS];
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
@@ -104,28 +114,23 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnK a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = 16 * t + 4 * q4 + r;
-                const bool dead = ((dead_bits >> (t * 4 + r)) & 1u) || (a.causal && key > query);
-                const float s = dead ? -INFINITY : st[t][u][r] * sc;
-                st[t][u][r] = s;
-                m = fmaxf(m, s);
-            }
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, st[t][u][r]);
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
         if (m == -INFINITY) m = 0.f;
+        const float mb = -m * sc;
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = exp2f(st[t][u][r] - m);
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][u][r], sc, mb));      // arguments <= 0: no range fix-up needed
                 st[t][u][r] = e;
                 sum += e;
             }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
+        const float inv = __builtin_amdgcn_rcpf(sum);
         if (a.drop.thresh) {            // dropout on the probabilities (training): same (row, col) counters as the fp32 set kernel
 #pragma unroll
             for (int t = 0; t < NT; ++t)
