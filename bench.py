@@ -185,7 +185,7 @@ def main():
                                   "other": round(bms[3], 3), "note": "one extra untimed step with all launches bracketed"},
             "whole_step_tflops_useful": round(alg_all_outfit * world * B * a.steps / elapsed / 1e12, 2),
         }
-        if a.cpu_outfits > 0:
+        if a.cpu_outfits > 0 and world == 1:      # the CPU baseline is a single-GPU-run datum (rank 0, N = 1 only)
             k = min(a.cpu_outfits, B)
             ref, dt = cpu_baseline(px[:k].cpu().numpy(), texts["input_ids"][:k].numpy(), texts["attention_mask"][:k].numpy(),
                                    mask[:k].cpu().numpy(), k, n)
