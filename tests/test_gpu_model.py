@@ -475,3 +475,28 @@ def test_text_dedup_runs_the_tower_on_distinct_rows_only(model):
     for k in range(7):
         rows = dd[torch.from_numpy(pick == k)]
         assert rows.shape[0] > 1 and torch.equal(rows, rows[:1].expand_as(rows))
+
+
+def test_cp_forward_replays_from_a_captured_hip_graph(model):
+    """Every launch goes to torch's current stream and nothing in the call synchronises or allocates outside torch's
+    allocator, so the precomputed-embedding CP forward can be stream-captured (torch.cuda.graph) and replayed: same logits,
+    and the replay follows new contents of the captured input buffers."""
+    CP = tasks()[0]
+    emb, mask = synth.outfit_batch(4321, 32, 16, 8)
+    x = torch.from_numpy(np.ascontiguousarray(emb)).cuda(); mk = torch.from_numpy(np.ascontiguousarray(mask)).cuda()
+    def fwd():
+        with torch.no_grad():
+            return model(task=CP, outfit_embedding=x, outfit_mask=mk)
+    ref = fwd()
+    s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fwd()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fwd()
+    g.replay(); torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    x.mul_(0.5)
+    g.replay(); torch.cuda.synchronize()
+    assert torch.equal(out, fwd()) and not torch.equal(out, ref)
