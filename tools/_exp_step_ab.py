@@ -20,6 +20,12 @@ def step():
 lib = L.load()
 for _ in range(3): step()
 torch.cuda.synchronize()
+# host time to ISSUE one step (no sync inside the call if this is a few ms) vs the GPU time of the step
+iss = []
+for _ in range(5):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); step(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    iss.append((t1 - t0, t2 - t0))
+print("issue ms / complete ms per step:", " ".join(f"{a*1e3:.2f}/{b*1e3:.2f}" for a, b in iss), flush=True)
 for rnd in range(3):
     for knob, val in [tuple(int(x) for x in a.split("=")) for a in sys.argv[1:]] or [(8, 1), (8, 0)]:
         lib.ofx_tune(knob, val)
