@@ -43,6 +43,64 @@ __global__ __launch_bounds__(64 * NW) void fill(const char* src, unsigned long l
     if (keep[0] == 12345.678f) out[0] = 0;
 }
 
+
+// Ring of NS slots of SLOT KiB each, filled by LDS-DMA; a slot is "consumed" (barrier + one read) once it has landed, while the
+// next NS-1 slots are already in flight: how does the fill rate move with the bytes kept in flight per CU?
+template <int NW, int SLOT_KB, int NS, int ROWB>
+__global__ __launch_bounds__(64 * NW) void fill_ring(const char* src, unsigned long long* out, int iters, size_t span) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    LDS char* lds = (LDS char*)smem;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int SLOT = SLOT_KB * 1024, PIECES = SLOT_KB / NW;       // 1 KiB pieces per wave per slot
+    constexpr int LPR = ROWB / 16;                                     // lanes per row segment (ROWB bytes contiguous, rows 4 KiB apart)
+    const char* base = src + (size_t)(blockIdx.x % 8) * 65536;
+    f32x4 keep = {0, 0, 0, 0};
+    auto issue = [&](int it) {
+        const char* p = base + ((size_t)it * SLOT) % span;
+        LDS char* dst = lds + (it % NS) * SLOT;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int piece = wave * PIECES + i;
+            // ROWB == 1024: fully contiguous; else each wave-instruction gathers 1024 / ROWB row segments
+            const size_t off = ROWB == 1024 ? (size_t)piece * 1024 + lane * 16
+                                            : ((size_t)(piece * (1024 / ROWB) + lane / LPR) * 4096) % 65536 + (piece % 8) * ROWB + (lane % LPR) * 16;
+            __builtin_amdgcn_global_load_lds((const GLB void*)(p + off), (LDS void*)(dst + piece * 1024), 16, 0, 0);
+        }
+    };
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(s);
+    for (int it = 0; it < iters; ++it) {
+        issue(it + NS - 1);
+        // all but the youngest (NS - 1) slots' pieces of this wave have landed
+        if (PIECES * (NS - 1) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (PIECES * (NS - 1) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (PIECES * (NS - 1) == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (PIECES * (NS - 1) == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (PIECES * (NS - 1) == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        keep += *(LDS f32x4*)(lds + (it % NS) * SLOT + ((lane * 16 + it * 64) & (SLOT - 1)));
+        __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+    if (keep[0] == 12345.678f) out[0] = 0;
+}
+template <int NW, int SLOT_KB, int NS, int ROWB> void run_ring(const char* name, const char* src, unsigned long long* out, size_t span) {
+    const int iters = 400, blocks = 256;
+    hipFuncSetAttribute((const void*)fill_ring<NW, SLOT_KB, NS, ROWB>, hipFuncAttributeMaxDynamicSharedMemorySize, SLOT_KB * NS * 1024);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((fill_ring<NW, SLOT_KB, NS, ROWB>), dim3(blocks), dim3(64 * NW), SLOT_KB * NS * 1024, 0, src, out, iters, span);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(blocks);
+    hipMemcpy(h.data(), out, blocks * 8, hipMemcpyDeviceToHost);
+    std::sort(h.begin(), h.end());
+    const double cyc = (double)h[blocks / 2] / iters;
+    printf("%-58s %7.0f cycles per %d KiB slot = %5.1f B/clk/CU\n", name, cyc, SLOT_KB, SLOT_KB * 1024.0 / cyc);
+}
+
 template <int MODE, int NW> void run(const char* name, const char* src, unsigned long long* out, size_t span) {
     const int iters = 200, blocks = 256;
     hipFuncSetAttribute((const void*)fill<MODE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
@@ -64,5 +122,14 @@ int main() {
     run<1, 4>("register staging, 4 waves", src, out, 65536);
     run<0, 8>("LDS-DMA, 8 waves, 8 MiB span", src, out, span);
     run<1, 8>("register staging, 8 waves, 8 MiB span", src, out, span);
+    run_ring<8, 64, 2, 1024>("ring 2 x 64 KiB (1 in flight), contiguous", src, out, 65536);
+    run_ring<8, 32, 4, 1024>("ring 4 x 32 KiB (3 in flight), contiguous", src, out, 65536);
+    run_ring<8, 32, 5, 1024>("ring 5 x 32 KiB (4 in flight), contiguous", src, out, 65536);
+    run_ring<8, 32, 2, 1024>("ring 2 x 32 KiB (1 in flight), contiguous", src, out, 65536);
+    run_ring<8, 32, 3, 1024>("ring 3 x 32 KiB (2 in flight), contiguous", src, out, 65536);
+    run_ring<8, 64, 2, 128>("ring 2 x 64 KiB, 128-B row segments", src, out, 65536);
+    run_ring<8, 32, 4, 64>("ring 4 x 32 KiB, 64-B row segments", src, out, 65536);
+    run_ring<8, 32, 4, 128>("ring 4 x 32 KiB, 128-B row segments", src, out, 65536);
+    run_ring<8, 32, 4, 1024>("ring 4 x 32 KiB, contiguous, 8 MiB span", src, out, span);
     return 0;
 }
