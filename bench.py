@@ -154,6 +154,7 @@ def main():
         T_real = 8
         alg_gemm_outfit = n * (VIT_GEMM + txt_gemm(T_real)) + ot_gemm(n)
         alg_all_outfit = alg_gemm_outfit + n * (VIT_ATTN + txt_attn(T_real)) + ot_attn(n)
+        padded_outfit = n * (VIT_GEMM + VIT_ATTN + txt_gemm(64) + txt_attn(64)) + ot_gemm(16) + ot_attn(16)
         gemm_ms, gemm_launches = ms[0], int(cnt[0])
         achieved = alg_gemm_outfit * B / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0   # one sampled step
         traffic = None        # PMC counters cannot be read inside a timed run: the committed rocprofv3 --pmc pass of this same command
@@ -184,6 +185,12 @@ def main():
             "step_breakdown_ms": {"gemm": round(bms[0], 3), "norm_embed": round(bms[1], 3), "attention": round(bms[2], 3),
                                   "other": round(bms[3], 3), "note": "one extra untimed step with all launches bracketed"},
             "whole_step_tflops_useful": round(alg_all_outfit * world * B * a.steps / elapsed / 1e12, 2),
+            # SURVEY.md 8(d) "report both": the FLOPs the reference's own execution spends on the same outfits (texts padded to
+            # 64 tokens, sets padded to 1 + 16 rows) - context for the north star's "40 % of MFMA peak", never used for `achieved`
+            "reference_padded_flop_count": {
+                "gflop_per_outfit": round(padded_outfit / 1e9, 2),
+                "tflops_equiv_per_gpu": round(padded_outfit * B * a.steps / elapsed / 1e12, 2),
+                "frac_of_peak": round(padded_outfit * B * a.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS, 4)},
         }
         if a.cpu_outfits > 0 and world == 1:      # the CPU baseline is a single-GPU-run datum (rank 0, N = 1 only)
             k = min(a.cpu_outfits, B)
