@@ -174,7 +174,8 @@ def main():
             "data": "synthetic (seeded uniform-uint8 images after CLIP normalise, 8-token ids, random-init weights of the reference architecture)",
             "config": {"workload": "BASELINE configs[1]: CP forward with CLIP ViT-B/32 image+text encode, 256 outfits x 8 items per GPU, 224^2",
                        "outfits_per_gpu": B, "items": n, "parallelism": f"dp{world} (batch sharded, no data-path collective)",
-                       "tower_precision": a.tower_precision, "outfit_precision": a.precision},
+                       "tower_precision": a.tower_precision,
+                       "outfit_precision": (model._tower_fed() or a.precision) + (" (set transformer fed by the in-call towers; bf16x3 for precomputed fp32 embeddings)" if model._tower_fed() else "")},
             "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_big_kernel<2,4,2> / <2,2,1> / gemm_128x128_kernel (every dense contraction of the step)",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,

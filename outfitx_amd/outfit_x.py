@@ -183,6 +183,13 @@ class OutfitX(nn.Module):
         if not t.norm_first:
             raise NotImplementedError("post-norm encoder layers are outside the scoring path (reference uses norm_first)")
         self.precision = precision
+        # Operand format of the set transformer when its input embeddings are produced IN THE SAME CALL by the reduced-precision
+        # towers (encoder_input_dict): those embeddings carry the towers' 2^-9 (bf16) / 2^-12 (f16) operand rounding, so the
+        # three-product bf16x3 scheme (kept for precomputed fp32 embeddings, where it holds 1e-5) buys nothing there; one f16
+        # product (2^-12) is below the bf16 towers' input error and a third of the GEMM work (end-to-end error vs the oracle
+        # unchanged at 5-7e-3, step 25.64 -> 24.98 ms; with f16 towers it would double 4e-4 to 8e-4, so it applies to bf16
+        # towers only).  None = always self.precision.
+        self.tower_fed_precision: Optional[str] = "f16"
         _LIVE_MODELS.add(self)
         self.train_precision = train_precision      # operand format of the training step (the reference trains under bf16 autocast)
         self.item_encoder.set_precision(tower_precision)
@@ -249,9 +256,14 @@ class OutfitX(nn.Module):
         """north-star alias of ItemEncoder.forward: [B,L] items -> [B,L,d_embed]."""
         return self.item_encoder(images, texts)
 
-    def _run_encoder(self, outfit_embedding, outfit_mask, prefix=None):
-        eng = self._engine()
+    def _run_encoder(self, outfit_embedding, outfit_mask, prefix=None, precision: Optional[str] = None):
+        eng = self._engine(precision)
         return eng, eng.set_encoder(outfit_embedding, outfit_mask, prefix)
+
+    def _tower_fed(self) -> Optional[str]:
+        """Precision of the set transformer for embeddings the towers produced in this call (see __init__)."""
+        bf16_towers = getattr(self.item_encoder.image_enc, "tower_precision", None) == "bf16"
+        return self.tower_fed_precision if (self.tower_fed_precision and self.precision == "bf16x3" and bf16_towers) else None
 
     # ------------------------------------------------------------------ indexed (varlen) input, SURVEY.md §8f N3
     def set_embedding_table(self, table: torch.Tensor) -> None:
@@ -277,11 +289,13 @@ class OutfitX(nn.Module):
                 return self._cp_train_forward(spec, None)
             eng = self._engine()
             return eng.cp_head(eng.set_encoder_indexed(*spec))
+        prec = None
         if encoder_input_dict is not None:
             outfit_embedding = self.item_encoder(**encoder_input_dict)
+            prec = self._tower_fed()
         if self.training and torch.is_grad_enabled():
             return self._cp_train_forward(outfit_embedding, outfit_mask)
-        eng, row0 = self._run_encoder(outfit_embedding, outfit_mask)
+        eng, row0 = self._run_encoder(outfit_embedding, outfit_mask, precision=prec)
         return eng.cp_head(row0)
 
     def _cp_train_forward(self, outfit_embedding, outfit_mask):

@@ -500,3 +500,34 @@ def test_cp_forward_replays_from_a_captured_hip_graph(model):
     x.mul_(0.5)
     g.replay(); torch.cuda.synchronize()
     assert torch.equal(out, fwd()) and not torch.equal(out, ref)
+
+
+def test_set_transformer_precision_follows_the_embedding_source(model):
+    """Embeddings computed in the call by the bf16 towers -> the set transformer runs one f16 product (OutfitX.tower_fed_precision);
+    precomputed fp32 embeddings and f16 towers keep bf16x3.  The tower-fed logits stay within the towers' own error of the
+    bf16x3 ones and of the fp32 oracle."""
+    CP = tasks()[0]
+    B, L = 4, 3
+    px = synth.pixel_values(77, B * L).reshape(B, L, 3, 224, 224)
+    ids, att = synth.token_batch(77, B * L, 64, 8)
+    texts = {"input_ids": torch.from_numpy(ids).view(B, L, 64), "attention_mask": torch.from_numpy(att).view(B, L, 64)}
+    mask = np.zeros((B, L), bool)
+    assert model.tower_fed_precision == "f16" and model._tower_fed() == "f16"
+    with torch.no_grad():
+        a = model(task=CP, outfit_embedding=None, outfit_mask=cu(mask), encoder_input_dict={"images": cu(px), "texts": texts}).cpu().numpy()
+        model.tower_fed_precision = None
+        try:
+            assert model._tower_fed() is None
+            b = model(task=CP, outfit_embedding=None, outfit_mask=cu(mask), encoder_input_dict={"images": cu(px), "texts": texts}).cpu().numpy()
+        finally:
+            model.tower_fed_precision = "f16"
+        model.item_encoder.set_precision("f16")
+        try:
+            assert model._tower_fed() is None              # f16 towers: the set transformer's own f16 error would show
+        finally:
+            model.item_encoder.set_precision("bf16")
+    ref = O.cp_forward(O.item_encoder(px, ids.reshape(B, L, 64), att.reshape(B, L, 64), synth.vision_weights(W_SEED), synth.text_weights(W_SEED)),
+                       mask, synth.outfit_transformer_weights(W_SEED))
+    assert not np.array_equal(a, b)
+    assert rel_err(a, b) < 3e-3
+    assert rel_err(a, ref) < 3e-2 and rel_err(b, ref) < 3e-2

@@ -28,7 +28,8 @@ for _ in range(5):
 print("issue ms / complete ms per step:", " ".join(f"{a*1e3:.2f}/{b*1e3:.2f}" for a, b in iss), flush=True)
 for rnd in range(3):
     for knob, val in [tuple(int(x) for x in a.split("=")) for a in sys.argv[1:]] or [(8, 1), (8, 0)]:
-        lib.ofx_tune(knob, val)
+        if knob == 100: model.tower_fed_precision = "f16" if val else None      # set transformer fed by in-call towers: f16 vs bf16x3
+        else: lib.ofx_tune(knob, val)
         step(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(6): step()
