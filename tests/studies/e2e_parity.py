@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """End-to-end CP-logit error of the bench workload against the fp32 numpy oracle, over several independent batches, with the
 towers' LayerNorms folded (default) and materialised, bf16 and f16 towers: is the bench line's single 8-outfit number a draw of
-rounding noise or a systematic cost of folding?   python tools/_exp_e2e_parity.py [batches] [outfits_per_batch]"""
+rounding noise or a systematic cost of folding?   python tests/studies/e2e_parity.py [batches] [outfits_per_batch]"""
 import json, os, sys, time, warnings
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); warnings.simplefilter("ignore")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); warnings.simplefilter("ignore")
 import numpy as np, torch
 from outfitx_amd import synth, _lib as L
 from oracle import np_oracle as O

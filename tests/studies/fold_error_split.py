@@ -2,7 +2,7 @@
 """Tower-level error of the LayerNorm-folded vs materialised path against the fp32 oracle, split into the part common to all
 inputs (norm of the mean error vector) and the per-input rest, bf16 and f16 operands."""
 import json, os, sys, warnings
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); warnings.simplefilter("ignore")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); warnings.simplefilter("ignore")
 import numpy as np, torch
 from outfitx_amd import synth, _lib as L
 from oracle import np_oracle as O
