@@ -154,7 +154,9 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(AttnK a) {      
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 const int key0 = 32 * ks + 16 * h2 + 4 * q4;
-                OFX_LDS s16x4* ap = (OFX_LDS s16x4*)(vl + (key0 + (r16 >> 2)) * V_ROW + (16 * nd + 4 * (r16 & 3)) * 2);
+                // d <-> MFMA row permutation: row m = r16 of tile nd carries d = 16 (m >> 2) + 4 nd + (m & 3), so after the MFMA a
+                // lane's 16 outputs of one query are 16 CONSECUTIVE columns (one 32-byte run per lane, 128 B per lane quad)
+                OFX_LDS s16x4* ap = (OFX_LDS s16x4*)(vl + (key0 + (r16 >> 2)) * V_ROW + (16 * (r16 & 3) + 4 * nd) * 2);
                 const s16x4 tr = __builtin_amdgcn_ds_read_tr16_b64_v4i16(ap);
                 const v4 trv = __builtin_bit_cast(v4, tr);
 #pragma unroll
@@ -169,19 +171,19 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(AttnK a) {      
         }
     }
 
-    // ---- store: ot[nd][u][r] = O[query 16u + r16][d 16nd + 4q4 + r]
+    // ---- store: ot[nd][u][r] = O[query 16u + r16][d = 16 q4 + 4 nd + r]: two 16-byte stores per lane and query
     if (live) {
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
             const int query = 16 * u + r16;
             if (query < (a.only_row0 ? 1 : S)) {
-                T* op = (T*)a.out + (size_t)(row_first + query) * a.ldo + head * 64 + 4 * q4;
+                T* op = (T*)a.out + (size_t)(row_first + query) * a.ldo + head * 64 + 16 * q4;
 #pragma unroll
-                for (int nd = 0; nd < 4; ++nd) {
-                    v4 o;
+                for (int h = 0; h < 2; ++h) {
+                    v8 o;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (T)ot[nd][u][r];
-                    *(v4*)(op + 16 * nd) = o;
+                    for (int e = 0; e < 8; ++e) o[e] = (T)ot[2 * h + (e >> 2)][u][e & 3];
+                    *(v8*)(op + 8 * h) = o;
                 }
             }
         }
