@@ -71,7 +71,7 @@ template <> struct OpT<f16_t> {
 
 // ---- activations (fp32) ----
 // v_rcp_f32 (1 ulp) instead of an IEEE division: results feed a bf16/f16 operand or are compared at 1e-5
-__device__ __forceinline__ float act_quick_gelu(float u) { return u * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * u)); }
+__device__ __forceinline__ float act_quick_gelu(float u) { return u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * u)); }   // exp(-1.702 u) = 2^(-1.702 log2(e) u): one multiply, one v_exp_f32
 __device__ __forceinline__ float act_gelu(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f)); }
 __device__ __forceinline__ float act_mish(float u) {
     // u * tanh(softplus(u)); softplus threshold 20 as torch.  tanh(log(1+e^u)) = ((1+e^u)^2-1)/((1+e^u)^2+1)
