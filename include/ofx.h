@@ -198,7 +198,7 @@ int ofx_focal_loss(const float* logits, const float* labels, int B, float alpha,
 /* ------------------------------------------------------------------ profiling --------------- */
 /* HIP-event timing of every launch, by category {0 GEMM, 1 norm/embed, 2 attention, 3 other}.
  * enable(mask) clears and starts recording the categories in the bit mask (1 GEMM | 2 norm | 4 attention | 8 other; 0 = off); read() waits for the events (host sync) and returns the
- * summed milliseconds, executed FLOPs (GEMM only) and launch counts; arrays of 4. */
+ * summed milliseconds, executed FLOPs (GEMM only) and launch counts; arrays of 4.  Process-global, not thread-safe: benchmarks and tests only. */
 void ofx_profile_enable(int on);
 int ofx_profile_read(double* ms, double* flops, long long* launches);
 

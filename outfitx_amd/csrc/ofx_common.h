@@ -125,6 +125,7 @@ void ofx_prof_end(hipStream_t s);
 // ext = true: nothing is recorded on the stream; the scope's launches carry the two events themselves (OFX_PLAUNCH ->
 // hipExtLaunchKernelGGL start / stop events: the timestamps come from the dispatch packet's completion signal, so no marker
 // packets are put between the kernels).  The first launch of the scope takes the start event, the one flagged `last` the stop.
+// Profiling state is process-global and single-threaded by contract (benchmarks / tests only, include/ofx.h).
 bool ofx_prof_ext_begin(int cat, double flops);
 void ofx_prof_ext_end();
 extern hipEvent_t g_ofx_launch_e0, g_ofx_launch_e1;

@@ -289,7 +289,7 @@ class Engine:
         offs = np.zeros(N, np.int64); offs[1:] = np.cumsum((nbytes[:-1] + 15) // 16 * 16)
         total = int(offs[-1] + nbytes[-1])
         stage = getattr(self, "_px_stage", None)
-        if stage is None or stage.numel() < total:
+        if stage is None or stage.numel() < total + 4:
             stage = torch.empty(int(total * 1.25) + 4096, dtype=torch.uint8).pin_memory()
             self._px_stage = stage
         else:
