@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--precision", default="bf16x3", help="outfit transformer MFMA operand format")
     ap.add_argument("--tower-precision", default="bf16", help="CLIP towers MFMA operand format (bf16|f16)")
     ap.add_argument("--cpu-outfits", type=int, default=8, help="sample size of the CPU baseline (0 = skip)")
-    ap.add_argument("--ln-fold", type=int, default=1, help="1: towers' LayerNorms folded into the GEMM epilogues (product default); 0: materialised (A/B)")
+    ap.add_argument("--ln-fold", type=int, default=2, help="2 (product default): towers' LayerNorms folded into the GEMM epilogues and the residual stream kept as a (hi, lo) operand-type pair; 1: folded, fp32 stream; 0: materialised (A/B)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))

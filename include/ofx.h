@@ -203,7 +203,8 @@ void ofx_profile_enable(int on);
 int ofx_profile_read(double* ms, double* flops, long long* launches);
 
 /* Process-wide tuning knobs (benchmarks / tests only).  knob 0: GEMM rasterisation group (row panels per L2 group, default 8);
- * knob 6: 1 (default) folds the CLIP towers' LayerNorms into the neighbouring GEMM epilogues, 0 materialises them;
+ * knob 6: 2 (default) folds the CLIP towers' LayerNorms into the neighbouring GEMM epilogues AND keeps their residual stream as an
+ * operand-type (hi, lo) pair updated in place (no fp32 stream between the layers), 1 folds with an fp32 stream, 0 materialises them;
  * knob 8: 1 (default) the ViT's last layer computes queries for the CLS rows only, 0 runs the full QKV GEMM. */
 int ofx_tune(int knob, int value);
 /* Diagnostics: when buf != NULL the big-tile GEMM writes {shader cycles, 100 MHz ticks} of its main loop per block (16 B each). */

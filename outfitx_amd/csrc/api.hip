@@ -406,7 +406,7 @@ size_t carve_set(const ofx_handle* h, Bump& b, int B, int L, SetWs* w) {
     return b.off;
 }
 struct ClipWs { float* X; char* H; char* QKV; char* U; int* idx; char* PL; float* E; float* XP; char* HP; char* UP; char* slab; size_t slab_bytes;
-                char* XB; float* P; float* S; };   // LayerNorm folding: raw operand copy of X, per-segment partial stats, (mean, rstd)
+                char* XB; float* P; float* S; char* XLO; };   // LayerNorm folding: raw operand copy of X, per-segment partial stats, (mean, rstd), lo half of the (hi, lo) stream
 size_t carve_clip(Bump& b, size_t rows, size_t n, size_t W, size_t MLP, size_t PD, size_t u_min_bytes, size_t qkv_min_bytes, ClipWs* w) {
     ClipWs t;
     t.X = b.take<float>(rows * W);
@@ -425,6 +425,7 @@ size_t carve_clip(Bump& b, size_t rows, size_t n, size_t W, size_t MLP, size_t P
     t.XB = b.take<char>(rows * W * 2);
     t.P = b.take<float>(rows * (W / 64) * 2);
     t.S = b.take<float>(rows * 2);
+    t.XLO = b.take<char>(rows * W * 2);
     if (w) *w = t;
     return b.off;
 }
@@ -575,7 +576,8 @@ extern "C" int ofx_cir_prefix(ofx_handle* h, const float* txt, int B, float* out
 // One CLIP encoder layer on `rows` rows.  When `pool_idx` is given (last layer) everything after the attention
 // runs only on the n pooled rows (CLS / EOS): they are the only ones the tower's output depends on.
 int g_prune_q = 1;      // ofx_tune(8, v): 1 = the ViT's last layer computes queries for the CLS rows only
-int g_ln_fold = 1;      // ofx_tune(6, v): 0 = materialise every LayerNorm, 1 = fold the towers' LayerNorms into the GEMM epilogues
+int g_ln_fold = 2;      // ofx_tune(6, v) (default 2): 0 = materialise every LayerNorm, 1 = fold the towers' LayerNorms into the GEMM epilogues,
+                        // 2 = fold AND keep the residual stream as an operand-type (hi, lo) pair (no fp32 stream between the layers)
 
 // fold == true: on entry w.XB / w.S hold the operand copy and the (mean, rstd) of X; on exit (non-pooled layers) they hold
 // those of the layer's output, produced by the fc2 epilogue.  No LayerNorm kernel runs on the full rows.
@@ -609,14 +611,17 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
     float* X = w.X; char* H = w.H; char* U = w.U; int M = rows;
     if (pool_idx) {
         TRY(ofx_launch_gather_rows(w.H, pool_idx, w.HP, nseq, W * 2, W * 2, s));
-        TRY(ofx_launch_gather_rows(w.X, pool_idx, w.XP, nseq, W * 4, W * 4, s));
+        if (fold && g_ln_fold == 2) TRY(ofx_launch_gather_hilo(w.XB, w.XLO, pool_idx, w.XP, nseq, W, dt, s));
+        else TRY(ofx_launch_gather_rows(w.X, pool_idx, w.XP, nseq, W * 4, W * 4, s));
         X = w.XP; H = w.HP; U = w.UP; M = nseq;
     }
     GemmArgs g2{}; g2.A = H; g2.W = L.w_o; g2.C = X; g2.bias = L.b_o; g2.resid = X; g2.M = M; g2.N = W; g2.K = W; g2.lda = W;
     g2.ldc = W; g2.ldr = W; g2.act = OFX_ACT_NONE; g2.out_kind = OFX_OUT_F32;
     if (pool_idx) { g2.slab = w.slab; g2.slab_bytes = w.slab_bytes; }
     const bool fold2 = fold && !pool_idx;          // the pruned last layer runs its tail on the pooled rows, unfolded
+    const bool hilo = fold && g_ln_fold == 2;      // residual stream = (XB, XLO) operand-type pair, no fp32 X (ofx_tune(6, 2))
     if (fold2) { g2.xb_out = w.XB; g2.stat_part = w.P; }
+    if (fold2 && hilo) { g2.xlo = w.XLO; g2.C = w.XB; g2.ldc = W; g2.out_kind = OFX_OUT_OP; g2.resid = nullptr; }
     TRY(ofx_launch_gemm(g2, dt, s));
     GemmArgs g3{}; g3.C = U; g3.M = M; g3.N = MLP; g3.K = W; g3.lda = W;
     g3.ldc = MLP; g3.act = act; g3.out_kind = OFX_OUT_OP;
@@ -634,6 +639,7 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
     g4.lda = MLP; g4.ldc = W; g4.ldr = W; g4.act = OFX_ACT_NONE; g4.out_kind = OFX_OUT_F32;
     if (pool_idx) { g4.slab = w.slab; g4.slab_bytes = w.slab_bytes; }
     if (fold2) { g4.xb_out = w.XB; g4.stat_part = w.P; }
+    if (fold2 && hilo) { g4.xlo = w.XLO; g4.C = w.XB; g4.ldc = W; g4.out_kind = OFX_OUT_OP; g4.resid = nullptr; }
     TRY(ofx_launch_gemm(g4, dt, s));
     if (fold2) TRY(ofx_launch_stats_finalize(w.P, W / 64, W, eps, w.S, M, s));
     return OFX_OK;
@@ -645,7 +651,7 @@ static int clip_layers(const std::vector<ClipLayer>& Ls, const ClipWs& w, int ro
                        int heads, int act, float eps, int causal, const int64_t* key_mask, int mask_ld, int dt,
                        const int* pool_idx, hipStream_t s, bool stats_ready = false, bool pool_first = false) {
     const bool fold = clip_fold(W);
-    if (fold && !stats_ready) TRY(ofx_launch_row_stats_cast(w.X, w.XB, w.S, rows, W, eps, dt, s));     // layer 0's LayerNorm-1 inputs
+    if (fold && !stats_ready) TRY(ofx_launch_row_stats_cast(w.X, w.XB, w.S, rows, W, eps, dt, s, g_ln_fold == 2 ? w.XLO : nullptr));     // layer 0's LayerNorm-1 inputs
     for (size_t l = 0; l < Ls.size(); ++l)
         TRY(clip_layer(Ls[l], w, rows, nseq, S, W, MLP, heads, act, eps, causal, key_mask, mask_ld, dt,
                        l + 1 == Ls.size() ? pool_idx : nullptr, s, fold, pool_first));
@@ -686,7 +692,7 @@ static int vit_core(ofx_handle* h, const float* pixels, const RawImages* raw, in
         TRY(ofx_launch_gemm(gp, dt, s));
         const bool fold = clip_fold(W);                                  // the pre-LN kernel then also emits layer 0's operand copy + statistics
         TRY(ofx_launch_vit_embed_ln((const float*)w.QKV, h->v_cls, h->v_pos, h->v_pre_g, h->v_pre_b, w.X, n, S, W, d.ln_eps, s, fold ? w.XB : nullptr,
-                                    fold ? w.S : nullptr, dt));
+                                    fold ? w.S : nullptr, dt, fold && g_ln_fold == 2 ? w.XLO : nullptr));
         TRY(ofx_launch_iota_rows(w.idx, n, S, s));                        // CLS rows
         TRY(clip_layers(h->vl, w, rows, n, S, W, d.vit_mlp, d.vit_heads, d.vit_act, d.ln_eps, 0, nullptr, 0, dt, w.idx, s, fold, true));
         LnArgs ln{w.XP, nullptr, h->v_post_g, h->v_post_b, w.PL, n, W, W, OFX_OUT_OP, d.ln_eps};

@@ -215,8 +215,10 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
     KArgs k;
     k.A = (const char*)g.A; k.W = (const char*)g.W; k.C = (char*)g.C; k.bias = g.bias; k.resid = g.resid; k.aux_out = g.aux_out; k.m_dev = g.m_dev; k.dbg = g_gemm_dbg; k.skew = g_gemm_skew; k.splits = 1; k.slab = nullptr; k.m_slab = g.M; k.kt_per_split = 0;
     k.M = g.M; k.N = g.N; k.K = g.K; k.lda = g.lda; k.ldc = g.ldc; k.ldr = g.ldr; k.act = g.act; k.out_kind = g.out_kind; k.drop = g.drop; k.n_valid = g.N;
-    k.xb_out = (char*)g.xb_out; k.stat_part = g.stat_part; k.row_stat = g.row_stat; k.col_sum = g.col_sum; k.stat_ld = g.stat_ld > 0 ? g.stat_ld : 1;
-    OFX_REQUIRE(!(g.xb_out || g.stat_part) || (g.out_kind == 0 && g.N % 64 == 0), OFX_EINVAL, "gemm: LayerNorm-fold producer outputs need an fp32 output");
+    k.xb_out = (char*)g.xb_out; k.stat_part = g.stat_part; k.row_stat = g.row_stat; k.col_sum = g.col_sum; k.stat_ld = g.stat_ld > 0 ? g.stat_ld : 1; k.xlo = (char*)g.xlo;
+    OFX_REQUIRE(!g.xlo || (g.xb_out && g.stat_part), OFX_EINVAL, "gemm: xlo needs the LayerNorm-fold producer outputs");
+    OFX_REQUIRE(!(g.xb_out || g.stat_part) || ((g.out_kind == 0 || (g.xlo && g.out_kind == 1 && g.C == g.xb_out && g.ldc == g.N)) && g.N % 64 == 0), OFX_EINVAL,
+                "gemm: LayerNorm-fold producer outputs need an fp32 output (or, with xlo, C == xb_out in the operand type)");
     OFX_REQUIRE(!g.row_stat || g.col_sum, OFX_EINVAL, "gemm: row_stat needs col_sum");
     OFX_REQUIRE(!(g.row_stat || g.xb_out || g.stat_part) || (!g.aux_out && !g.drop.thresh && g.act != OFX_ACT_MISH && g.act != OFX_ACT_MISH_GRAD), OFX_EINVAL,
                 "gemm: LayerNorm folding does not combine with the training epilogue features");

@@ -30,7 +30,7 @@ struct KArgs {
     int splits, kt_per_split;   // 128x128 kernel only: blockIdx.y owns k-tiles [y*kt_per_split, ...) and writes a raw fp32 slab
     float* slab;                // [splits, M, N] partial sums when splits > 1
     DropArgs drop;
-    char* xb_out; float* stat_part; const float* row_stat; const float* col_sum; int stat_ld;   // LayerNorm folding (GemmArgs)
+    char* xb_out; float* stat_part; const float* row_stat; const float* col_sum; int stat_ld; char* xlo;   // LayerNorm folding (GemmArgs)
     int n_valid;                // columns >= n_valid are computed but not stored (fp32 outputs of the TN kernel; = N elsewhere)
 };
 
@@ -75,7 +75,18 @@ __device__ __forceinline__ void epilogue(const KArgs& p, OFX_LDS float* ep, int 
                     for (int e = 0; e < 4; ++e) v[e] *= act_mish_grad(rr[e]);
                 } else v += rr;
             }
-            if (p.out_kind == 0) {
+            if (p.xlo) {            // LayerNorm-fold producer on a (hi, lo) residual stream (see epilogue2, FOLD 3): in-place update
+                T* hp = (T*)p.xb_out + (size_t)gm * p.N + gn;
+                T* lp = (T*)p.xlo + (size_t)gm * p.N + gn;
+                const v4 h0 = *(const v4*)hp, l0 = *(const v4*)lp;
+                v4 hb, lb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += (float)h0[e] + (float)l0[e]; hb[e] = (T)v[e]; lb[e] = (T)(v[e] - (float)hb[e]); }
+                *(v4*)hp = hb; *(v4*)lp = lb;
+                const float ssum = row16_sum_to_lane15((v[0] + v[1]) + (v[2] + v[3]));
+                const float ssq = row16_sum_to_lane15((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+                if ((lane & 15) == 15) *(f32x2*)(p.stat_part + ((size_t)gm * (p.N >> 6) + (gn0 >> 6)) * 2) = f32x2{ssum, ssq};
+            } else if (p.out_kind == 0) {
                 *(f32x4*)(p.C + ((size_t)gm * p.ldc + gn) * 4) = v;
                 if (p.xb_out) {
                     v4 hb;
@@ -128,12 +139,13 @@ __device__ __forceinline__ float act_apply(float v) {
 }
 
 // FOLD (LayerNorm folding, compile-time so the common path keeps its registers): 0 none, 1 producer (fp32 output + operand copy
-// + per-segment statistics), 2 consumer (row statistics + column sums applied to the accumulator).
+// + per-segment statistics), 2 consumer (row statistics + column sums applied to the accumulator), 3 producer whose residual
+// stream is the operand-type pair (xb_out = hi, xlo = lo = x - hi), read and rewritten in place - no fp32 copy of the stream.
 template <typename T, int ACT, int FOLD = 0, int RAMP = 0>
 __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x4 (&acc)[8][4], int gm0, int gn0, int lane) {
     typedef typename OpT<T>::v8 v8;
     const int fr = lane & 15, fq = lane >> 4;
-    if (p.out_kind == 0) {
+    if (FOLD != 3 && p.out_kind == 0) {
         constexpr int DEPTH = 2;
         const int chunk = lane & 15, rsub = lane >> 4;
         const int gn = gn0 + chunk * 4;
@@ -209,8 +221,21 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
         if (p.bias) { b0 = *(const f32x4*)(p.bias + gn); b1 = *(const f32x4*)(p.bias + gn + 4); }
         f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = cs0;
         if (FOLD == 2) { cs0 = *(const f32x4*)(p.col_sum + gn); cs1 = *(const f32x4*)(p.col_sum + gn + 4); }
+        // FOLD 3: the residual stream is the operand-type pair (hi at xb_out == C, lo at xlo), 16 bytes of each per lane and row,
+        // fetched two passes ahead and rewritten in place (every element is owned by exactly one lane of one block)
+        v8 rh[FOLD == 3 ? 3 : 1][2], rl[FOLD == 3 ? 3 : 1][2];
+        auto fetch_hl = [&](int pass, v8 (&dh)[2], v8 (&dl)[2]) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int gm = min(gm0 + pass * 16 + it * 8 + rsub, p.M - 1);
+                dh[it] = *(const v8*)((const T*)p.xb_out + (size_t)gm * p.N + gn);
+                dl[it] = *(const v8*)((const T*)p.xlo + (size_t)gm * p.N + gn);
+            }
+        };
+        if (FOLD == 3) { fetch_hl(0, rh[0], rl[0]); fetch_hl(1, rh[FOLD == 3 ? 1 : 0], rl[FOLD == 3 ? 1 : 0]); }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
+            if (FOLD == 3 && i + 2 < 8) fetch_hl(i + 2, rh[FOLD == 3 ? (i + 2) % 3 : 0], rl[FOLD == 3 ? (i + 2) % 3 : 0]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) *(OFX_LDS f32x4*)(ep + fr * 256 + (((j * 4 + fq) ^ (fr & 7)) << 4)) = acc[i][j];
 #pragma unroll
@@ -238,11 +263,27 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
                             for (int e = 0; e < 4; ++e) { v0[e] *= act_mish_grad(r0[e]); v1[e] *= act_mish_grad(r1[e]); }
                         } else { v0 += r0; v1 += r1; }
                     }
+                    if (FOLD == 3) {
+                        const v8 h = rh[FOLD == 3 ? i % 3 : 0][it], l = rl[FOLD == 3 ? i % 3 : 0][it];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v0[e] += (float)h[e] + (float)l[e]; v1[e] += (float)h[4 + e] + (float)l[4 + e]; }
+                    }
                     v8 hi;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { hi[e] = (T)v0[e]; hi[4 + e] = (T)v1[e]; }
                     T* crow = (T*)p.C + (size_t)gm * p.ldc + gn;
                     *(v8*)crow = hi;
+                    if (FOLD == 3) {
+                        v8 lo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { lo[e] = (T)(v0[e] - (float)hi[e]); lo[4 + e] = (T)(v1[e] - (float)hi[4 + e]); }
+                        *(v8*)((T*)p.xlo + (size_t)gm * p.N + gn) = lo;
+                        // per-64-column (sum, sum of squares) of the fp32 values: the 8 lanes of this row
+                        const float ssum = row8_sum(((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3])));
+                        const float ssq = row8_sum(((v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3])) +
+                                                   ((v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3])));
+                        if (c8 == 7) *(f32x2*)(p.stat_part + ((size_t)gm * (p.N >> 6) + (gn0 >> 6)) * 2) = f32x2{ssum, ssq};
+                    }
                     if (p.out_kind == 2) {
                         v8 lo;
 #pragma unroll
@@ -266,7 +307,11 @@ __device__ __forceinline__ void epilogue2_dispatch(const KArgs& p, OFX_LDS char*
         }
         return;
     }
-    if (p.xb_out || p.stat_part) { epilogue2<T, OFX_ACT_NONE, 1, 1>(p, ep, acc, gm0, gn0, lane); return; }
+    if (p.xb_out || p.stat_part) {
+        if (p.xlo) epilogue2<T, OFX_ACT_NONE, 3, 1>(p, ep, acc, gm0, gn0, lane);
+        else epilogue2<T, OFX_ACT_NONE, 1, 1>(p, ep, acc, gm0, gn0, lane);
+        return;
+    }
     switch (p.act) {
         case OFX_ACT_QUICK_GELU: epilogue2<T, OFX_ACT_QUICK_GELU>(p, ep, acc, gm0, gn0, lane); break;
         case OFX_ACT_GELU: epilogue2<T, OFX_ACT_GELU>(p, ep, acc, gm0, gn0, lane); break;

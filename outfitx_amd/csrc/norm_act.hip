@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* px, T* out, 
 template <int NCH, typename T>
 __global__ __launch_bounds__(256) void vit_embed_ln_kernel(const float* patch_out, const float* cls, const float* pos,
                                                           const float* gamma, const float* beta, float* x, int N, int S,
-                                                          float eps, T* xb, float* stat) {
+                                                          float eps, T* xb, float* stat, T* xlo) {
     typedef typename OpT<T>::v4 v4;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int D = NCH * 256, rows = N * S;
@@ -201,6 +201,12 @@ __global__ __launch_bounds__(256) void vit_embed_ln_kernel(const float* patch_ou
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float dlt = v[c][e] - mo; qo += dlt * dlt; o[e] = (T)v[c][e]; }
                 *(v4*)(xb + (size_t)r * D + col) = o;
+                if (xlo) {              // residual stream as a (hi, lo) operand-type pair: lo = x - hi
+                    v4 l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) l[e] = (T)(v[c][e] - (float)o[e]);
+                    *(v4*)(xlo + (size_t)r * D + col) = l;
+                }
             }
             qo = wave_sum(qo);
             if (lane == 0) { stat[2 * (size_t)r] = mo; stat[2 * (size_t)r + 1] = rsqrtf(qo * (1.0f / D) + eps); }
@@ -338,6 +344,23 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const char* src, const
     }
 }
 
+// dst[r] = hi[idx[r]] + lo[idx[r]] (fp32): pooled rows of a residual stream kept as an operand-type (hi, lo) pair
+template <typename T>
+__global__ __launch_bounds__(256) void gather_hilo_kernel(const T* hi, const T* lo, const int* idx, float* dst, int rows, int W) {
+    typedef typename OpT<T>::v4 v4;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int r = blockIdx.x * 4 + w; r < rows; r += gridDim.x * 4) {
+        const size_t so = (size_t)idx[r] * W;
+        for (int c = lane * 4; c < W; c += 256) {
+            const v4 h = *(const v4*)(hi + so + c), l = *(const v4*)(lo + so + c);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (float)h[e] + (float)l[e];
+            *(f32x4*)(dst + (size_t)r * W + c) = o;
+        }
+    }
+}
+
 // out[b] = X[cu[b]]
 __global__ __launch_bounds__(256) void gather_row0_kernel(const float* X, const int* cu, float* out, int B, int D) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -358,7 +381,7 @@ __global__ __launch_bounds__(256) void cir_prefix_kernel(const float* img_emb, c
 // ---- LayerNorm folding support (GemmArgs::row_stat / col_sum) ---------------------------------------------------------
 // First layer of a tower: operand-type copy of the raw rows + their (mean, rstd).  One wave per row.
 template <typename T>
-__global__ __launch_bounds__(256) void row_stats_cast_kernel(const float* X, T* Xb, float* stat, int rows, int W, float eps) {
+__global__ __launch_bounds__(256) void row_stats_cast_kernel(const float* X, T* Xb, float* stat, int rows, int W, float eps, T* Xlo) {
     typedef typename OpT<T>::v4 v4;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int r = blockIdx.x * 4 + w; r < rows; r += gridDim.x * 4) {
@@ -373,6 +396,12 @@ __global__ __launch_bounds__(256) void row_stats_cast_kernel(const float* X, T* 
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float d = v[e] - mu; q += d * d; o[e] = (T)v[e]; }
             *(v4*)(Xb + (size_t)r * W + c) = o;
+            if (Xlo) {
+                v4 l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) l[e] = (T)(v[e] - (float)o[e]);
+                *(v4*)(Xlo + (size_t)r * W + c) = l;
+            }
         }
         q = wave_sum(q);
         if (lane == 0) { stat[2 * (size_t)r] = mu; stat[2 * (size_t)r + 1] = rsqrtf(q / W + eps); }
@@ -445,11 +474,11 @@ int ofx_launch_patchify(const float* px, void* out, int N, int img, int patch, i
     return OFX_OK;
 }
 int ofx_launch_vit_embed_ln(const float* patch_out, const float* cls, const float* pos, const float* g, const float* b,
-                            float* x, int N, int S, int D, float eps, hipStream_t s, void* xb, float* stat, int op_dtype) {
+                            float* x, int N, int S, int D, float eps, hipStream_t s, void* xb, float* stat, int op_dtype, void* xlo) {
     OFX_REQUIRE(D == 768 || D == 512 || D == 1024, OFX_ESHAPE, "vit_embed_ln: D=%d", D);
     const int grid = rows_grid(N * S);
     ProfScope prof(PROF_NORM, s);
-#define VEL(NCH, T) hipLaunchKernelGGL((vit_embed_ln_kernel<NCH, T>), dim3(grid), dim3(256), 0, s, patch_out, cls, pos, g, b, x, N, S, eps, (T*)xb, stat)
+#define VEL(NCH, T) hipLaunchKernelGGL((vit_embed_ln_kernel<NCH, T>), dim3(grid), dim3(256), 0, s, patch_out, cls, pos, g, b, x, N, S, eps, (T*)xb, stat, (T*)xlo)
     if (op_dtype == OFX_F16) { if (D == 768) VEL(3, f16_t); else if (D == 512) VEL(2, f16_t); else VEL(4, f16_t); }
     else { if (D == 768) VEL(3, bf16_t); else if (D == 512) VEL(2, bf16_t); else VEL(4, bf16_t); }
 #undef VEL
@@ -501,11 +530,18 @@ int ofx_launch_gather_rows(const void* src, const int* idx, void* dst, int rows,
     OFX_LAUNCH_CHECK();
     return OFX_OK;
 }
-int ofx_launch_row_stats_cast(const float* X, void* Xb, float* stat, int rows, int W, float eps, int op_dtype, hipStream_t s) {
+int ofx_launch_gather_hilo(const void* hi, const void* lo, const int* idx, float* dst, int rows, int W, int op_dtype, hipStream_t s) {
+    OFX_REQUIRE(W % 4 == 0 && rows > 0, OFX_ESHAPE, "gather_hilo: rows=%d W=%d", rows, W);
+    if (op_dtype == OFX_F16) hipLaunchKernelGGL(gather_hilo_kernel<f16_t>, dim3(rows_grid(rows)), dim3(256), 0, s, (const f16_t*)hi, (const f16_t*)lo, idx, dst, rows, W);
+    else hipLaunchKernelGGL(gather_hilo_kernel<bf16_t>, dim3(rows_grid(rows)), dim3(256), 0, s, (const bf16_t*)hi, (const bf16_t*)lo, idx, dst, rows, W);
+    OFX_LAUNCH_CHECK();
+    return OFX_OK;
+}
+int ofx_launch_row_stats_cast(const float* X, void* Xb, float* stat, int rows, int W, float eps, int op_dtype, hipStream_t s, void* Xlo) {
     OFX_REQUIRE(W % 4 == 0 && rows > 0, OFX_ESHAPE, "row_stats_cast: rows=%d W=%d", rows, W);
     ProfScope prof(PROF_NORM, s);
-    if (op_dtype == OFX_F16) hipLaunchKernelGGL(row_stats_cast_kernel<f16_t>, dim3(rows_grid(rows)), dim3(256), 0, s, X, (f16_t*)Xb, stat, rows, W, eps);
-    else hipLaunchKernelGGL(row_stats_cast_kernel<bf16_t>, dim3(rows_grid(rows)), dim3(256), 0, s, X, (bf16_t*)Xb, stat, rows, W, eps);
+    if (op_dtype == OFX_F16) hipLaunchKernelGGL(row_stats_cast_kernel<f16_t>, dim3(rows_grid(rows)), dim3(256), 0, s, X, (f16_t*)Xb, stat, rows, W, eps, (f16_t*)Xlo);
+    else hipLaunchKernelGGL(row_stats_cast_kernel<bf16_t>, dim3(rows_grid(rows)), dim3(256), 0, s, X, (bf16_t*)Xb, stat, rows, W, eps, (bf16_t*)Xlo);
     OFX_LAUNCH_CHECK();
     return OFX_OK;
 }

@@ -105,6 +105,13 @@ __device__ __forceinline__ float row16_sum_to_lane15(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));   // row_shr:8
     return v;
 }
+// sum over aligned groups of 8 lanes (xor 1, xor 2 within quads, then the mirrored half row); every lane of the group gets the total
+__device__ __forceinline__ float row8_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm:[1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm:[2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -228,6 +235,8 @@ struct GemmArgs {
     float* stat_part = nullptr;     // [M, N / 64, 2]
     const float* row_stat = nullptr;   // [M, 2] (mean, rstd)
     int stat_ld = 1;                   // row m's statistics sit at row_stat[2 * m * stat_ld] (strided A rows)
+    void* xlo = nullptr;               // producer with xb_out: the residual stream is the operand-type pair (xb_out, xlo), updated in place;
+                                       // `resid` / `C` are then unused (no fp32 copy of the stream exists)
     const float* col_sum = nullptr;    // [N] column sums of the (rounded) gamma-scaled weight rows
 };
 int ofx_launch_gemm(const GemmArgs& g, int op_dtype /*OFX_BF16|OFX_F16*/, hipStream_t s);
@@ -255,7 +264,8 @@ int ofx_launch_pack_rows(const float* src, void* dst, int rows_src, int rows_dst
                          int mode, int op_dtype, hipStream_t s);
 int ofx_launch_patchify(const float* px, void* out, int N, int img, int patch, int op_dtype, hipStream_t s);
 int ofx_launch_vit_embed_ln(const float* patch_out, const float* cls, const float* pos, const float* g, const float* b,
-                            float* x, int N, int S, int D, float eps, hipStream_t s, void* xb = nullptr, float* stat = nullptr, int op_dtype = OFX_BF16);
+                            float* x, int N, int S, int D, float eps, hipStream_t s, void* xb = nullptr, float* stat = nullptr, int op_dtype = OFX_BF16,
+                            void* xlo = nullptr);
 int ofx_launch_text_embed(const int64_t* ids, const float* tok, const float* pos, float* x, int N, int T, int Tc, int D,
                           int vocab, hipStream_t s);
 int ofx_launch_text_eos_index(const int64_t* ids, int* row_idx, int N, int T, int Tc, int eos_id, hipStream_t s);
@@ -268,7 +278,8 @@ int ofx_launch_set_build_indexed(const float* table, int ld, long long n_table, 
                                  int prefix_stride, int* cu_rows, float* X, int B, int D, hipStream_t s);
 int ofx_preprocess_to(const uint8_t* src, const long long* offsets, const int* heights, const int* widths, int N, int channels, int size,
                       const float* mean, const float* stdv, float* out, void* patches, int patch, int op_dtype, void* ws, size_t ws_bytes, hipStream_t stream);
-int ofx_launch_row_stats_cast(const float* X, void* Xb, float* stat, int rows, int W, float eps, int op_dtype, hipStream_t s);
+int ofx_launch_row_stats_cast(const float* X, void* Xb, float* stat, int rows, int W, float eps, int op_dtype, hipStream_t s, void* Xlo = nullptr);
+int ofx_launch_gather_hilo(const void* hi, const void* lo, const int* idx, float* dst, int rows, int W, int op_dtype, hipStream_t s);
 int ofx_launch_stats_finalize(const float* part, int slots, int W, float eps, float* stat, int rows, hipStream_t s);
 int ofx_launch_fold_pack(const float* Wsrc, const float* gamma, const float* beta, const float* bias, void* Wf, float* col_sum, float* bias_f,
                          int N, int K, int op_dtype, hipStream_t s);

@@ -36,19 +36,19 @@ for b in range(nb):
     ref = O.cp_forward(emb, mask, Wt)
     texts = {"input_ids": torch.from_numpy(ids).view(k, n, 64), "attention_mask": torch.from_numpy(att).view(k, n, 64)}
     for tp in ("bf16", "f16"):
-        for fold in (1, 0):
+        for fold in (2, 1, 0):
             lib.ofx_tune(6, fold)
             with torch.no_grad():
                 got = models[tp](task=CP, outfit_embedding=None, outfit_mask=torch.from_numpy(mask).to(dev),
                                  encoder_input_dict={"images": px.to(dev), "texts": texts}).float().cpu().numpy()
-            lib.ofx_tune(6, 1)
+            lib.ofx_tune(6, 2)
             d = got.reshape(-1) - ref.reshape(-1)
             rows.append({"batch": b, "towers": tp, "fold": fold, "max_rel": float(np.abs(d).max() / np.abs(ref).max()),
                          "rms_rel": float(np.sqrt((d ** 2).mean()) / np.sqrt((ref ** 2).mean()))})
     print(f"batch {b}: oracle {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
 summary = {}
 for tp in ("bf16", "f16"):
-    for fold in (1, 0):
+    for fold in (2, 1, 0):
         r = [x for x in rows if x["towers"] == tp and x["fold"] == fold]
         summary[f"{tp}_fold{fold}"] = {"max_rel_per_batch": [round(x["max_rel"], 5) for x in r],
                                       "mean_of_max_rel": round(float(np.mean([x["max_rel"] for x in r])), 5),

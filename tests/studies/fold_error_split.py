@@ -17,12 +17,12 @@ te = CLIPTextEncoder(); te.model.load_state_dict({k: torch.from_numpy(v) for k, 
 out = {}
 for tp in ("bf16", "f16"):
     ie.tower_precision = tp; te.tower_precision = tp
-    for fold in (1, 0):
+    for fold in (2, 1, 0):
         lib.ofx_tune(6, fold)
         with torch.no_grad():
             gi = ie(torch.from_numpy(px).view(n, 1, 3, 224, 224).cuda(), normalize=False).view(n, -1).cpu().numpy()
             gt = te({"input_ids": torch.from_numpy(ids).view(n, 1, 64), "attention_mask": torch.from_numpy(att).view(n, 1, 64)}, normalize=False).view(n, -1).cpu().numpy()
-        lib.ofx_tune(6, 1)
+        lib.ofx_tune(6, 2)
         for name, g, r in (("vit", gi, ref_i), ("text", gt, ref_t)):
             gn_, rn_ = g / np.linalg.norm(g, axis=1, keepdims=True), r / np.linalg.norm(r, axis=1, keepdims=True)
             dn = gn_ - rn_
