@@ -179,7 +179,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_big_kernel<2,4,2> / <2,2,1> / gemm_128x128_kernel (every dense contraction of the step)",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                         "traffic_note": "bytes/launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/r01_traffic_pmc.json (separate --pmc passes); algorithmic ~400e6 (operands + fp32 residual in/out + outputs + the folded LayerNorm row copies)",
+                         "traffic_note": "bytes/launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/r01_traffic_pmc.json (separate --pmc passes); algorithmic ~370e6 (operands + the (hi, lo) residual stream in/out + outputs)",
                          "launches_per_step": gemm_launches, "sampled_steps": 1,
                          "avg_launch_us": round(gemm_ms * 1e3 / max(gemm_launches, 1), 2),
                          "algorithmic_gflop_per_outfit": round(alg_gemm_outfit / 1e9, 3)},
