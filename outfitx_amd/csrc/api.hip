@@ -691,7 +691,7 @@ static int vit_core(ofx_handle* h, const float* pixels, const RawImages* raw, in
         gp.act = OFX_ACT_NONE; gp.out_kind = OFX_OUT_F32;
         TRY(ofx_launch_gemm(gp, dt, s));
         const bool fold = clip_fold(W);                                  // the pre-LN kernel then also emits layer 0's operand copy + statistics
-        TRY(ofx_launch_vit_embed_ln((const float*)w.QKV, h->v_cls, h->v_pos, h->v_pre_g, h->v_pre_b, w.X, n, S, W, d.ln_eps, s, fold ? w.XB : nullptr,
+        TRY(ofx_launch_vit_embed_ln((const float*)w.QKV, h->v_cls, h->v_pos, h->v_pre_g, h->v_pre_b, fold && g_ln_fold == 2 ? nullptr : w.X, n, S, W, d.ln_eps, s, fold ? w.XB : nullptr,
                                     fold ? w.S : nullptr, dt, fold && g_ln_fold == 2 ? w.XLO : nullptr));
         TRY(ofx_launch_iota_rows(w.idx, n, S, s));                        // CLS rows
         TRY(clip_layers(h->vl, w, rows, n, S, W, d.vit_mlp, d.vit_heads, d.vit_act, d.ln_eps, 0, nullptr, 0, dt, w.idx, s, fold, true));

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void vit_embed_ln_kernel(const float* patch_ou
         for (int c = 0; c < NCH; ++c) {
             const int col = (lane + 64 * c) * 4;
             v[c] = v[c] * rstd * *(const f32x4*)(gamma + col) + *(const f32x4*)(beta + col);
-            *(f32x4*)(x + (size_t)r * D + col) = v[c];
+            if (x) *(f32x4*)(x + (size_t)r * D + col) = v[c];          // NULL: the stream lives in (xb, xlo) only
             so += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
         }
         if (xb) {
