@@ -146,7 +146,10 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_big_kernel(KArgs p) {
 
     OFX_LDS char* ep = lds + NST * STAGE + wave * EPI2_BYTES_PER_WAVE;   // private staging, outside the stages
     const int gm0 = m0 + wr * 128, gn0 = n0 + wc * 64;
-    epilogue2_dispatch<T>(p, ep, acc, gm0, gn0, lane);
+    // LayerNorm-fold consumer: the row statistics are staged per wave in the (now idle) stage buffers - block-uniform condition
+    OFX_LDS float* st = nullptr;
+    if (p.row_stat && p.out_kind != 0 && ABL == 0) { __syncthreads(); st = (OFX_LDS float*)(lds + wave * 1024); }
+    epilogue2_dispatch<T>(p, ep, acc, gm0, gn0, lane, st);
     if (p.dbg) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) p.dbg[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memtime() - cloop_end;

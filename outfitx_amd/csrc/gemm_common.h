@@ -142,7 +142,8 @@ __device__ __forceinline__ float act_apply(float v) {
 // + per-segment statistics), 2 consumer (row statistics + column sums applied to the accumulator), 3 producer whose residual
 // stream is the operand-type pair (xb_out = hi, xlo = lo = x - hi), read and rewritten in place - no fp32 copy of the stream.
 template <typename T, int ACT, int FOLD = 0, int RAMP = 0>
-__device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x4 (&acc)[8][4], int gm0, int gn0, int lane) {
+__device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x4 (&acc)[8][4], int gm0, int gn0, int lane,
+                                          OFX_LDS float* st = nullptr) {
     typedef typename OpT<T>::v8 v8;
     const int fr = lane & 15, fq = lane >> 4;
     if (FOLD != 3 && p.out_kind == 0) {
@@ -221,6 +222,21 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
         if (p.bias) { b0 = *(const f32x4*)(p.bias + gn); b1 = *(const f32x4*)(p.bias + gn + 4); }
         f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = cs0;
         if (FOLD == 2) { cs0 = *(const f32x4*)(p.col_sum + gn); cs1 = *(const f32x4*)(p.col_sum + gn + 4); }
+        // FOLD 2 with a staging slot: the wave's 128 (mean, rstd) pairs go through LDS - one 16-byte global load per lane (rows
+        // 2 lane, 2 lane + 1) instead of an 8-byte global load per row, lane and pass (the epilogues are bound by their memory
+        // instructions)
+        const bool st_lds = FOLD == 2 && st != nullptr;
+        if (st_lds) {
+            const int ra = min(gm0 + 2 * lane, p.M - 1), rb = min(gm0 + 2 * lane + 1, p.M - 1);
+            f32x4 pr;
+            if (p.stat_ld == 1 && rb == ra + 1) pr = *(const f32x4*)(p.row_stat + 2 * (size_t)ra);
+            else {
+                const f32x2 a2 = *(const f32x2*)(p.row_stat + 2 * (size_t)ra * p.stat_ld), b2 = *(const f32x2*)(p.row_stat + 2 * (size_t)rb * p.stat_ld);
+                pr = f32x4{a2[0], a2[1], b2[0], b2[1]};
+            }
+            *(OFX_LDS f32x4*)(st + 4 * lane) = pr;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         // FOLD 3: the residual stream is the operand-type pair (hi at xb_out == C, lo at xlo), 16 bytes of each per lane and row,
         // fetched two passes ahead and rewritten in place (every element is owned by exactly one lane of one block)
         v8 rh[FOLD == 3 ? 3 : 1][2], rl[FOLD == 3 ? 3 : 1][2];
@@ -246,7 +262,9 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
                 f32x4 v1 = *(OFX_LDS f32x4*)(ep + row * 256 + (((2 * c8 + 1) ^ (row & 7)) << 4));
                 if (gm < p.M) {
                     if (FOLD == 2) {
-                        const float mu = p.row_stat[2 * (size_t)gm * p.stat_ld], rs = p.row_stat[2 * (size_t)gm * p.stat_ld + 1];
+                        float mu, rs;
+                        if (st_lds) { const f32x2 ms = *(OFX_LDS f32x2*)(st + 2 * (i * 16 + row)); mu = ms[0]; rs = ms[1]; }
+                        else { mu = p.row_stat[2 * (size_t)gm * p.stat_ld]; rs = p.row_stat[2 * (size_t)gm * p.stat_ld + 1]; }
                         v0 = (v0 - cs0 * mu) * rs + b0; v1 = (v1 - cs1 * mu) * rs + b1;
                     } else { v0 += b0; v1 += b1; }
                     if (FOLD == 0 && p.aux_out) { *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn) = v0; *(f32x4*)(p.aux_out + (size_t)gm * p.N + gn + 4) = v1; }
@@ -298,12 +316,13 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
 }
 
 template <typename T>
-__device__ __forceinline__ void epilogue2_dispatch(const KArgs& p, OFX_LDS char* ep, f32x4 (&acc)[8][4], int gm0, int gn0, int lane) {
+__device__ __forceinline__ void epilogue2_dispatch(const KArgs& p, OFX_LDS char* ep, f32x4 (&acc)[8][4], int gm0, int gn0, int lane,
+                                                   OFX_LDS float* st = nullptr) {
     if (p.row_stat) {                                  // LayerNorm-fold consumer: towers only (no residual, no dropout, no tape)
         switch (p.act) {
-            case OFX_ACT_QUICK_GELU: epilogue2<T, OFX_ACT_QUICK_GELU, 2>(p, ep, acc, gm0, gn0, lane); break;
-            case OFX_ACT_GELU: epilogue2<T, OFX_ACT_GELU, 2>(p, ep, acc, gm0, gn0, lane); break;
-            default: epilogue2<T, OFX_ACT_NONE, 2>(p, ep, acc, gm0, gn0, lane); break;
+            case OFX_ACT_QUICK_GELU: epilogue2<T, OFX_ACT_QUICK_GELU, 2>(p, ep, acc, gm0, gn0, lane, st); break;
+            case OFX_ACT_GELU: epilogue2<T, OFX_ACT_GELU, 2>(p, ep, acc, gm0, gn0, lane, st); break;
+            default: epilogue2<T, OFX_ACT_NONE, 2>(p, ep, acc, gm0, gn0, lane, st); break;
         }
         return;
     }

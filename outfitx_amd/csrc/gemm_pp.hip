@@ -143,7 +143,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(KArgs p) {
 
     OFX_LDS char* ep = lds + 2 * STAGE + wave * EPI2_BYTES_PER_WAVE;
     const int gm0 = m0 + wr * 128, gn0 = n0 + wc * 64;
-    epilogue2_dispatch<T>(p, ep, acc, gm0, gn0, lane);
+    // LayerNorm-fold consumer: the row statistics are staged per wave in the (now idle) stage buffers - block-uniform condition
+    OFX_LDS float* st = nullptr;
+    if (p.row_stat && p.out_kind != 0) { __syncthreads(); st = (OFX_LDS float*)(lds + wave * 1024); }
+    epilogue2_dispatch<T>(p, ep, acc, gm0, gn0, lane, st);
 }
 
 
