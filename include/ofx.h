@@ -7,9 +7,19 @@
  * ctypes; see INTEGRATION.md for the stub a reference maintainer would add.
  *
  * Conventions: plain pointers and sizes only (no torch types); every pointer is a DEVICE pointer
- * unless marked host; every launch goes to the hipStream_t passed as `stream` (void*); no
- * function synchronises the host or allocates caller-visible memory; return 0 on success or a
- * negative OFX_E* code with text in ofx_last_error() (thread-local).  gfx950 only.
+ * unless marked host; every launch goes to the hipStream_t passed as `stream` (void*); no function
+ * allocates caller-visible memory; return 0 on success or a negative OFX_E* code with text in
+ * ofx_last_error() (thread-local).  gfx950 only.
+ *
+ * Host synchronisation and state - the complete list:
+ *   - no entry point waits for the stream it launches on, with ONE bounded exception: ofx_clip_preprocess /
+ *     ofx_vit_b32_fwd_u8 copy a few KB of host-computed resampling plan through a library-owned ring of 4 pinned
+ *     slots per device and wait (hipEventSynchronize) only if the copy issued 4 calls earlier on that device has not
+ *     left its slot yet;
+ *   - ofx_profile_read waits for its events (it is a read-back; profiling is off by default);
+ *   - library-owned state: the ofx_handle (packed weight arenas on the handle's device), the per-device pinned ring
+ *     above, a host-side cache of resampling coefficient tables, the ofx_tune knobs and the profiling records.
+ *     Nothing else is process-global; handles of different devices are independent.
  */
 #ifndef OFX_H
 #define OFX_H
@@ -194,6 +204,11 @@ int ofx_dropout_mask(float dropout_p, unsigned seed, int site, int rows, int col
 /* FocalLoss(alpha, gamma, mean) forward and d loss / d logits * upstream (src/losses/focal_loss.py:23-41). loss / dlogits may be NULL. */
 int ofx_focal_loss(const float* logits, const float* labels, int B, float alpha, float gamma, float upstream, float* loss, float* dlogits,
                    ofx_stream stream);
+/* The same with the reference's `reduction` argument (focal_loss.py:36-41): 1 mean, 2 sum, 0 none.  `per_elem` [B] (required for
+ * 'none', optional otherwise) receives the unreduced losses; for 'none' dlogits is the per-element derivative (times upstream) and
+ * *loss, if given, their sum. */
+int ofx_focal_loss_ex(const float* logits, const float* labels, int B, float alpha, float gamma, float upstream, int reduction, float* loss,
+                      float* per_elem, float* dlogits, ofx_stream stream);
 
 /* ------------------------------------------------------------------ profiling --------------- */
 /* HIP-event timing of every launch, by category {0 GEMM, 1 norm/embed, 2 attention, 3 other}.
@@ -213,6 +228,10 @@ void ofx_debug_gemm_clock(void* buf);
 /* ------------------------------------------------------------------ op level (tests) ------- */
 int ofx_gemm(const void* A, const void* W, void* C, const float* bias, const float* resid, int M, int N, int K,
              int lda, int ldc, int ldr, int act, int out_kind, int op_dtype, ofx_stream stream);
+/* The same against a SPLIT weight matrix W2 [N, 2K], row n = [hi(K) | lo(K)] (ofx_convert mode 3): C = A (hi + lo)^T + ... with one
+ * copy of A - two MFMA products per weight, ~22 significant weight bits.  K multiple of 64. */
+int ofx_gemm_w2(const void* A, const void* W2, void* C, const float* bias, const float* resid, int M, int N, int K,
+                int lda, int ldc, int ldr, int act, int out_kind, int op_dtype, ofx_stream stream);
 /* Weight-gradient GEMM of the training step: C[M,N] fp32 = sum_k A[k, m] * B[k, n]; A [K, lda] and B [K, ldb] row-major
  * operand-type matrices whose ROW index is contracted (dW = dY^T X without transposed copies).  M, N multiples of 256.
  * k_dev: optional device-side live row count (<= K).  Both operands must be readable up to round_up(K, 64) rows.

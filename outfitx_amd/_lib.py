@@ -72,11 +72,13 @@ SIGNATURES = {
     "ofx_cir_train_bwd_into": (_i, [_vp, _vp, _sz, _vp, _i, _i, C.POINTER(_vp), _i, _i, _vp, _sz, _f, C.c_uint, _vp]),
     "ofx_dropout_mask": (_i, [_f, C.c_uint, _i, _i, _i, _vp, _vp]),
     "ofx_focal_loss": (_i, [_vp, _vp, _i, _f, _f, _f, _vp, _vp, _vp]),
+    "ofx_focal_loss_ex": (_i, [_vp, _vp, _i, _f, _f, _f, _i, _vp, _vp, _vp, _vp]),
     "ofx_profile_enable": (None, [_i]),
     "ofx_profile_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "ofx_tune": (_i, [_i, _i]),
     "ofx_debug_gemm_clock": (None, [_vp]),
     "ofx_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ofx_gemm_w2": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ofx_gemm_tn_ws": (_sz, [_i, _i, _i]),
     "ofx_gemm_tn": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp]),
     "ofx_gemm_splitk_ws": (_sz, [_i, _i, _i]),

@@ -96,7 +96,8 @@ int ofx_launch_set_attention_bwd(const void* qkv, const float* d_o, void* dqkv, 
 int ofx_launch_set_attention_bwd_mfma(const void* qkv, const float* d_o, void* dqkv, const int* cu, int nseq, int n_head, int D, int max_len,
                                       float scale, int op_dtype, const DropArgs& drop, int only_row0, hipStream_t s);
 int ofx_launch_drop_rows(float* x, int rows, int cols, const DropArgs& d, hipStream_t s);
-int ofx_launch_focal_loss(const float* logits, const float* labels, int B, float alpha, float gamma, float upstream, float* loss, float* dlogits, hipStream_t s);
+int ofx_launch_focal_loss(const float* logits, const float* labels, int B, float alpha, float gamma, float upstream, float* loss, float* dlogits, hipStream_t s,
+                          int reduction = 1, float* per_elem = nullptr);
 int ofx_launch_cp_head_bwd(const float* dlogits, const float* w_or_rows, const int* cu, float* dX, void* dXb, float* db, int B, int D, int op_dtype,
                            const DropArgs& head, const DropArgs& below, hipStream_t s, int accumulate = 0);
 int ofx_launch_fitb(const float* y, const float* cand, int B, int C, int D, int64_t* idx, float* dist, hipStream_t s);
@@ -197,35 +198,20 @@ extern "C" void ofx_destroy(ofx_handle* h) {
 // The ~60 small fp32 tensors of a pack (biases, LayerNorm parameters, tokens) travel in ONE kernel launch instead of one
 // hipMemcpyAsync each: training re-packs after every optimizer step, and 60 x 3 us of copy launches were 0.2 ms of a 4 ms step.
 // Entries are collected while a CopyBatch is active on this thread and flushed at the end of the pack call.
-int ofx_launch_multi_copy(const void* table_dev, int n, hipStream_t s);
+int ofx_launch_multi_copy(const void* table_host, int n, hipStream_t s);
+int ofx_launch_fill_f32(float* p, size_t n, float v, hipStream_t s);
 namespace {
 struct CopyEntry { const float* src; float* dst; long long n; };
 struct CopyBatch;
 thread_local CopyBatch* g_copy_batch = nullptr;
-struct CopyStage { char* host = nullptr; char* dev = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; std::mutex mu; };
-CopyStage g_copy_stage;
 struct CopyBatch {
     std::vector<CopyEntry> e;
     CopyBatch() { g_copy_batch = this; }
     ~CopyBatch() { g_copy_batch = nullptr; }
-    int flush(hipStream_t s) {
+    int flush(hipStream_t s) {          // the table rides in the kernel arguments: nothing is staged, nothing is waited for
         g_copy_batch = nullptr;
         if (e.empty()) return OFX_OK;
-        std::lock_guard<std::mutex> lk(g_copy_stage.mu);
-        const size_t nb = e.size() * sizeof(CopyEntry);
-        if (!g_copy_stage.ev) OFX_HIP(hipEventCreateWithFlags(&g_copy_stage.ev, hipEventDisableTiming));
-        else OFX_HIP(hipEventSynchronize(g_copy_stage.ev));           // the previous flush has consumed the staging area
-        if (g_copy_stage.cap < nb) {
-            if (g_copy_stage.host) { (void)hipHostFree(g_copy_stage.host); (void)hipFree(g_copy_stage.dev); }
-            g_copy_stage.cap = nb * 2;
-            OFX_HIP(hipHostMalloc((void**)&g_copy_stage.host, g_copy_stage.cap, hipHostMallocDefault));
-            OFX_HIP(hipMalloc((void**)&g_copy_stage.dev, g_copy_stage.cap));
-        }
-        memcpy(g_copy_stage.host, e.data(), nb);
-        OFX_HIP(hipMemcpyAsync(g_copy_stage.dev, g_copy_stage.host, nb, hipMemcpyHostToDevice, s));
-        const int rc = ofx_launch_multi_copy(g_copy_stage.dev, (int)e.size(), s);
-        OFX_HIP(hipEventRecord(g_copy_stage.ev, s));
-        return rc;
+        return ofx_launch_multi_copy(e.data(), (int)e.size(), s);
     }
 };
 }  // namespace
@@ -1104,9 +1090,7 @@ static int set_train_bwd_core(ofx_handle* h, void* tape_mem, size_t tape_bytes, 
 extern "C" int ofx_dropout_mask(float dropout_p, unsigned seed, int site, int rows, int cols, float* out, ofx_stream stream) {
     OFX_REQUIRE(out && rows > 0 && cols > 0 && dropout_p >= 0.f && dropout_p < 1.f, OFX_EINVAL, "dropout_mask: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    std::vector<float> ones((size_t)rows * cols, 1.0f);
-    OFX_HIP(hipMemcpyAsync(out, ones.data(), ones.size() * 4, hipMemcpyHostToDevice, s));
-    OFX_HIP(hipStreamSynchronize(s));
+    TRY(ofx_launch_fill_f32(out, (size_t)rows * cols, 1.0f, s));
     return ofx_launch_drop_rows(out, rows, cols, make_drop(dropout_p, seed, (unsigned)site), s);
 }
 
@@ -1114,6 +1098,12 @@ extern "C" int ofx_focal_loss(const float* logits, const float* labels, int B, f
                               ofx_stream stream) {
     OFX_REQUIRE(logits && labels && B > 0, OFX_EINVAL, "focal_loss: bad argument");
     return ofx_launch_focal_loss(logits, labels, B, alpha, gamma, upstream, loss, dlogits, (hipStream_t)stream);
+}
+extern "C" int ofx_focal_loss_ex(const float* logits, const float* labels, int B, float alpha, float gamma, float upstream, int reduction, float* loss,
+                                 float* per_elem, float* dlogits, ofx_stream stream) {
+    OFX_REQUIRE(logits && labels && B > 0 && reduction >= 0 && reduction <= 2, OFX_EINVAL, "focal_loss_ex: bad argument");
+    OFX_REQUIRE(reduction != 0 || per_elem, OFX_EINVAL, "focal_loss_ex: reduction 'none' needs per_elem");
+    return ofx_launch_focal_loss(logits, labels, B, alpha, gamma, upstream, loss, dlogits, (hipStream_t)stream, reduction, per_elem);
 }
 
 // ------------------------------------------------------------------------------------- tuning
@@ -1140,6 +1130,12 @@ extern "C" int ofx_tune(int knob, int value) {
 extern "C" int ofx_gemm(const void* A, const void* W, void* C, const float* bias, const float* resid, int M, int N, int K,
                         int lda, int ldc, int ldr, int act, int out_kind, int op_dtype, ofx_stream stream) {
     GemmArgs g{}; g.A = A; g.W = W; g.C = C; g.bias = bias; g.resid = resid; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc;
+    g.ldr = ldr; g.act = act; g.out_kind = out_kind;
+    return ofx_launch_gemm(g, op_dtype, (hipStream_t)stream);
+}
+extern "C" int ofx_gemm_w2(const void* A, const void* W2, void* C, const float* bias, const float* resid, int M, int N, int K,
+                           int lda, int ldc, int ldr, int act, int out_kind, int op_dtype, ofx_stream stream) {
+    GemmArgs g{}; g.A = A; g.W = W2; g.C = C; g.bias = bias; g.resid = resid; g.M = M; g.N = N; g.K = 2 * K; g.a_wrap = K; g.lda = lda; g.ldc = ldc;
     g.ldr = ldr; g.act = act; g.out_kind = out_kind;
     return ofx_launch_gemm(g, op_dtype, (hipStream_t)stream);
 }

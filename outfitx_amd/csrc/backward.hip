@@ -239,10 +239,13 @@ __global__ __launch_bounds__(64) void set_attention_bwd_kernel(SetBwdK a) {
 // ---- heads and loss
 // FocalLoss (mean) forward + dlogits: ce = BCEWithLogits, p = sigmoid, p_t = p y + (1-p)(1-y), a_t = a y + (1-a)(1-y),
 // loss_i = a_t ce (1-p_t)^g.  One block.
+// reduction (focal_loss.py:36-41): 1 mean (loss and gradient / B), 2 sum, 0 none (`per_elem` receives the B unreduced losses and
+// dlogits the per-element derivative; `loss` then still gets their sum)
 __global__ __launch_bounds__(256) void focal_loss_kernel(const float* logits, const float* labels, int B, float alpha, float gamma, float up,
-                                                         float* loss, float* dlogits) {
+                                                         float* loss, float* dlogits, int reduction, float* per_elem) {
     __shared__ float red[256];
     float acc = 0.f;
+    const float inv = reduction == 1 ? 1.0f / B : 1.0f;
     for (int i = threadIdx.x; i < B; i += 256) {
         const float x = logits[i], y = labels[i];
         const float ce = fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
@@ -250,17 +253,18 @@ __global__ __launch_bounds__(256) void focal_loss_kernel(const float* logits, co
         const float pt = p * y + (1.f - p) * (1.f - y), at = alpha * y + (1.f - alpha) * (1.f - y);
         const float om = 1.f - pt, mod = powf(fmaxf(om, 0.f), gamma);
         acc += at * ce * mod;
+        if (per_elem) per_elem[i] = at * ce * mod;
         if (dlogits) {
             // d ce/dx = p - y ; d pt/dx = p(1-p)(2y-1) ; d mod/dx = -g (1-pt)^(g-1) d pt/dx
             const float dpt = p * (1.f - p) * (2.f * y - 1.f);
             const float dmod = om > 0.f ? -gamma * powf(om, gamma - 1.f) * dpt : 0.f;
-            dlogits[i] = up * at * ((p - y) * mod + ce * dmod) / B;
+            dlogits[i] = up * at * ((p - y) * mod + ce * dmod) * inv;
         }
     }
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-    if (threadIdx.x == 0 && loss) *loss = red[0] / B;
+    if (threadIdx.x == 0 && loss) *loss = red[0] * inv;
 }
 
 
@@ -390,8 +394,9 @@ int ofx_launch_set_attention_bwd(const void* qkv, const float* d_o, void* dqkv, 
     return OFX_OK;
 }
 
-int ofx_launch_focal_loss(const float* logits, const float* labels, int B, float alpha, float gamma, float upstream, float* loss, float* dlogits, hipStream_t s) {
-    hipLaunchKernelGGL(focal_loss_kernel, dim3(1), dim3(256), 0, s, logits, labels, B, alpha, gamma, upstream, loss, dlogits);
+int ofx_launch_focal_loss(const float* logits, const float* labels, int B, float alpha, float gamma, float upstream, float* loss, float* dlogits, hipStream_t s,
+                          int reduction, float* per_elem) {
+    hipLaunchKernelGGL(focal_loss_kernel, dim3(1), dim3(256), 0, s, logits, labels, B, alpha, gamma, upstream, loss, dlogits, reduction, per_elem);
     BWD_CHECK();
     return OFX_OK;
 }

@@ -80,9 +80,9 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
     auto issue = [&](int kt, int stage) {
         if (ABL == 1) return;
         OFX_LDS char* base = lds + stage * STAGE_T;
-        const size_t koff = (size_t)kt * BK * 2;
+        const size_t koff = (size_t)kt * BK * 2, koff_a = (size_t)(kt % p.ka_tiles) * BK * 2;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) glds16(a_src[i] + koff, base + a_dst + i * 1024);
+        for (int i = 0; i < MT; ++i) glds16(a_src[i] + koff_a, base + a_dst + i * 1024);
 #pragma unroll
         for (int i = 0; i < 4; ++i) glds16(w_src[i] + koff, base + w_dst + i * 1024);
     };
@@ -197,13 +197,15 @@ int g_gemm_ablate = 0;    // diagnostics only (tools/gemm_bench.py)
 unsigned long long* g_gemm_dbg = nullptr;   // diagnostics only
 int g_gemm_pref = 2;      // short-K big GEMMs: 0 -> 256x128 kernel, 1 -> 256x256, 2 -> 256x256 ping-pong
 int g_gemm_skew = 0;      // start skew of the second co-resident block (x 8128 cycles), 256x128 kernel only
-int g_gemm_kernel = 0;    // 0 auto, 1 force 128x128, 2 force 256x256 (8 waves, 2 stages), 3 force 256x128 (4 waves, register-resident k-tile), 4 force 256x256 ping-pong
+int g_gemm_kernel = 0;    // 0 auto, 1 force 128x128, 2 force 256x256 (8 waves, 2 stages), 3 force 256x128 (4 waves, register-resident k-tile), 4 force 256x256 ping-pong, 6 force the dual-weight 256x256 kernel for split weights
 
 int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
     OFX_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, OFX_ESHAPE, "gemm: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
     OFX_REQUIRE(g.N % BN == 0, OFX_ESHAPE, "gemm: N=%d must be a multiple of %d (pad the weight at pack time)", g.N, BN);
     OFX_REQUIRE(g.K % BK == 0, OFX_ESHAPE, "gemm: K=%d must be a multiple of %d", g.K, BK);
-    OFX_REQUIRE(g.lda >= g.K && g.lda % 8 == 0, OFX_ESHAPE, "gemm: lda=%d must be >= K and a multiple of 8", g.lda);
+    OFX_REQUIRE(g.a_wrap == 0 || (g.a_wrap > 0 && g.a_wrap % BK == 0 && g.K % g.a_wrap == 0), OFX_ESHAPE, "gemm: a_wrap=%d must be a multiple of %d dividing K=%d", g.a_wrap, BK, g.K);
+    const int ka = g.a_wrap ? g.a_wrap : g.K;
+    OFX_REQUIRE(g.lda >= ka && g.lda % 8 == 0, OFX_ESHAPE, "gemm: lda=%d must be >= K and a multiple of 8", g.lda);
     OFX_REQUIRE(g.ldc % (g.out_kind == 0 ? 4 : 8) == 0 && g.ldc >= (g.out_kind == 2 ? 3 * g.N : g.N), OFX_ESHAPE, "gemm: bad ldc=%d", g.ldc);
     OFX_REQUIRE(!g.resid || (g.ldr % 4 == 0 && g.ldr >= g.N), OFX_ESHAPE, "gemm: bad ldr=%d", g.ldr);
     OFX_REQUIRE(((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.W % 16 == 0) && ((uintptr_t)g.C % 16 == 0), OFX_EINVAL,
@@ -214,6 +216,7 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
 #endif
     KArgs k;
     k.A = (const char*)g.A; k.W = (const char*)g.W; k.C = (char*)g.C; k.bias = g.bias; k.resid = g.resid; k.aux_out = g.aux_out; k.m_dev = g.m_dev; k.dbg = g_gemm_dbg; k.skew = g_gemm_skew; k.splits = 1; k.slab = nullptr; k.m_slab = g.M; k.kt_per_split = 0;
+    k.ka_tiles = ka / BK;
     k.M = g.M; k.N = g.N; k.K = g.K; k.lda = g.lda; k.ldc = g.ldc; k.ldr = g.ldr; k.act = g.act; k.out_kind = g.out_kind; k.drop = g.drop; k.n_valid = g.N;
     k.xb_out = (char*)g.xb_out; k.stat_part = g.stat_part; k.row_stat = g.row_stat; k.col_sum = g.col_sum; k.stat_ld = g.stat_ld > 0 ? g.stat_ld : 1; k.xlo = (char*)g.xlo;
     OFX_REQUIRE(!g.xlo || (g.xb_out && g.stat_part), OFX_EINVAL, "gemm: xlo needs the LayerNorm-fold producer outputs");
@@ -239,7 +242,10 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
     }));
     // big tiles when they still fill the chip, else the 128^2 kernel
     int kind = g_gemm_kernel;
-    if (kind == 0) {   // measured crossover points (tools/gemm_bench.py, profiles/r01_gemm_variants.txt)
+    if (g.a_wrap) {        // split weights: the dual-weight 256x256 kernel when its grid fills the chip, else the 128x128 kernel with a wrapping A index
+        const long t2 = (long)((g.M + 255) / 256) * (g.N / 256);
+        kind = (g.K == 2 * g.a_wrap && g.a_wrap % 32 == 0 && g.N % 256 == 0 && (t2 >= 256 || g_gemm_kernel == 6) && g_gemm_kernel != 1) ? 6 : 1;
+    } else if (kind == 0) {   // measured crossover points (tools/gemm_bench.py, profiles/r01_gemm_variants.txt)
         const long t2 = (long)((g.M + 255) / 256) * (g.N / 256), t3 = (long)((g.M + 255) / 256) * (g.N / 128);
         if (g.N % 256 == 0 && t2 >= 1024 && (g.K > 1024 || g_gemm_pref >= 1)) kind = g_gemm_pref == 2 && g.K <= 1024 ? 4 : 2;   // 256x256, one block per CU
         else if (g.N % 128 == 0 && t3 >= 512) kind = 3;                    // short K / mid-size M: 256x128, two blocks per CU
@@ -248,10 +254,11 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
     if ((kind == 2 || kind == 4) && g.N % 256) kind = 1;
     if (kind == 5 && g.N % 128) kind = 1;
     ProfScope prof(PROF_GEMM, s, 2.0 * g.M * g.N * g.K, true);      // events ride on the launches (OFX_PLAUNCH)
-    if (kind == 2 || kind == 3 || kind == 4) {
+    if (kind == 2 || kind == 3 || kind == 4 || kind == 6) {
         k.group_m = g_gemm_group_m > 0 ? g_gemm_group_m : (kind == 3 ? 4 : 8);
         int rc;
-        if (kind == 4) rc = ofx_gemm_launch_pp(&k, op_dtype, g.M, g.N, s);
+        if (kind == 6) rc = ofx_gemm_launch_w2(&k, op_dtype, g.M, g.N, s);
+        else if (kind == 4) rc = ofx_gemm_launch_pp(&k, op_dtype, g.M, g.N, s);
         else rc = ofx_gemm_launch_big(&k, kind, g_gemm_ablate, op_dtype, g.M, g.N, s);
         if (rc != OFX_OK) return rc;
     } else {

@@ -32,6 +32,7 @@ struct KArgs {
     DropArgs drop;
     char* xb_out; float* stat_part; const float* row_stat; const float* col_sum; int stat_ld; char* xlo;   // LayerNorm folding (GemmArgs)
     int n_valid;                // columns >= n_valid are computed but not stored (fp32 outputs of the TN kernel; = N elsewhere)
+    int ka_tiles;               // A's k-tile index wraps modulo ka_tiles (K-concatenated weights against ONE copy of A: GemmArgs::a_wrap); = K / BK otherwise
 };
 
 __device__ __forceinline__ void glds16(const char* g, OFX_LDS char* l) {
@@ -395,3 +396,4 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(KArgs p) {
 // launchers implemented by the other translation units (KArgs travels as an opaque pointer: each unit sees the same definition)
 int ofx_gemm_launch_big(void* kargs, int kind, int ablate, int op_dtype, int M, int N, hipStream_t s);
 int ofx_gemm_launch_pp(void* kargs, int op_dtype, int M, int N, hipStream_t s);
+int ofx_gemm_launch_w2(void* kargs, int op_dtype, int M, int N, hipStream_t s);

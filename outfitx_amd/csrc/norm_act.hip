@@ -2,6 +2,7 @@
 // ViT patchify / embedding assembly, CLIP text embedding, L2-normalise+concat fuser, set build
 // (prefix token + pad-free compaction), row-0 gather, CP head.  One wave per row, 16-byte
 // accesses, fp32 statistics.  Reference arithmetic: SURVEY.md Appendix A items 1-5.
+#include <algorithm>
 #include "ofx_common.h"
 
 namespace {
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* src, T* dst
                                                        int K_dst, int ld_src, int mode) {
     const int chunks = K_dst / 4;
     const size_t total = (size_t)rows_dst * chunks;
-    const int ld = mode ? 3 * K_dst : K_dst;
+    const int ld = mode == 3 ? 2 * K_dst : (mode ? 3 * K_dst : K_dst);      // mode 3: split weights [hi | lo] (GemmArgs::a_wrap)
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / chunks), c = (int)(i % chunks) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* src, T* dst
         *(v4*)p = hi;
         if (mode == 1) { *(v4*)(p + K_dst) = lo; *(v4*)(p + 2 * K_dst) = hi; }
         if (mode == 2) { *(v4*)(p + K_dst) = hi; *(v4*)(p + 2 * K_dst) = lo; }
+        if (mode == 3) *(v4*)(p + K_dst) = lo;
     }
 }
 }  // namespace
@@ -439,9 +441,11 @@ __global__ __launch_bounds__(256) void fold_pack_kernel(const float* Wsrc, const
 }
 
 // table[i] = {src, dst, n floats}: block i copies entry i (pack time: every small fp32 tensor of a model in one launch)
+// The table travels BY VALUE in the kernel arguments (<= 128 entries = 3 KiB per launch): no staging buffer, no host-side wait.
 struct MultiCopyEntry { const float* src; float* dst; long long n; };
-__global__ __launch_bounds__(256) void multi_copy_kernel(const MultiCopyEntry* table) {
-    const MultiCopyEntry e = table[blockIdx.x];            // blockIdx.y strides over the entry (the text tower's 101 MB token table is one entry)
+struct MultiCopyTable { MultiCopyEntry e[128]; };
+__global__ __launch_bounds__(256) void multi_copy_kernel(const MultiCopyTable table) {
+    const MultiCopyEntry e = table.e[blockIdx.x];          // blockIdx.y strides over the entry (the text tower's 101 MB token table is one entry)
     for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < e.n; i += (long long)gridDim.y * 256) e.dst[i] = e.src[i];
 }
 
@@ -558,8 +562,25 @@ int ofx_launch_fold_pack(const float* Wsrc, const float* gamma, const float* bet
     OFX_LAUNCH_CHECK();
     return OFX_OK;
 }
-int ofx_launch_multi_copy(const void* table_dev, int n, hipStream_t s) {
-    hipLaunchKernelGGL(multi_copy_kernel, dim3(n, 64), dim3(256), 0, s, (const MultiCopyEntry*)table_dev);
+int ofx_launch_multi_copy(const void* table_host, int n, hipStream_t s) {
+    const MultiCopyEntry* src = (const MultiCopyEntry*)table_host;
+    for (int i0 = 0; i0 < n; i0 += 128) {
+        MultiCopyTable t;
+        const int m = n - i0 < 128 ? n - i0 : 128;
+        for (int i = 0; i < m; ++i) t.e[i] = src[i0 + i];
+        hipLaunchKernelGGL(multi_copy_kernel, dim3(m, 64), dim3(256), 0, s, t);
+    }
+    OFX_LAUNCH_CHECK();
+    return OFX_OK;
+}
+namespace {
+__global__ __launch_bounds__(256) void fill_f32_kernel(float* p, size_t n, float v) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
+}
+}  // namespace
+int ofx_launch_fill_f32(float* p, size_t n, float v, hipStream_t s) {
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(fill_f32_kernel, dim3(grid < 1 ? 1 : grid), dim3(256), 0, s, p, n, v);
     OFX_LAUNCH_CHECK();
     return OFX_OK;
 }

@@ -238,6 +238,9 @@ struct GemmArgs {
     void* xlo = nullptr;               // producer with xb_out: the residual stream is the operand-type pair (xb_out, xlo), updated in place;
                                        // `resid` / `C` are then unused (no fp32 copy of the stream exists)
     const float* col_sum = nullptr;    // [N] column sums of the (rounded) gamma-scaled weight rows
+    // ---- split weights against ONE copy of A ("W2"): W = [N, K] with K = 2 a_wrap, row n = [hi(a_wrap) | lo(a_wrap)]; A is
+    // [M, a_wrap] and its k index wraps, so C = A . (hi + lo)^T: ~22 significant weight bits for two MFMA products
+    int a_wrap = 0;
 };
 int ofx_launch_gemm(const GemmArgs& g, int op_dtype /*OFX_BF16|OFX_F16*/, hipStream_t s);
 int ofx_gemm_splitk_plan(int M, int N, int K);

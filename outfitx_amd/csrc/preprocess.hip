@@ -224,11 +224,21 @@ const std::vector<int>& cached_plan(int in_size, int out_size, int crop0, int n_
     return it->second;
 }
 
-// One pinned host staging area for the per-batch plan; an event marks when the previous batch's copies have left it.
-struct PinnedStage {
-    char* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; std::mutex mu;
+// Pinned host staging for the per-batch plan (descriptors + coefficient tables, a few KB): a ring of 4 slots PER DEVICE, each with
+// an event that marks when its copy has left it.  A call waits on the host only when the copy issued four calls earlier on the same
+// device is still in flight (documented in include/ofx.h; every other entry point is wait-free).
+struct PinnedRing {
+    struct Slot { char* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; };
+    Slot slot[4]; int next = 0; std::mutex mu;
 };
-PinnedStage g_stage;
+std::mutex g_rings_mu;
+std::map<int, PinnedRing> g_rings;
+PinnedRing& ring_for_current_device() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_rings_mu);
+    return g_rings[dev];
+}
 
 struct Batch {
     std::vector<ImgDesc> descs;
@@ -293,20 +303,23 @@ int ofx_preprocess_to(const uint8_t* src, const long long* offsets, const int* h
     uint8_t* d_inter = (uint8_t*)bump.take<char>(b.inter_bytes);
     OFX_REQUIRE(bump.ok, OFX_EWORKSPACE, "clip_preprocess: workspace %zu < %zu bytes", ws_bytes, bump.off);
     {
-        std::lock_guard<std::mutex> lk(g_stage.mu);
+        PinnedRing& ring = ring_for_current_device();
+        std::lock_guard<std::mutex> lk(ring.mu);
+        PinnedRing::Slot& st = ring.slot[ring.next];
+        ring.next = (ring.next + 1) & 3;
         const size_t nd = align_up(b.descs.size() * sizeof(ImgDesc), 256), nb = b.blob.size() * 4;
-        if (!g_stage.ev) OFX_HIP(hipEventCreateWithFlags(&g_stage.ev, hipEventDisableTiming));
-        else OFX_HIP(hipEventSynchronize(g_stage.ev));
-        if (g_stage.cap < nd + nb) {
-            if (g_stage.p) (void)hipHostFree(g_stage.p);
-            g_stage.cap = (nd + nb) * 2;
-            OFX_HIP(hipHostMalloc((void**)&g_stage.p, g_stage.cap, hipHostMallocDefault));
+        if (!st.ev) OFX_HIP(hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+        else if (hipEventQuery(st.ev) != hipSuccess) OFX_HIP(hipEventSynchronize(st.ev));      // only when 4 earlier plans are still in flight
+        if (st.cap < nd + nb) {
+            if (st.p) (void)hipHostFree(st.p);
+            st.cap = (nd + nb) * 2;
+            OFX_HIP(hipHostMalloc((void**)&st.p, st.cap, hipHostMallocDefault));
         }
-        memcpy(g_stage.p, b.descs.data(), b.descs.size() * sizeof(ImgDesc));
-        memcpy(g_stage.p + nd, b.blob.data(), nb);
-        OFX_HIP(hipMemcpyAsync(d_desc, g_stage.p, b.descs.size() * sizeof(ImgDesc), hipMemcpyHostToDevice, s));
-        OFX_HIP(hipMemcpyAsync(d_blob, g_stage.p + nd, nb, hipMemcpyHostToDevice, s));
-        OFX_HIP(hipEventRecord(g_stage.ev, s));
+        memcpy(st.p, b.descs.data(), b.descs.size() * sizeof(ImgDesc));
+        memcpy(st.p + nd, b.blob.data(), nb);
+        OFX_HIP(hipMemcpyAsync(d_desc, st.p, b.descs.size() * sizeof(ImgDesc), hipMemcpyHostToDevice, s));
+        OFX_HIP(hipMemcpyAsync(d_blob, st.p + nd, nb, hipMemcpyHostToDevice, s));
+        OFX_HIP(hipEventRecord(st.ev, s));
     }
     ProfScope prof(PROF_OTHER, s);
     const dim3 gh((b.max_rows + ROWS_H - 1) / ROWS_H, N);

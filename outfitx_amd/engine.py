@@ -292,12 +292,14 @@ class Engine:
         if stage is None or stage.numel() < total + 4:
             stage = torch.empty(int(total * 1.25) + 4096, dtype=torch.uint8).pin_memory()
             self._px_stage = stage
-        else:
-            torch.cuda.current_stream(self.device).synchronize()      # the previous batch's copy must have left the staging buffer
+        elif getattr(self, "_px_event", None) is not None:
+            self._px_event.synchronize()      # only the previous batch's H2D copy (not the kernels queued behind it) must have left the staging buffer
         buf = stage.numpy()
         for a, o, n in zip(arrs, offs, nbytes):
             buf[o:o + n] = a.reshape(-1)
         src = stage[:total + 4].to(self.device, non_blocking=True)    # + 4: RGB pixels are fetched as unaligned dwords
+        self._px_event = torch.cuda.Event()
+        self._px_event.record(torch.cuda.current_stream(self.device))
         self._keep_px = src
         return src, offs, hs, ws_
 
@@ -396,19 +398,26 @@ def dropout_mask(p: float, seed: int, site: int, rows: int, cols: int, device) -
     return out
 
 
-def focal_loss(logits: torch.Tensor, labels: torch.Tensor, alpha: float, gamma: float, upstream: float = 1.0, need_grad: bool = True):
-    """FocalLoss(alpha, gamma, 'mean') (src/losses/focal_loss.py:23-41) and upstream * d loss / d logits, one kernel."""
+FOCAL_REDUCTIONS = {"none": 0, "mean": 1, "sum": 2}
+
+
+def focal_loss(logits: torch.Tensor, labels: torch.Tensor, alpha: float, gamma: float, upstream: float = 1.0, need_grad: bool = True,
+               reduction: str = "mean"):
+    """FocalLoss(alpha, gamma, reduction) (src/losses/focal_loss.py:23-41) and upstream * d loss / d logits, one kernel.
+    'mean' / 'sum' return a 0-d loss; 'none' returns the [B] unreduced losses (dlogits is then the per-element derivative)."""
     lib = L.load()
     dev = logits.device
     if dev.type != "cuda":
         raise L.OfxError("focal_loss needs HIP tensors; there is no CPU path")
     y = _f32c(logits.reshape(-1), dev); t = _f32c(labels.reshape(-1), dev)
+    red = FOCAL_REDUCTIONS[reduction]
     loss = torch.empty((), dtype=torch.float32, device=dev)
+    per = torch.empty_like(y) if red == 0 else None
     dl = torch.empty_like(y) if need_grad else None
     with torch.cuda.device(dev):
-        L.check(lib.ofx_focal_loss(_ptr(y), _ptr(t), y.numel(), float(alpha), float(gamma), float(upstream), _ptr(loss), _ptr(dl),
-                                   _stream(dev)), "ofx_focal_loss")
-    return loss, dl
+        L.check(lib.ofx_focal_loss_ex(_ptr(y), _ptr(t), y.numel(), float(alpha), float(gamma), float(upstream), red, _ptr(loss), _ptr(per),
+                                      _ptr(dl), _stream(dev)), "ofx_focal_loss_ex")
+    return (per if red == 0 else loss), dl
 
 
 def topk_merge(idx_parts: torch.Tensor, dist_parts: torch.Tensor):

@@ -1,5 +1,6 @@
 """FocalLoss — drop-in for the reference's `src.losses.FocalLoss` (src/losses/focal_loss.py:8-41), fused: loss value and
-d loss / d logits come from ONE kernel (ofx_focal_loss) instead of ~12 eager elementwise launches.  Used by the CP
+d loss / d logits come from ONE kernel (ofx_focal_loss_ex; reduction 'mean' | 'sum' | 'none' as focal_loss.py:36-41) instead of
+~12 eager elementwise launches.  Used by the CP
 trainer as `FocalLoss(alpha=0.75, gamma=2, reduction='mean')` (compatibility_prediction_trainer.py:369-370).
 No CPU path: HIP tensors only."""
 from __future__ import annotations
@@ -12,16 +13,16 @@ from .engine import focal_loss
 
 class _FocalFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y_hat, y_true, alpha, gamma):
-        loss, dl = focal_loss(y_hat, y_true, alpha, gamma, 1.0, need_grad=y_hat.requires_grad)
+    def forward(ctx, y_hat, y_true, alpha, gamma, reduction):
+        loss, dl = focal_loss(y_hat, y_true, alpha, gamma, 1.0, need_grad=y_hat.requires_grad, reduction=reduction)
         ctx.save_for_backward(dl)
         ctx.shape = y_hat.shape
-        return loss
+        return loss.view(y_hat.shape) if reduction == "none" else loss
 
     @staticmethod
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
-        return (dl * g).view(ctx.shape), None, None, None
+        return (dl * g.reshape(-1) if g.dim() else dl * g).view(ctx.shape), None, None, None, None
 
 
 class FocalLoss(nn.Module):
@@ -30,12 +31,10 @@ class FocalLoss(nn.Module):
         assert gamma >= 0, f"Invalid Value for arg 'gamma': '{gamma}' \n Gamma should be non-negative"
         assert 0 <= alpha <= 1, f"Invalid Value for arg 'alpha': '{alpha}' \n Alpha should be in range [0, 1]"
         assert reduction in ["none", "mean", "sum"], f"Invalid Value for arg 'reduction': '{reduction}'"
-        if reduction != "mean":
-            raise NotImplementedError("only reduction='mean' is fused (the only mode the reference's trainers use)")
         self.gamma, self.alpha, self.reduction = gamma, alpha, reduction
 
     def forward(self, y_hat: torch.Tensor, y_true: torch.Tensor) -> torch.Tensor:
-        return _FocalFn.apply(y_hat, y_true, float(self.alpha), float(self.gamma))
+        return _FocalFn.apply(y_hat, y_true, float(self.alpha), float(self.gamma), self.reduction)
 
 
 class SetWiseRankingLoss(nn.Module):

@@ -5,8 +5,8 @@ backend 'nccl' (= RCCL over xGMI on ROCm) or 'gloo' (CPU tests).
   replicated, and the forward needs NO collective.  `shard_range` gives a rank's
   slice; `gather_scores` is the optional final all-gather of [B/N] logits (4 KB).
 * CIR retrieval (BASELINE config 4): the POOL is row-sharded.  Every rank scores all queries
-  against its shard (fp32-exact distances + local top-k), then ONE all-gather of the per-shard
-  (dist, global index) candidate lists — nq*k*12 B per rank, 600 KB at 1000x50, latency-bound on
+  against its shard (fp32-exact distances + local top-k), then ONE `all_gather_into_tensor` of the
+  per-shard (dist, global index) candidate lists, packed into one byte record — nq*k*12 B per rank, 600 KB at 1000x50, latency-bound on
   the fully connected xGMI mesh — and a local merge with a deterministic tie-break (smaller global
   index).  This step has no reference call site: the reference scores CIR on one GPU
   (complementary_item_retrieval_trainer.py:240-249); results are identical to the unsharded call.
@@ -48,11 +48,17 @@ def sharded_topk(queries: torch.Tensor, pool_shard: torch.Tensor, k: int, shard_
     idx, dst = local_topk(queries, pool_shard, k, shard_base)
     if world == 1:
         return idx, dst
-    idx_all = torch.empty((world,) + tuple(idx.shape), dtype=idx.dtype, device=idx.device)
-    dst_all = torch.empty((world,) + tuple(dst.shape), dtype=dst.dtype, device=dst.device)
-    # list-of-views form: accepted by both RCCL and gloo (the payload is ~600 KB, latency-bound either way)
-    dist.all_gather([idx_all[r] for r in range(world)], idx.contiguous(), group=group)
-    dist.all_gather([dst_all[r] for r in range(world)], dst.contiguous(), group=group)
+    # ONE collective: the rank's (global index int64, distance fp32) lists travel as one packed byte record
+    # [nq*k*8 B of indices | nq*k*4 B of distances] (600 KB at 1000 x 50; latency-bound on the xGMI mesh, so one launch, not two)
+    nb_i, nb_d = idx.numel() * 8, dst.numel() * 4
+    rec = torch.empty(nb_i + nb_d, dtype=torch.uint8, device=idx.device)
+    rec[:nb_i] = idx.contiguous().view(torch.uint8).reshape(-1)
+    rec[nb_i:] = dst.contiguous().view(torch.uint8).reshape(-1)
+    flat = torch.empty(world * (nb_i + nb_d), dtype=torch.uint8, device=idx.device)     # 1-D: the form RCCL and gloo both accept
+    dist.all_gather_into_tensor(flat, rec, group=group)
+    allrec = flat.view(world, nb_i + nb_d)
+    idx_all = allrec[:, :nb_i].contiguous().view(torch.int64).view((world,) + tuple(idx.shape))
+    dst_all = allrec[:, nb_i:].contiguous().view(torch.float32).view((world,) + tuple(dst.shape))
     return merge(idx_all, dst_all)
 
 

@@ -53,6 +53,41 @@ def test_gemm_plain(dt, M, N, K):
     assert rel_err(out.cpu().numpy(), want) < 2e-5
 
 
+def _split_w(Wf, dt):
+    """fp32 [N, K] -> ([N, 2K] operand-type [hi | lo] via ofx_convert mode 3, float64 value hi + lo)."""
+    N, K = Wf.shape
+    src = dev(Wf)
+    td = torch.bfloat16 if dt == "bf16" else torch.float16
+    W2 = torch.empty(N, 2 * K, dtype=td, device="cuda")
+    L.check(L.load().ofx_convert(src.data_ptr(), W2.data_ptr(), N, K, 3, DT[dt], stream()))
+    hi = src.to(td)
+    lo = (src - hi.float()).to(td)
+    assert torch.equal(W2[:, :K], hi) and torch.equal(W2[:, K:], lo)
+    return W2, (hi.double() + lo.double()).cpu().numpy()
+
+
+@pytest.mark.parametrize("force", [0, 6])
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K", [(1, 256, 64), (255, 256, 128), (300, 512, 768), (1000, 768, 3072), (70000, 768, 192)])
+def test_gemm_split_weights(force, dt, M, N, K):
+    """C = A (W_hi + W_lo)^T with one copy of A: the dual-weight 256x256 kernel (forced, and chosen by the dispatcher at M = 70000)
+    and the 128x128 kernel with a wrapping A index; exact arithmetic on the rounded operands, fp32 accumulation."""
+    g = np.random.default_rng(M + 3 * N + K)
+    A = to_op(g.standard_normal((M, K), dtype=np.float32), dt)
+    W2, Wv = _split_w(g.standard_normal((N, K), dtype=np.float32) / np.sqrt(K), dt)
+    bias = dev(g.standard_normal(N, dtype=np.float32))
+    res = dev(g.standard_normal((M, N), dtype=np.float32))
+    out = torch.full((M, N), float("nan"), device="cuda")
+    lib = L.load()
+    lib.ofx_tune(2, force)
+    try:
+        L.check(lib.ofx_gemm_w2(A.data_ptr(), W2.data_ptr(), out.data_ptr(), bias.data_ptr(), res.data_ptr(), M, N, K, K, N, N, 0, 0, DT[dt], stream()))
+    finally:
+        lib.ofx_tune(2, 0)
+    want = A.double().cpu().numpy() @ Wv.T + bias.cpu().numpy() + res.cpu().numpy()
+    assert rel_err(out.cpu().numpy(), want) < 2e-5
+
+
 @pytest.mark.parametrize("kern", [2, 3, 4, 5])
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("M,N,K", [(1, 256, 64), (255, 256, 128), (257, 512, 768), (1000, 768, 3072), (5000, 256, 192)])

@@ -156,6 +156,33 @@ def test_fused_focal_loss_and_gradient_vs_golden_and_torch():
     assert np.abs(x.grad.cpu().numpy() - xr.grad.numpy()).max() <= 1e-6 * np.abs(xr.grad.numpy()).max() + 1e-9
 
 
+@pytest.mark.parametrize("reduction", ["sum", "none"])
+def test_focal_loss_reductions_match_the_reference_composition(reduction):
+    """FocalLoss(reduction='sum'|'none') (focal_loss.py:36-41) - value and gradient vs the reference's composition of torch ops in
+    float64, on the golden logits."""
+    from src.losses import FocalLoss
+    g = golden("aux")
+    x = cu(g["focal_logits"]).requires_grad_(True)
+    y = cu(g["focal_labels"])
+    loss = FocalLoss(alpha=0.75, gamma=2.0, reduction=reduction)(x, y)
+    xr = torch.from_numpy(g["focal_logits"]).double().requires_grad_(True)
+    yr = torch.from_numpy(g["focal_labels"]).double()
+    ce = torch.nn.functional.binary_cross_entropy_with_logits(xr, yr, reduction="none")
+    p = torch.sigmoid(xr)
+    pt = p * yr + (1 - p) * (1 - yr)
+    ref = (0.75 * yr + 0.25 * (1 - yr)) * ce * (1 - pt) ** 2
+    wgt = torch.linspace(0.5, 2.0, xr.numel(), dtype=torch.float64).view(xr.shape)      # a non-uniform upstream gradient
+    if reduction == "sum":
+        ref = ref.sum()
+        assert loss.dim() == 0
+        (loss * 3.0).backward(); (ref * 3.0).backward()
+    else:
+        assert loss.shape == x.shape
+        (loss * wgt.float().to(loss.device)).sum().backward(); (ref * wgt).sum().backward()
+    assert np.abs(loss.detach().cpu().numpy() - ref.detach().numpy()).max() <= 3e-6 * np.abs(ref.detach().numpy()).max() + 1e-7
+    assert np.abs(x.grad.cpu().numpy() - xr.grad.numpy()).max() <= 2e-6 * np.abs(xr.grad.numpy()).max() + 1e-9
+
+
 def test_dropout_masks_are_stateless_and_have_the_right_rate():
     from outfitx_amd.engine import dropout_mask
     if not torch.cuda.is_available():
