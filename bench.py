@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: outfits/sec, CP forward with CLIP ViT-B/32 image + text encode
-(BASELINE.json configs[1]: 256 outfits x 8 items per GPU, 224^2, bf16) on N MI355X.
+(BASELINE.json configs[1]: 256 outfits x 8 items per GPU, 224^2) on N MI355X, in the operand scheme that holds the north star's
+1e-3 parity bound (f16 MFMA operands with split weights / three-product arithmetic where the error budget needs them).
 
 One "step" = one pass of the hot path over one batch: item encoder (ViT-B/32 + text tower + concat
 fuser) -> 6-layer outfit transformer -> CP head, through the drop-in `src.models.OutfitX` API.
@@ -44,18 +45,95 @@ def ot_gemm(n): return 6 * (1 + n) * 16_678_912 + 2 * 1024 * 0
 def ot_attn(n): return 6 * 4 * (1 + n) ** 2 * 1024 + 2 * 1024
 
 
-def cpu_baseline(px, ids, att, mask, n_outfits, items):
-    """The numpy oracle (a port of the reference's CPU path, oracle/np_oracle.py) on a bounded sample of
-    the same workload, executed the way the reference executes it: texts padded to 64 tokens, fp32."""
+def oracle_logits(px, ids, att, mask, n_outfits):
+    """fp32 numpy oracle (oracle/np_oracle.py, pinned to the reference's golden vectors) on the first outfits of the batch, the way
+    the reference executes them (texts padded to 64 tokens): the parity number printed next to the throughput."""
     from oracle import np_oracle as O
-    Wt = synth.outfit_transformer_weights(W_SEED)
-    Wv = synth.vision_weights(W_SEED)
-    Wx = synth.text_weights(W_SEED)
-    t0 = time.perf_counter()
-    emb = O.item_encoder(px[:n_outfits], ids[:n_outfits], att[:n_outfits], Wv, Wx)
-    logits = O.cp_forward(emb, mask[:n_outfits], Wt)
-    dt = time.perf_counter() - t0
-    return logits, dt
+    emb = O.item_encoder(px[:n_outfits], ids[:n_outfits], att[:n_outfits], synth.vision_weights(W_SEED), synth.text_weights(W_SEED))
+    return O.cp_forward(emb, mask[:n_outfits], synth.outfit_transformer_weights(W_SEED))
+
+
+def host_cores():
+    """CPU cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands one job a 16-core
+    share of a 256-thread host; 256 torch threads on that share run several times slower than 16)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1") and float(quota) > 0:
+                n = max(1, min(n, int(-(-float(quota) // period))))
+            break
+        except Exception:
+            continue
+    return n
+
+
+def _log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def _median_ms(fn, warm, iters):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter(); fn(); ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts))
+
+
+def cpu_baseline(px, ids, att, n_items, cfg2_outfits):
+    """our own plain-PyTorch fp32 restatement of the reference's CPU path (oracle/torch_ref.py, pinned to the
+    reference's golden vectors - not the reference's files, which never travel to the GPU box), on this box's host cores,
+    torch.set_num_threads(os.cpu_count()) and 1 thread, warm-up + timed iterations, median.
+      cfg1: _cp_forward (outfit_x.py:120-144) on BASELINE configs[0]: 32 outfits, 8 items padded to 16 (S = 17 as the reference's
+            processor feeds them), 3 warm-up + 10 timed;
+      cfg2: a bounded sample of THIS bench's workload (towers + fuser + CP forward, texts padded to 64 tokens), 1 warm-up + 5 timed.
+    Baseline only: a GPU/CPU ratio says nothing about kernel quality (the roofline fraction does)."""
+    from oracle import torch_ref as T
+    ncpu = os.cpu_count() or 1
+    cores = host_cores()
+    Wt, Wv, Wx = synth.outfit_transformer_weights(W_SEED), synth.vision_weights(W_SEED), synth.text_weights(W_SEED)
+    rs, rv, rt = T.TorchRef(Wt), T.TorchRef(Wv), T.TorchRef(Wx)
+    emb1, mask1 = synth.outfit_batch(1235, 32, 16, 8)
+    emb1, mask1 = torch.from_numpy(emb1), torch.from_numpy(mask1)
+    k = cfg2_outfits
+    pxs, idss, atts = px[:k].cpu(), ids[:k], att[:k]
+    m2 = torch.zeros(k, n_items, dtype=torch.bool)
+    out = {}
+    prev = torch.get_num_threads()
+    with torch.no_grad():
+        # thread count of the "all threads" leg: every core this process may use - unless that over-subscribes a CPU share the
+        # process cannot see (a GPU box gives one job 16 cores of a 256-thread host without a visible cgroup quota): one probe
+        # forward at each candidate, keep the faster; the count used is reported
+        cand, best = sorted({min(ncpu, cores), min(ncpu, cores, 32), min(ncpu, cores, 16)}, reverse=True), None
+        for nt in cand:
+            torch.set_num_threads(nt)
+            rs.cp(emb1[:8], mask1[:8])
+            t0 = time.perf_counter(); rs.cp(emb1, mask1); dt = time.perf_counter() - t0
+            _log(f"cpu baseline: probe {nt} threads: {dt * 1e3:.0f} ms")
+            if best is None or dt < best[1]:
+                best = (nt, dt)
+        for name, nt in (("all_threads", best[0]), ("one_thread", 1)):
+            torch.set_num_threads(nt)
+            _log(f"cpu baseline: cfg1 on {nt} thread(s)")
+            ms1 = _median_ms(lambda: rs.cp(emb1, mask1), 3, 10)
+            out[name] = {"threads": nt, "cfg1": {"outfits": 32, "iters": 10, "warmup": 3, "median_ms": round(ms1, 2), "outfits_per_s": round(32e3 / ms1, 1)}}
+            if name == "all_threads":
+                _log(f"cpu baseline: cfg2 sample of {k} outfits on {nt} thread(s)")
+                ms2 = _median_ms(lambda: rs.cp(T.item_encoder(rv, rt, pxs, idss, atts), m2), 1, 5)
+                out[name]["cfg2_sample"] = {"outfits": k, "iters": 5, "warmup": 1, "median_ms": round(ms2, 1), "outfits_per_s": round(k * 1e3 / ms2, 3)}
+    torch.set_num_threads(prev)
+    a = out["all_threads"]
+    return {"value": a["cfg2_sample"]["outfits_per_s"], "unit": "outfits/s", "cores": a["threads"], "kind": "port",
+            "threads": a["threads"], "host_logical_cpus": ncpu, "iters": 5, "median_ms": a["cfg2_sample"]["median_ms"],
+            "sample": f"{k} outfits x {n_items} items of the same batch ({k * n_items} images 224^2, {k * n_items} texts padded to 64 tokens as the reference feeds "
+                      f"them), plain-PyTorch fp32 restatement (oracle/torch_ref.py), median of 5 after 1 warm-up on {a['threads']} threads",
+            "cfg1_cp_forward_32_outfits": {"all_threads": a["cfg1"], "one_thread": out["one_thread"]["cfg1"],
+                                           "note": "BASELINE configs[0] / BASELINE.md section 3: S = 17 rows as the reference's processor feeds them, 3 warm-up + 10 timed, median"}}
 
 
 def main():
@@ -66,8 +144,11 @@ def main():
     ap.add_argument("--outfits", type=int, default=256, help="outfits per GPU per step")
     ap.add_argument("--items", type=int, default=8)
     ap.add_argument("--precision", default="bf16x3", help="outfit transformer MFMA operand format")
-    ap.add_argument("--tower-precision", default="bf16", help="CLIP towers MFMA operand format (bf16|f16)")
-    ap.add_argument("--cpu-outfits", type=int, default=8, help="sample size of the CPU baseline (0 = skip)")
+    ap.add_argument("--tower-precision", default="f16w2", help="CLIP towers operand scheme: f16w2 (default: f16 operands, split weights on the patch / out-proj / "
+                    "fc2 GEMMs, three-product text tower and projection - meets 1e-3 vs the fp32 oracle) | f16 | bf16 (single product, faster, 5e-4 / 4e-3 at the tower outputs)")
+    ap.add_argument("--cpu-outfits", type=int, default=8, help="outfits of the batch checked against the fp32 oracle (0 = skip the oracle check and the CPU baseline)")
+    ap.add_argument("--cpu-cfg2-outfits", type=int, default=2, help="sample size of the CPU baseline's cfg2 leg")
+    ap.add_argument("--secondary", default="bf16", help="tower scheme of the secondary (non-headline) measurement after the timed region ('' = skip)")
     ap.add_argument("--ln-fold", type=int, default=2, help="2 (product default): towers' LayerNorms folded into the GEMM epilogues and the residual stream kept as a (hi, lo) operand-type pair; 1: folded, fp32 stream; 0: materialised (A/B)")
     a = ap.parse_args()
 
@@ -121,9 +202,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    _log("model packed, inputs resident; warm-up")
     for _ in range(a.warmup):
         out = step()
     fence()
+    _log("timed region")
     lib = L.load()
     # Live roofline sample: HIP events bracket every GEMM launch of ONE timed step (the middle one) on the launch
     # stream.  Bracketing all K steps costs ~1 ms/step of serialisation (246 event markers), so it is sampled.
@@ -137,6 +220,8 @@ def main():
             lib.ofx_profile_enable(0)
     fence()
     elapsed = time.perf_counter() - t0
+    recs = (L.ProfRecord * 4096)()
+    nrec = lib.ofx_profile_records(recs, 4096)              # per-launch records of the sampled step (before read() clears them)
     ms, fl, cnt = (C.c_double * 4)(), (C.c_double * 4)(), (C.c_longlong * 4)()
     L.check(lib.ofx_profile_read(ms, fl, cnt), "ofx_profile_read")
     # one extra, untimed step with every category bracketed: the per-step breakdown
@@ -157,12 +242,34 @@ def main():
         padded_outfit = n * (VIT_GEMM + VIT_ATTN + txt_gemm(64) + txt_attn(64)) + ot_gemm(16) + ot_attn(16)
         gemm_ms, gemm_launches = ms[0], int(cnt[0])
         achieved = alg_gemm_outfit * B / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0   # one sampled step
-        traffic = None        # PMC counters cannot be read inside a timed run: the committed rocprofv3 --pmc pass of this same command
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")) as f:
-                traffic = round(json.load(f)["gemm_hbm_bytes_per_launch"])
-        except Exception:
-            pass
+        executed = fl[0] / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        # per-shape table of the sampled step: shape -> kernel -> launches, us per launch, useful TF/s (2 M N K_logical) and its
+        # fraction of the dense peak, executed TF/s (x kmul: split weights run 2, three-product GEMMs 3 MFMA products per term)
+        KIND = {1: "gemm_128x128_kernel", 2: "gemm_big_kernel<2,4,2>", 3: "gemm_big_kernel<2,2,1>", 4: "gemm_pp_kernel", 6: "gemm_w2_kernel"}
+        shapes = {}
+        for i in range(nrec):
+            r = recs[i]
+            if r.cat != 0:
+                continue
+            e = shapes.setdefault((r.M, r.N, r.K, r.kmul, r.kind), [0, 0.0])
+            e[0] += 1; e[1] += r.ms
+        table = []
+        for (M_, N_, K_, km_, kind_), (c_, t_) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+            useful = 2.0 * M_ * N_ * K_ * c_ / (t_ * 1e-3) / 1e12
+            table.append({"M": M_, "N": N_, "K": K_, "products_per_term": km_, "kernel": KIND.get(kind_, str(kind_)), "launches": c_,
+                          "us_per_launch": round(t_ * 1e3 / c_, 1), "ms_per_step": round(t_, 3), "useful_tflops": round(useful, 1),
+                          "frac_useful": round(useful / PEAK_BF16_TFLOPS, 4), "executed_tflops": round(useful * km_, 1)})
+        traffic, traffic_src = None, None   # PMC counters cannot be read inside a timed run: the committed rocprofv3 --pmc passes of this same command
+        for f_ in ("r02_traffic_pmc.json",):
+            try:
+                with open(os.path.join(ROOT, "profiles", f_)) as f:
+                    traffic = round(json.load(f)["gemm_hbm_bytes_per_launch"]); traffic_src = f_
+                    break
+            except Exception:
+                pass
+        scheme = {"f16w2": "f16w2 = f16 MFMA operands; split (hi, lo) weights (2 products per weight) on the ViT patch-embedding / out-proj / fc2 GEMMs; text tower, "
+                           "ViT projection tail and the outfit transformer in three-product arithmetic",
+                  "f16": "f16, one MFMA product per term", "bf16": "bf16, one MFMA product per term"}.get(a.tower_precision, a.tower_precision)
         res = {
             "metric": "outfits/sec CP forward (8-item sets, 224^2, bf16)",
             "value": round(world * B * a.steps / elapsed, 2),
@@ -170,19 +277,24 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if a.tower_precision == "bf16" else a.tower_precision,
+            "dtype": "bf16" if a.tower_precision.startswith("bf16") else "f16",
             "data": "synthetic (seeded uniform-uint8 images after CLIP normalise, 8-token ids, random-init weights of the reference architecture)",
             "config": {"workload": "BASELINE configs[1]: CP forward with CLIP ViT-B/32 image+text encode, 256 outfits x 8 items per GPU, 224^2",
                        "outfits_per_gpu": B, "items": n, "parallelism": f"dp{world} (batch sharded, no data-path collective)",
-                       "tower_precision": a.tower_precision,
-                       "outfit_precision": (model._tower_fed() or a.precision) + (" (set transformer fed by the in-call towers; bf16x3 for precomputed fp32 embeddings)" if model._tower_fed() else "")},
-            "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_big_kernel<2,4,2> / <2,2,1> / gemm_128x128_kernel (every dense contraction of the step)",
+                       "tower_precision": scheme,
+                       "outfit_precision": (model._tower_fed() or a.precision) + (" (set transformer fed by the in-call bf16 towers)" if model._tower_fed() else ""),
+                       "parity_bound": "north star: <= 1e-3 max|d| / max|ref| on the CP logit vs the fp32 reference path; held by the default scheme (tests/test_gpu_model.py::test_cfg2_end_to_end_within_1e3_on_every_weight_seed)"},
+            "roofline": {"bound": "mfma", "kernel": "every dense contraction of the step: " + " / ".join(sorted({t_["kernel"] for t_ in table})),
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                         "traffic_note": "bytes/launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/r01_traffic_pmc.json (separate --pmc passes); algorithmic ~370e6 (operands + the (hi, lo) residual stream in/out + outputs)",
+                         "traffic_note": f"bytes/launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/{traffic_src} (separate --pmc passes)" if traffic else "no PMC pass committed for this build yet",
+                         "note": "achieved = ALGORITHMIC (useful, pad-free, one product per term) GEMM FLOPs of the step / summed GEMM launch time of one sampled step; "
+                                 "executed_tflops counts the extra MFMA products the 1e-3-compliant scheme spends (split weights x2, three-product x3)",
+                         "executed_tflops": round(executed, 2), "executed_frac": round(executed / PEAK_BF16_TFLOPS, 4),
                          "launches_per_step": gemm_launches, "sampled_steps": 1,
                          "avg_launch_us": round(gemm_ms * 1e3 / max(gemm_launches, 1), 2),
-                         "algorithmic_gflop_per_outfit": round(alg_gemm_outfit / 1e9, 3)},
+                         "algorithmic_gflop_per_outfit": round(alg_gemm_outfit / 1e9, 3),
+                         "per_shape": table},
             "step_breakdown_ms": {"gemm": round(bms[0], 3), "norm_embed": round(bms[1], 3), "attention": round(bms[2], 3),
                                   "other": round(bms[3], 3), "note": "one extra untimed step with all launches bracketed"},
             "whole_step_tflops_useful": round(alg_all_outfit * world * B * a.steps / elapsed / 1e12, 2),
@@ -193,15 +305,33 @@ def main():
                 "tflops_equiv_per_gpu": round(padded_outfit * B * a.steps / elapsed / 1e12, 2),
                 "frac_of_peak": round(padded_outfit * B * a.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS, 4)},
         }
-        if a.cpu_outfits > 0 and world == 1:      # the CPU baseline is a single-GPU-run datum (rank 0, N = 1 only)
+        if a.cpu_outfits > 0 and world == 1:      # oracle check + CPU baseline: single-GPU-run data (rank 0, N = 1 only), outside the timed region
             k = min(a.cpu_outfits, B)
-            ref, dt = cpu_baseline(px[:k].cpu().numpy(), texts["input_ids"][:k].numpy(), texts["attention_mask"][:k].numpy(),
-                                   mask[:k].cpu().numpy(), k, n)
+            _log(f"timed region done: {elapsed / a.steps * 1e3:.2f} ms/step; oracle check on {k} outfits")
+            torch.set_num_threads(min(host_cores(), 32))
+            ref = oracle_logits(px[:k].cpu().numpy(), texts["input_ids"][:k].numpy(), texts["attention_mask"][:k].numpy(), mask[:k].cpu().numpy(), k)
             got = out[:k].float().cpu().numpy()
-            res["cpu_baseline"] = {"value": round(k / dt, 4), "unit": "outfits/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
-                                   "sample": f"{k} outfits x {n} items of the same batch ({k * n} images 224^2, {k * n} texts padded to 64 tokens as the "
-                                             f"reference feeds them), fp32 numpy oracle (BLAS threads = all cores), {dt:.1f} s"}
             res["parity_rel_err_vs_oracle"] = float(np.abs(got - ref).max() / np.abs(ref).max())
+            res["parity_note"] = f"max|d| / max|ref| of the first {k} outfits' CP logits vs the fp32 numpy oracle (oracle/np_oracle.py), weight seed {W_SEED}"
+            res["cpu_baseline"] = cpu_baseline(px, texts["input_ids"], texts["attention_mask"], n, min(a.cpu_cfg2_outfits, B))
+            if a.secondary and a.secondary != a.tower_precision:
+                # secondary, NON-compliant mode for context (never `value`): single-product towers, same batch, 5 steps after 2 warm-up
+                _log(f"secondary measurement: {a.secondary} towers")
+                model.item_encoder.set_precision(a.secondary)
+                for _ in range(2):
+                    o2 = step()
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    o2 = step()
+                fence()
+                dt2 = (time.perf_counter() - t1) / 5
+                g2 = o2[:k].float().cpu().numpy()
+                res["secondary_single_product"] = {"tower_precision": a.secondary + ", one MFMA product per term (the round-1 headline mode)",
+                                                   "outfits_per_s": round(B / dt2, 1), "ms_per_step": round(dt2 * 1e3, 3),
+                                                   "parity_rel_err_vs_oracle": float(np.abs(g2 - ref).max() / np.abs(ref).max()),
+                                                   "note": "faster but outside the 1e-3 bound: reported for context only"}
+                model.item_encoder.set_precision(a.tower_precision)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

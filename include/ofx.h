@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define OFX_ABI_VERSION 1
+#define OFX_ABI_VERSION 2
 
 enum { OFX_OK = 0, OFX_EINVAL = -1, OFX_ESHAPE = -2, OFX_EHIP = -3, OFX_EWORKSPACE = -4, OFX_ESTATE = -5 };
 enum ofx_dtype { OFX_F32 = 0, OFX_BF16 = 1, OFX_F16 = 2 };
@@ -58,9 +58,15 @@ typedef struct ofx_model_desc {
     /* CLIP text tower — HF CLIPTextConfig as loaded by clip_text_encoder.py:19-21 */
     int txt_width, txt_layers, txt_heads, txt_mlp, txt_vocab, txt_max_pos, txt_act, txt_eos_id; /* 512,12,8,2048,49408,77 */
     int proj_dim;                                     /* 512 */
-    int tower_precision;                              /* OFX_PREC_BF16 | OFX_PREC_F16 */
+    int tower_precision;                              /* OFX_PREC_BF16 | OFX_PREC_F16: operand type of both towers */
     float ln_eps;                                     /* 1e-5 */
+    /* Operand scheme of the towers beyond one product per term (all zero = single product everywhere):
+     * vit_w2_mask: OFX_W2_* bits - these ViT GEMMs multiply against split (hi, lo) weights, two MFMA products per weight;
+     * txt_x3:      the text tower runs three products per term (hi*hi + lo*hi + hi*lo, K-concatenated);
+     * proj_x3:     the ViT's post-LayerNorm + visual_projection tail runs three products per term. */
+    int vit_w2_mask, txt_x3, proj_x3;
 } ofx_model_desc;
+enum { OFX_W2_PATCH = 1, OFX_W2_OUT = 4, OFX_W2_FC2 = 16 };
 
 /* Fills *d with the configuration of the reference's type='clip' model. */
 void ofx_default_desc(ofx_model_desc* d);
@@ -216,6 +222,12 @@ int ofx_focal_loss_ex(const float* logits, const float* labels, int B, float alp
  * summed milliseconds, executed FLOPs (GEMM only) and launch counts; arrays of 4.  Process-global, not thread-safe: benchmarks and tests only. */
 void ofx_profile_enable(int on);
 int ofx_profile_read(double* ms, double* flops, long long* launches);
+/* Per-launch records of the last recording, in launch order (call BEFORE ofx_profile_read, which clears them).  GEMM records carry
+ * their shape and kernel: M, N, K (logical depth), kmul (executed K = kmul x K: 2 split weights [hi | lo], 3 three-product
+ * K-concatenation) and kind (1 128x128 tile kernel incl. its split-K / 64-row variants, 2 256x256, 3 256x128, 4 256x256 ping-pong,
+ * 6 dual-weight 256x256); flops = executed FLOPs.  Returns the count. */
+typedef struct ofx_prof_record { int cat, M, N, K, kind, kmul; float ms; double flops; } ofx_prof_record;
+int ofx_profile_records(ofx_prof_record* out, int cap);
 
 /* Process-wide tuning knobs (benchmarks / tests only).  knob 0: GEMM rasterisation group (row panels per L2 group, default 8);
  * knob 6: 2 (default) folds the CLIP towers' LayerNorms into the neighbouring GEMM epilogues AND keeps their residual stream as an

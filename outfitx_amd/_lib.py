@@ -18,6 +18,18 @@ PREC_BF16, PREC_F16, PREC_BF16X3 = 0, 1, 2
 OUT_F32, OUT_OP, OUT_SPLIT3 = 0, 1, 2
 OP_SET_ENCODER, OP_VIT, OP_TEXT, OP_TOPK = 0, 1, 2, 3
 PRECISIONS = {"bf16": PREC_BF16, "f16": PREC_F16, "fp16": PREC_F16, "bf16x3": PREC_BF16X3}
+# CLIP tower operand schemes: name -> (operand type, vit_w2_mask, txt_x3, proj_x3).
+#   "bf16" / "f16": one MFMA product per term everywhere (fastest; 4e-3 / 5e-4 typical at the tower outputs).
+#   "f16w2" (default): f16 operands; the ViT's patch-embedding, out-proj and fc2 GEMMs multiply against split (hi, lo) weights
+#   (two products per weight), the text tower and the ViT's projection tail run three products per term - the scheme that
+#   holds the end-to-end CP logit within 1e-3 of the fp32 reference on every weight seed tried (tests/studies/operand_scheme_cpu.py).
+W2_PATCH, W2_OUT, W2_FC2 = 1, 4, 16
+TOWER_SCHEMES = {
+    "bf16": (PREC_BF16, 0, 0, 0), "f16": (PREC_F16, 0, 0, 0), "fp16": (PREC_F16, 0, 0, 0),
+    "f16w2": (PREC_F16, W2_PATCH | W2_OUT | W2_FC2, 1, 1),
+    "bf16w2": (PREC_BF16, W2_PATCH | W2_OUT | W2_FC2, 1, 1),
+}
+DEFAULT_TOWER_PRECISION = "f16w2"
 ACTS = {"none": ACT_NONE, "quick_gelu": ACT_QUICK_GELU, "gelu": ACT_GELU, "mish": ACT_MISH}
 
 
@@ -30,7 +42,11 @@ class ModelDesc(C.Structure):
         "d_model", "n_head", "d_ffn", "n_layers", "max_items", "outfit_act", "outfit_precision",
         "vit_width", "vit_layers", "vit_heads", "vit_mlp", "vit_patch", "vit_image", "vit_act",
         "txt_width", "txt_layers", "txt_heads", "txt_mlp", "txt_vocab", "txt_max_pos", "txt_act", "txt_eos_id",
-        "proj_dim", "tower_precision")] + [("ln_eps", C.c_float)]
+        "proj_dim", "tower_precision")] + [("ln_eps", C.c_float)] + [(n, C.c_int) for n in ("vit_w2_mask", "txt_x3", "proj_x3")]
+
+
+class ProfRecord(C.Structure):
+    _fields_ = [("cat", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("kind", C.c_int), ("kmul", C.c_int), ("ms", C.c_float), ("flops", C.c_double)]
 
 
 _vp, _i, _f, _sz, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
@@ -75,6 +91,7 @@ SIGNATURES = {
     "ofx_focal_loss_ex": (_i, [_vp, _vp, _i, _f, _f, _f, _i, _vp, _vp, _vp, _vp]),
     "ofx_profile_enable": (None, [_i]),
     "ofx_profile_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "ofx_profile_records": (_i, [C.POINTER(ProfRecord), _i]),
     "ofx_tune": (_i, [_i, _i]),
     "ofx_debug_gemm_clock": (None, [_vp]),
     "ofx_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -104,7 +121,7 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)        # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.ofx_abi_version() != 1:
+    if lib.ofx_abi_version() != 2:
         raise OfxError("libofx_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -25,8 +25,9 @@ extern "C" int ofx_abi_version(void) { return OFX_ABI_VERSION; }
 bool g_ofx_prof_on = false;
 int g_ofx_prof_mask = 0xf;
 namespace {
-struct ProfRec { hipEvent_t a, b; int cat; double flops; };
+struct ProfRec { hipEvent_t a, b; int cat; double flops; int tag[5]; };      // tag: {M, N, logical K, kernel kind, K multiplier} of a GEMM launch
 std::vector<ProfRec> g_prof;
+int g_prof_next_tag[5] = {0, 0, 0, 0, 0};
 size_t g_prof_used = 0;
 bool g_prof_over = false;
 }
@@ -38,8 +39,10 @@ void ofx_prof_begin(int cat, hipStream_t s, double flops) {
     g_prof_over = false;
     ProfRec& r = g_prof[g_prof_used];
     r.cat = cat; r.flops = flops;
+    for (int i = 0; i < 5; ++i) { r.tag[i] = g_prof_next_tag[i]; g_prof_next_tag[i] = 0; }
     (void)hipEventRecord(r.a, s);
 }
+void ofx_prof_set_tag(int M, int N, int K, int kind, int kmul) { g_prof_next_tag[0] = M; g_prof_next_tag[1] = N; g_prof_next_tag[2] = K; g_prof_next_tag[3] = kind; g_prof_next_tag[4] = kmul; }
 void ofx_prof_end(hipStream_t s) {
     if (!g_prof_over && g_prof_used < g_prof.size()) { (void)hipEventRecord(g_prof[g_prof_used].b, s); ++g_prof_used; }
 }
@@ -48,6 +51,7 @@ bool ofx_prof_ext_begin(int cat, double flops) {
     if (g_prof_used == g_prof.size()) return false;
     ProfRec& r = g_prof[g_prof_used];
     r.cat = cat; r.flops = flops;
+    for (int i = 0; i < 5; ++i) { r.tag[i] = g_prof_next_tag[i]; g_prof_next_tag[i] = 0; }
     g_ofx_launch_e0 = r.a; g_ofx_launch_e1 = r.b;
     return true;
 }
@@ -60,13 +64,25 @@ void ofx_prof_ext_end() {
 extern "C" void ofx_profile_enable(int on) {
     // create the event pool up front (never inside a timed region): room for 4096 bracketed launches
     while (on && g_prof.size() < 4096) {
-        ProfRec r; r.cat = 0; r.flops = 0;
+        ProfRec r; r.cat = 0; r.flops = 0; r.tag[0] = r.tag[1] = r.tag[2] = r.tag[3] = r.tag[4] = 0;
         if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) break;
         g_prof.push_back(r);
     }
     if (on) g_prof_used = 0;               // turning recording ON clears; turning it off keeps the records for read()
     g_ofx_prof_on = on != 0;
     if (on) g_ofx_prof_mask = on;
+}
+// Per-launch records of the last recording (call BEFORE ofx_profile_read, which clears them): waits for the events.
+extern "C" int ofx_profile_records(ofx_prof_record* out, int cap) {
+    int n = 0;
+    for (size_t i = 0; i < g_prof_used && n < cap; ++i, ++n) {
+        ProfRec& r = g_prof[i];
+        OFX_HIP(hipEventSynchronize(r.b));
+        float t = 0;
+        OFX_HIP(hipEventElapsedTime(&t, r.a, r.b));
+        out[n].cat = r.cat; out[n].M = r.tag[0]; out[n].N = r.tag[1]; out[n].K = r.tag[2]; out[n].kind = r.tag[3]; out[n].kmul = r.tag[4]; out[n].ms = t; out[n].flops = r.flops;
+    }
+    return n;
 }
 // Waits for the recorded events (host sync: call outside the timed region) and sums per category.
 extern "C" int ofx_profile_read(double* ms, double* flops, long long* launches) {
@@ -133,7 +149,9 @@ struct OutfitLayer { void *w_in, *w_out, *w_1, *w_2; float *b_in, *b_out, *b_1, 
                      void *w_in_t, *w_out_t, *w_1_t, *w_2_t; };   // transposed operand copies (dgrad), single-product precisions only
 struct ClipLayer { void *w_qkv, *w_o, *w_fc1, *w_fc2; float *b_qkv, *b_o, *b_fc1, *b_fc2, *g1, *be1, *g2, *be2;
                    // LayerNorm-folded copies: W . gamma (rounded), column sums of the rounded rows, bias + W beta
-                   void *w_qkv_f, *w_fc1_f; float *cs_qkv, *bf_qkv, *cs_fc1, *bf_fc1; };
+                   void *w_qkv_f, *w_fc1_f; float *cs_qkv, *bf_qkv, *cs_fc1, *bf_fc1;
+                   // split-weight copies [hi | lo] (GemmArgs::a_wrap) of the GEMMs in the tower's w2 mask; null otherwise
+                   void *w_o2 = nullptr, *w_fc22 = nullptr; };
 
 }  // namespace
 
@@ -147,6 +165,8 @@ struct ofx_handle {
     float *outfit_token, *tgt_img_emb, *cp_w, *cp_b; void* cir_w; void* cir_w_t = nullptr;   // cir_w_t: W^T operand copy (training dgrad)
     // towers
     int tw_dtype;
+    int vit_w2_mask = 0, txt_x3 = 0, proj_x3 = 0;    // operand scheme (ofx_model_desc); x3 towers hold ONLY the K-concatenated [hi | hi | lo] weight copies
+    void* v_patch_w2 = nullptr; void* v_proj_w3 = nullptr;
     Arena a_vis; bool vis_ready = false;
     std::vector<ClipLayer> vl;
     void *v_patch_w, *v_proj_w; float *v_cls, *v_pos, *v_pre_g, *v_pre_b, *v_post_g, *v_post_b;
@@ -178,6 +198,7 @@ extern "C" ofx_handle* ofx_create(int device, const ofx_model_desc* desc) {
     if (d.tower_precision != OFX_PREC_BF16 && d.tower_precision != OFX_PREC_F16) return bad("tower_precision must be BF16 or F16");
     if (d.outfit_precision < 0 || d.outfit_precision > 2) return bad("bad outfit_precision");
     if (d.n_layers < 1 || d.vit_layers < 1 || d.txt_layers < 1 || d.d_ffn < 1) return bad("layer counts / d_ffn must be positive");
+    if (d.vit_w2_mask & ~(OFX_W2_PATCH | OFX_W2_OUT | OFX_W2_FC2)) return bad("vit_w2_mask: only the patch, out-proj and fc2 GEMMs have split-weight copies");
     if (hipSetDevice(device) != hipSuccess) return bad("hipSetDevice failed");
     ofx_handle* h = new ofx_handle();
     h->device = device; h->d = d;
@@ -185,6 +206,7 @@ extern "C" ofx_handle* ofx_create(int device, const ofx_model_desc* desc) {
     h->ot_kmul = d.outfit_precision == OFX_PREC_BF16X3 ? 3 : 1;
     h->ot_ffn_pad = pad128(d.d_ffn);
     h->tw_dtype = d.tower_precision == OFX_PREC_F16 ? OFX_F16 : OFX_BF16;
+    h->vit_w2_mask = d.vit_w2_mask; h->txt_x3 = d.txt_x3 != 0; h->proj_x3 = d.proj_x3 != 0;
     return h;
 }
 
@@ -282,24 +304,28 @@ extern "C" int ofx_pack_outfit_weights(ofx_handle* h, const void* const* P, int 
 
 // q/k/v Linear weights -> one [3W, W] operand matrix in q|k|v order (+ fused bias).  `q` points at
 // the 16 per-layer tensors in HF order: k.w,k.b,v.w,v.b,q.w,q.b,out.w,out.b,ln1.w,ln1.b,fc1.w,fc1.b,fc2.w,fc2.b,ln2.w,ln2.b
-static int pack_clip_layer(Arena& A, ClipLayer& L, const void* const* q, size_t W, size_t MLP, int dt, hipStream_t s) {
-    char* wq = A.take<char>(2 * 3 * W * W);
+static int pack_clip_layer(Arena& A, ClipLayer& L, const void* const* q, size_t W, size_t MLP, int dt, hipStream_t s, int w2_mask = 0, bool x3 = false) {
+    const size_t km = x3 ? 3 : 1;
+    const int mode = x3 ? 2 : 0;                    // x3: every weight row is [hi | hi | lo] (K' = 3K), no single-product / folded copy exists
+    char* wq = A.take<char>(2 * km * 3 * W * W);
     L.w_qkv = wq;
-    TRY(ofx_launch_pack_rows((const float*)q[4], wq, W, W, W, W, W, 0, dt, s));
-    TRY(ofx_launch_pack_rows((const float*)q[0], wq + 2 * W * W, W, W, W, W, W, 0, dt, s));
-    TRY(ofx_launch_pack_rows((const float*)q[2], wq + 4 * W * W, W, W, W, W, W, 0, dt, s));
+    TRY(ofx_launch_pack_rows((const float*)q[4], wq, W, W, W, W, W, mode, dt, s));
+    TRY(ofx_launch_pack_rows((const float*)q[0], wq + 2 * km * W * W, W, W, W, W, W, mode, dt, s));
+    TRY(ofx_launch_pack_rows((const float*)q[2], wq + 4 * km * W * W, W, W, W, W, W, mode, dt, s));
     L.b_qkv = A.take<float>(3 * W);
     TRY(copy_f32(L.b_qkv, q[5], W, s)); TRY(copy_f32(L.b_qkv + W, q[1], W, s)); TRY(copy_f32(L.b_qkv + 2 * W, q[3], W, s));
-    L.w_o = A.take<char>(2 * W * W); TRY(ofx_launch_pack_rows((const float*)q[6], L.w_o, W, W, W, W, W, 0, dt, s));
+    L.w_o = A.take<char>(2 * km * W * W); TRY(ofx_launch_pack_rows((const float*)q[6], L.w_o, W, W, W, W, W, mode, dt, s));
     L.b_o = A.take<float>(W); TRY(copy_f32(L.b_o, q[7], W, s));
     L.g1 = A.take<float>(W); TRY(copy_f32(L.g1, q[8], W, s));
     L.be1 = A.take<float>(W); TRY(copy_f32(L.be1, q[9], W, s));
-    L.w_fc1 = A.take<char>(2 * MLP * W); TRY(ofx_launch_pack_rows((const float*)q[10], L.w_fc1, MLP, MLP, W, W, W, 0, dt, s));
+    L.w_fc1 = A.take<char>(2 * km * MLP * W); TRY(ofx_launch_pack_rows((const float*)q[10], L.w_fc1, MLP, MLP, W, W, W, mode, dt, s));
     L.b_fc1 = A.take<float>(MLP); TRY(copy_f32(L.b_fc1, q[11], MLP, s));
-    L.w_fc2 = A.take<char>(2 * W * MLP); TRY(ofx_launch_pack_rows((const float*)q[12], L.w_fc2, W, W, MLP, MLP, MLP, 0, dt, s));
+    L.w_fc2 = A.take<char>(2 * km * W * MLP); TRY(ofx_launch_pack_rows((const float*)q[12], L.w_fc2, W, W, MLP, MLP, MLP, mode, dt, s));
     L.b_fc2 = A.take<float>(W); TRY(copy_f32(L.b_fc2, q[13], W, s));
     L.g2 = A.take<float>(W); TRY(copy_f32(L.g2, q[14], W, s));
     L.be2 = A.take<float>(W); TRY(copy_f32(L.be2, q[15], W, s));
+    L.w_qkv_f = L.w_fc1_f = nullptr; L.cs_qkv = L.bf_qkv = L.cs_fc1 = L.bf_fc1 = nullptr; L.w_o2 = L.w_fc22 = nullptr;
+    if (x3) return OFX_OK;
     // folded copies (q, k, v order as above: HF stores k, v, q, out in q[0..7])
     char* wf = A.take<char>(2 * 3 * W * W);
     L.w_qkv_f = wf; L.cs_qkv = A.take<float>(3 * W); L.bf_qkv = A.take<float>(3 * W);
@@ -309,9 +335,16 @@ static int pack_clip_layer(Arena& A, ClipLayer& L, const void* const* q, size_t 
     TRY(ofx_launch_fold_pack((const float*)q[2], (const float*)q[8], (const float*)q[9], (const float*)q[3], wf + 4 * W * W, L.cs_qkv + 2 * W, L.bf_qkv + 2 * W, Wi, Wi, dt, s));
     L.w_fc1_f = A.take<char>(2 * MLP * W); L.cs_fc1 = A.take<float>(MLP); L.bf_fc1 = A.take<float>(MLP);
     TRY(ofx_launch_fold_pack((const float*)q[10], (const float*)q[14], (const float*)q[15], (const float*)q[11], L.w_fc1_f, L.cs_fc1, L.bf_fc1, (int)MLP, Wi, dt, s));
+    // split-weight copies: row n = [hi(K) | lo(K)]
+    if (w2_mask & OFX_W2_OUT) { L.w_o2 = A.take<char>(4 * W * W); TRY(ofx_launch_pack_rows((const float*)q[6], L.w_o2, W, W, W, W, W, 3, dt, s)); }
+    if (w2_mask & OFX_W2_FC2) { L.w_fc22 = A.take<char>(4 * W * MLP); TRY(ofx_launch_pack_rows((const float*)q[12], L.w_fc22, W, W, MLP, MLP, MLP, 3, dt, s)); }
     return OFX_OK;
 }
-static size_t clip_layer_bytes(size_t W, size_t MLP) { return 2 * (4 * W * W + 2 * W * MLP) + 4 * (9 * W + MLP) + 2 * (3 * W * W + W * MLP) + 4 * (6 * W + 2 * MLP) + 32 * 256; }
+static size_t clip_layer_bytes(size_t W, size_t MLP, int w2_mask = 0, bool x3 = false) {
+    if (x3) return 6 * (4 * W * W + 2 * W * MLP) + 4 * (9 * W + MLP) + 32 * 256;
+    return 2 * (4 * W * W + 2 * W * MLP) + 4 * (9 * W + MLP) + 2 * (3 * W * W + W * MLP) + 4 * (6 * W + 2 * MLP) +
+           ((w2_mask & OFX_W2_OUT) ? 4 * W * W : 0) + ((w2_mask & OFX_W2_FC2) ? 4 * W * MLP : 0) + 34 * 256;
+}
 
 extern "C" int ofx_pack_vision_weights(ofx_handle* h, const void* const* P, int n, ofx_stream stream) {
     OFX_REQUIRE(h, OFX_EINVAL, "pack_vision: NULL handle");
@@ -320,21 +353,25 @@ extern "C" int ofx_pack_vision_weights(ofx_handle* h, const void* const* P, int 
     for (int i = 0; i < n; ++i) OFX_REQUIRE(P[i], OFX_EINVAL, "pack_vision: tensor %d is NULL", i);
     hipStream_t s = (hipStream_t)stream;
     const size_t W = d.vit_width, MLP = d.vit_mlp, KP = 3 * (size_t)d.vit_patch * d.vit_patch, g = d.vit_image / d.vit_patch, S = g * g + 1, PD = d.proj_dim;
-    TRY(h->a_vis.reserve(clip_layer_bytes(W, MLP) * d.vit_layers + 2 * W * KP + 2 * PD * W + 4 * (W + S * W + 4 * W) + 16 * 256));
+    TRY(h->a_vis.reserve(clip_layer_bytes(W, MLP, h->vit_w2_mask) * d.vit_layers + 6 * W * KP + 8 * PD * W + 4 * (W + S * W + 4 * W) + 18 * 256));
     Arena& A = h->a_vis;
     CopyBatch copies;
     const int dt = h->tw_dtype;
     h->v_cls = A.take<float>(W); TRY(copy_f32(h->v_cls, P[0], W, s));
     h->v_patch_w = A.take<char>(2 * W * KP); TRY(ofx_launch_pack_rows((const float*)P[1], h->v_patch_w, W, W, KP, KP, KP, 0, dt, s));
+    h->v_patch_w2 = nullptr;
+    if (h->vit_w2_mask & OFX_W2_PATCH) { h->v_patch_w2 = A.take<char>(4 * W * KP); TRY(ofx_launch_pack_rows((const float*)P[1], h->v_patch_w2, W, W, KP, KP, KP, 3, dt, s)); }
     h->v_pos = A.take<float>(S * W); TRY(copy_f32(h->v_pos, P[2], S * W, s));
     h->v_pre_g = A.take<float>(W); TRY(copy_f32(h->v_pre_g, P[3], W, s));
     h->v_pre_b = A.take<float>(W); TRY(copy_f32(h->v_pre_b, P[4], W, s));
     h->vl.resize(d.vit_layers);
-    for (int l = 0; l < d.vit_layers; ++l) TRY(pack_clip_layer(A, h->vl[l], P + 5 + 16 * l, W, MLP, dt, s));
+    for (int l = 0; l < d.vit_layers; ++l) TRY(pack_clip_layer(A, h->vl[l], P + 5 + 16 * l, W, MLP, dt, s, h->vit_w2_mask));
     const void* const* t = P + 5 + 16 * d.vit_layers;
     h->v_post_g = A.take<float>(W); TRY(copy_f32(h->v_post_g, t[0], W, s));
     h->v_post_b = A.take<float>(W); TRY(copy_f32(h->v_post_b, t[1], W, s));
     h->v_proj_w = A.take<char>(2 * PD * W); TRY(ofx_launch_pack_rows((const float*)t[2], h->v_proj_w, PD, PD, W, W, W, 0, dt, s));
+    h->v_proj_w3 = nullptr;
+    if (h->proj_x3) { h->v_proj_w3 = A.take<char>(6 * PD * W); TRY(ofx_launch_pack_rows((const float*)t[2], h->v_proj_w3, PD, PD, W, W, W, 2, dt, s)); }
     OFX_REQUIRE(A.off <= A.cap, OFX_ESTATE, "pack_vision: arena overflow");
     TRY(copies.flush(s));
     h->vis_ready = true;
@@ -348,18 +385,19 @@ extern "C" int ofx_pack_text_weights(ofx_handle* h, const void* const* P, int n,
     for (int i = 0; i < n; ++i) OFX_REQUIRE(P[i], OFX_EINVAL, "pack_text: tensor %d is NULL", i);
     hipStream_t s = (hipStream_t)stream;
     const size_t W = d.txt_width, MLP = d.txt_mlp, V = d.txt_vocab, NP = d.txt_max_pos, PD = d.proj_dim;
-    TRY(h->a_txt.reserve(clip_layer_bytes(W, MLP) * d.txt_layers + 4 * (V * W + NP * W + 2 * W) + 2 * PD * W + 16 * 256));
+    const bool x3 = h->txt_x3 != 0;
+    TRY(h->a_txt.reserve(clip_layer_bytes(W, MLP, 0, x3) * d.txt_layers + 4 * (V * W + NP * W + 2 * W) + 6 * PD * W + 16 * 256));
     Arena& A = h->a_txt;
     CopyBatch copies;
     const int dt = h->tw_dtype;
     h->t_tok = A.take<float>(V * W); TRY(copy_f32(h->t_tok, P[0], V * W, s));
     h->t_pos = A.take<float>(NP * W); TRY(copy_f32(h->t_pos, P[1], NP * W, s));
     h->tl.resize(d.txt_layers);
-    for (int l = 0; l < d.txt_layers; ++l) TRY(pack_clip_layer(A, h->tl[l], P + 2 + 16 * l, W, MLP, dt, s));
+    for (int l = 0; l < d.txt_layers; ++l) TRY(pack_clip_layer(A, h->tl[l], P + 2 + 16 * l, W, MLP, dt, s, 0, x3));
     const void* const* t = P + 2 + 16 * d.txt_layers;
     h->t_fin_g = A.take<float>(W); TRY(copy_f32(h->t_fin_g, t[0], W, s));
     h->t_fin_b = A.take<float>(W); TRY(copy_f32(h->t_fin_b, t[1], W, s));
-    h->t_proj_w = A.take<char>(2 * PD * W); TRY(ofx_launch_pack_rows((const float*)t[2], h->t_proj_w, PD, PD, W, W, W, 0, dt, s));
+    h->t_proj_w = A.take<char>(2 * (x3 ? 3 : 1) * PD * W); TRY(ofx_launch_pack_rows((const float*)t[2], h->t_proj_w, PD, PD, W, W, W, x3 ? 2 : 0, dt, s));
     OFX_REQUIRE(A.off <= A.cap, OFX_ESTATE, "pack_text: arena overflow");
     TRY(copies.flush(s));
     h->txt_ready = true;
@@ -393,20 +431,24 @@ size_t carve_set(const ofx_handle* h, Bump& b, int B, int L, SetWs* w) {
 }
 struct ClipWs { float* X; char* H; char* QKV; char* U; int* idx; char* PL; float* E; float* XP; char* HP; char* UP; char* slab; size_t slab_bytes;
                 char* XB; float* P; float* S; char* XLO; };   // LayerNorm folding: raw operand copy of X, per-segment partial stats, (mean, rstd), lo half of the (hi, lo) stream
-size_t carve_clip(Bump& b, size_t rows, size_t n, size_t W, size_t MLP, size_t PD, size_t u_min_bytes, size_t qkv_min_bytes, ClipWs* w) {
+// km = 3: the three-product towers keep their GEMM operands K-concatenated ([hi | lo | hi] rows of 3 W / 3 MLP elements);
+// kk = K multiplier of the pooled-row GEMMs' split-K plans (2 with split weights, 3 in three-product mode)
+size_t carve_clip(Bump& b, size_t rows, size_t n, size_t W, size_t MLP, size_t PD, size_t u_min_bytes, size_t qkv_min_bytes, ClipWs* w, size_t km = 1, size_t kk = 1) {
     ClipWs t;
     t.X = b.take<float>(rows * W);
-    t.H = b.take<char>(rows * W * 2);
-    t.QKV = b.take<char>(std::max(rows * 3 * W * 2, qkv_min_bytes));
-    t.U = b.take<char>(std::max(rows * MLP * 2, u_min_bytes));
+    t.H = b.take<char>(rows * km * W * 2);
+    t.QKV = b.take<char>(std::max(rows * 3 * W * (km == 3 ? 4 : 2), qkv_min_bytes));      // three-product towers keep q | k | v in fp32
+    t.U = b.take<char>(std::max(rows * km * MLP * 2, u_min_bytes));
     t.idx = b.take<int>(n);
-    t.PL = b.take<char>(n * W * 2);
+    t.PL = b.take<char>(n * 3 * W * 2);   // pooled LayerNorm output, [hi | lo | hi] when the projection runs three products
     t.E = b.take<float>(n * PD);
     t.XP = b.take<float>(n * W);          // last layer runs on the pooled rows only
-    t.HP = b.take<char>(n * W * 2);
-    t.UP = b.take<char>(n * MLP * 2);
-    t.slab_bytes = std::max(std::max(ofx_gemm_splitk_bytes((int)n, (int)W, (int)W), ofx_gemm_splitk_bytes((int)n, (int)MLP, (int)W)),
-                            std::max(ofx_gemm_splitk_bytes((int)n, (int)W, (int)MLP), ofx_gemm_splitk_bytes((int)n, (int)PD, (int)W)));
+    t.HP = b.take<char>(n * km * W * 2);
+    t.UP = b.take<char>(n * km * MLP * 2);
+    t.slab_bytes = 0;
+    for (size_t k : {(size_t)1, kk, (size_t)3})
+        t.slab_bytes = std::max(std::max(std::max(ofx_gemm_splitk_bytes((int)n, (int)W, (int)(k * W)), ofx_gemm_splitk_bytes((int)n, (int)MLP, (int)(k * W))),
+                                         std::max(ofx_gemm_splitk_bytes((int)n, (int)W, (int)(k * MLP)), ofx_gemm_splitk_bytes((int)n, (int)PD, (int)(k * W)))), t.slab_bytes);
     t.slab = b.take<char>(t.slab_bytes);
     t.XB = b.take<char>(rows * W * 2);
     t.P = b.take<float>(rows * (W / 64) * 2);
@@ -420,13 +462,13 @@ size_t vit_bytes(const ofx_handle* h, int n, ClipWs* w, void* ws, size_t cap) {
     const size_t g = d.vit_image / d.vit_patch, S = g * g + 1, KP = 3 * (size_t)d.vit_patch * d.vit_patch;
     Bump b(ws, cap);
     // the patch matrix aliases U and the fp32 patch-GEMM output aliases QKV (both dead before the layers start)
-    size_t r = carve_clip(b, (size_t)n * S, n, d.vit_width, d.vit_mlp, d.proj_dim, (size_t)n * g * g * KP * 2, (size_t)n * g * g * d.vit_width * 4, w);
+    size_t r = carve_clip(b, (size_t)n * S, n, d.vit_width, d.vit_mlp, d.proj_dim, (size_t)n * g * g * KP * 2, (size_t)n * g * g * d.vit_width * 4, w, 1, 2);
     return align_up(r, 256);
 }
 size_t txt_bytes(const ofx_handle* h, int n, int Tc, ClipWs* w, void* ws, size_t cap) {
     const ofx_model_desc& d = h->d;
     Bump b(ws, cap);
-    size_t r = carve_clip(b, (size_t)n * Tc, n, d.txt_width, d.txt_mlp, d.proj_dim, 0, 0, w);
+    size_t r = carve_clip(b, (size_t)n * Tc, n, d.txt_width, d.txt_mlp, d.proj_dim, 0, 0, w, h->txt_x3 ? 3 : 1, h->txt_x3 ? 3 : 1);
     return align_up(r, 256);
 }
 constexpr int VIT_CHUNK_MAX = 2048;
@@ -495,7 +537,7 @@ static int set_encoder_core(ofx_handle* h, const SetInput& in, const float* pref
         LnArgs ln{w.X, nullptr, Ly.g1, Ly.be1, w.H, M, D, km * D, okind, d.ln_eps};
         TRY(ofx_launch_layernorm_dev(ln, m_dev, dt, s));
         GemmArgs g1{}; g1.A = w.H; g1.W = Ly.w_in; g1.C = w.QKV; g1.bias = Ly.b_in; g1.resid = nullptr; g1.m_dev = m_dev;
-        g1.M = M; g1.N = 3 * D; g1.K = km * D; g1.lda = km * D; g1.ldc = 3 * D; g1.ldr = 0; g1.act = OFX_ACT_NONE;
+        g1.M = M; g1.N = 3 * D; g1.K = km * D; g1.k_mult = km; g1.lda = km * D; g1.ldc = 3 * D; g1.ldr = 0; g1.act = OFX_ACT_NONE;
         // single-product precisions: q|k|v stay in the operand type and the varlen MFMA attention runs (as in the training forward);
         // bf16x3 keeps fp32 q|k|v and the fp32 set attention (1e-5 parity)
         const bool mfma_attn = km == 1 && g_train_mfma_attn;
@@ -517,17 +559,17 @@ static int set_encoder_core(ofx_handle* h, const SetInput& in, const float* pref
             X = out_row0; H = w.HP; U = w.UP; Ml = B; md = nullptr;
         }
         GemmArgs g2{}; g2.A = H; g2.W = Ly.w_out; g2.C = X; g2.bias = Ly.b_out; g2.resid = X; g2.m_dev = md;
-        g2.M = Ml; g2.N = D; g2.K = km * D; g2.lda = km * D; g2.ldc = D; g2.ldr = D; g2.act = OFX_ACT_NONE; g2.out_kind = OFX_OUT_F32;
+        g2.M = Ml; g2.N = D; g2.K = km * D; g2.k_mult = km; g2.lda = km * D; g2.ldc = D; g2.ldr = D; g2.act = OFX_ACT_NONE; g2.out_kind = OFX_OUT_F32;
         g2.slab = w.slab; g2.slab_bytes = w.slab_bytes;
         TRY(ofx_launch_gemm(g2, dt, s));
         LnArgs ln2{X, nullptr, Ly.g2, Ly.be2, H, Ml, D, km * D, okind, d.ln_eps};
         TRY(ofx_launch_layernorm_dev(ln2, md, dt, s));
         GemmArgs g3{}; g3.A = H; g3.W = Ly.w_1; g3.C = U; g3.bias = Ly.b_1; g3.resid = nullptr; g3.m_dev = md;
-        g3.M = Ml; g3.N = Fp; g3.K = km * D; g3.lda = km * D; g3.ldc = km * Fp; g3.ldr = 0; g3.act = d.outfit_act; g3.out_kind = okind;
+        g3.M = Ml; g3.N = Fp; g3.K = km * D; g3.k_mult = km; g3.lda = km * D; g3.ldc = km * Fp; g3.ldr = 0; g3.act = d.outfit_act; g3.out_kind = okind;
         g3.slab = w.slab; g3.slab_bytes = w.slab_bytes;
         TRY(ofx_launch_gemm(g3, dt, s));
         GemmArgs g4{}; g4.A = U; g4.W = Ly.w_2; g4.C = X; g4.bias = Ly.b_2; g4.resid = X; g4.m_dev = md;
-        g4.M = Ml; g4.N = D; g4.K = km * Fp; g4.lda = km * Fp; g4.ldc = D; g4.ldr = D; g4.act = OFX_ACT_NONE; g4.out_kind = OFX_OUT_F32;
+        g4.M = Ml; g4.N = D; g4.K = km * Fp; g4.k_mult = km; g4.lda = km * Fp; g4.ldc = D; g4.ldr = D; g4.act = OFX_ACT_NONE; g4.out_kind = OFX_OUT_F32;
         g4.slab = w.slab; g4.slab_bytes = w.slab_bytes;
         TRY(ofx_launch_gemm(g4, dt, s));
     }
@@ -608,6 +650,7 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
     const bool hilo = fold && g_ln_fold == 2;      // residual stream = (XB, XLO) operand-type pair, no fp32 X (ofx_tune(6, 2))
     if (fold2) { g2.xb_out = w.XB; g2.stat_part = w.P; }
     if (fold2 && hilo) { g2.xlo = w.XLO; g2.C = w.XB; g2.ldc = W; g2.out_kind = OFX_OUT_OP; g2.resid = nullptr; }
+    if (L.w_o2) { g2.W = L.w_o2; g2.K = 2 * W; g2.a_wrap = W; }                 // split weights: A . (hi + lo)^T
     TRY(ofx_launch_gemm(g2, dt, s));
     GemmArgs g3{}; g3.C = U; g3.M = M; g3.N = MLP; g3.K = W; g3.lda = W;
     g3.ldc = MLP; g3.act = act; g3.out_kind = OFX_OUT_OP;
@@ -626,16 +669,67 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
     if (pool_idx) { g4.slab = w.slab; g4.slab_bytes = w.slab_bytes; }
     if (fold2) { g4.xb_out = w.XB; g4.stat_part = w.P; }
     if (fold2 && hilo) { g4.xlo = w.XLO; g4.C = w.XB; g4.ldc = W; g4.out_kind = OFX_OUT_OP; g4.resid = nullptr; }
+    if (L.w_fc22) { g4.W = L.w_fc22; g4.K = 2 * MLP; g4.a_wrap = MLP; }
     TRY(ofx_launch_gemm(g4, dt, s));
     if (fold2) TRY(ofx_launch_stats_finalize(w.P, W / 64, W, eps, w.S, M, s));
     return OFX_OK;
+}
+
+// Three-product layer (hi*hi + lo*hi + hi*lo as ONE K-concatenated GEMM, K' = 3K): fp32 residual stream, materialised LayerNorms
+// writing [hi | lo | hi] rows, weights packed [hi | hi | lo] (the outfit transformer's bf16x3 scheme in the towers' operand type).
+// q | k | v leave the projection rounded once to the operand type for the MFMA attention, whose output is again (hi, lo).
+static int clip_layer_x3(const ClipLayer& L, const ClipWs& w, int rows, int nseq, int S, int W, int MLP, int heads, int act,
+                         float eps, int causal, const int64_t* key_mask, int mask_ld, int dt, const int* pool_idx, hipStream_t s) {
+    LnArgs ln{w.X, nullptr, L.g1, L.be1, w.H, rows, W, 3 * W, OFX_OUT_SPLIT3, eps};
+    TRY(ofx_launch_layernorm(ln, dt, s));
+    GemmArgs g1{}; g1.A = w.H; g1.W = L.w_qkv; g1.C = w.QKV; g1.bias = L.b_qkv; g1.M = rows; g1.N = 3 * W; g1.K = 3 * W; g1.k_mult = 3; g1.lda = 3 * W;
+    // sequences of <= 32 rows (item texts: category names): q | k | v stay fp32 and the attention runs in fp32 arithmetic (the outfit
+    // transformer's set kernel with HF's causal AND key-padding mask); longer ones round q | k | v once to the operand type for
+    // the single-tile MFMA kernel (3e-4 at the text embedding, tests/studies/operand_scheme_cpu.py)
+    const bool f32_attn = S <= 32;
+    g1.ldc = 3 * W; g1.act = OFX_ACT_NONE; g1.out_kind = f32_attn ? OFX_OUT_F32 : OFX_OUT_OP;
+    TRY(ofx_launch_gemm(g1, dt, s));
+    if (f32_attn) {
+        SetAttnArgs sa{w.QKV, w.H, nullptr, nseq, heads, W, 3 * W, OFX_OUT_SPLIT3, S, 0, 0.125f};
+        sa.fixed_len = S; sa.causal = causal; sa.key_mask = key_mask; sa.mask_ld = mask_ld;
+        TRY(ofx_launch_set_attention(sa, dt, s));
+    } else {
+        AttnArgs at{w.QKV, w.H, key_mask, nseq, S, heads, 3 * W, 3 * W, W, 2 * W, mask_ld, causal, 0.125f};
+        at.split3_w = W;
+        TRY(ofx_launch_attention_mfma(at, dt, s));
+    }
+    float* X = w.X; char* H = w.H; char* U = w.U; int M = rows;
+    if (pool_idx) {
+        TRY(ofx_launch_gather_rows(w.H, pool_idx, w.HP, nseq, 3 * W * 2, 3 * W * 2, s));
+        TRY(ofx_launch_gather_rows(w.X, pool_idx, w.XP, nseq, W * 4, W * 4, s));
+        X = w.XP; H = w.HP; U = w.UP; M = nseq;
+    }
+    GemmArgs g2{}; g2.A = H; g2.W = L.w_o; g2.C = X; g2.bias = L.b_o; g2.resid = X; g2.M = M; g2.N = W; g2.K = 3 * W; g2.k_mult = 3; g2.lda = 3 * W;
+    g2.ldc = W; g2.ldr = W; g2.act = OFX_ACT_NONE; g2.out_kind = OFX_OUT_F32;
+    if (pool_idx) { g2.slab = w.slab; g2.slab_bytes = w.slab_bytes; }          // the split-K scratch is sized for the pooled rows
+    TRY(ofx_launch_gemm(g2, dt, s));
+    LnArgs ln2{X, nullptr, L.g2, L.be2, H, M, W, 3 * W, OFX_OUT_SPLIT3, eps};
+    TRY(ofx_launch_layernorm(ln2, dt, s));
+    GemmArgs g3{}; g3.A = H; g3.W = L.w_fc1; g3.C = U; g3.bias = L.b_fc1; g3.M = M; g3.N = MLP; g3.K = 3 * W; g3.k_mult = 3; g3.lda = 3 * W;
+    g3.ldc = 3 * MLP; g3.act = act; g3.out_kind = OFX_OUT_SPLIT3;
+    if (pool_idx) { g3.slab = w.slab; g3.slab_bytes = w.slab_bytes; }
+    TRY(ofx_launch_gemm(g3, dt, s));
+    GemmArgs g4{}; g4.A = U; g4.W = L.w_fc2; g4.C = X; g4.bias = L.b_fc2; g4.resid = X; g4.M = M; g4.N = W; g4.K = 3 * MLP; g4.k_mult = 3;
+    g4.lda = 3 * MLP; g4.ldc = W; g4.ldr = W; g4.act = OFX_ACT_NONE; g4.out_kind = OFX_OUT_F32;
+    if (pool_idx) { g4.slab = w.slab; g4.slab_bytes = w.slab_bytes; }
+    return ofx_launch_gemm(g4, dt, s);
 }
 
 // All layers; the pooled rows end up compacted in w.XP [nseq, W].
 static bool clip_fold(int W) { return g_ln_fold != 0 && W % 64 == 0; }
 static int clip_layers(const std::vector<ClipLayer>& Ls, const ClipWs& w, int rows, int nseq, int S, int W, int MLP,
                        int heads, int act, float eps, int causal, const int64_t* key_mask, int mask_ld, int dt,
-                       const int* pool_idx, hipStream_t s, bool stats_ready = false, bool pool_first = false) {
+                       const int* pool_idx, hipStream_t s, bool stats_ready = false, bool pool_first = false, bool x3 = false) {
+    if (x3) {
+        for (size_t l = 0; l < Ls.size(); ++l)
+            TRY(clip_layer_x3(Ls[l], w, rows, nseq, S, W, MLP, heads, act, eps, causal, key_mask, mask_ld, dt, l + 1 == Ls.size() ? pool_idx : nullptr, s));
+        return OFX_OK;
+    }
     const bool fold = clip_fold(W);
     if (fold && !stats_ready) TRY(ofx_launch_row_stats_cast(w.X, w.XB, w.S, rows, W, eps, dt, s, g_ln_fold == 2 ? w.XLO : nullptr));     // layer 0's LayerNorm-1 inputs
     for (size_t l = 0; l < Ls.size(); ++l)
@@ -675,16 +769,18 @@ static int vit_core(ofx_handle* h, const float* pixels, const RawImages* raw, in
             TRY(ofx_launch_patchify(pixels + (size_t)n0 * px_per_img, w.U, n, d.vit_image, d.vit_patch, dt, s));
         GemmArgs gp{}; gp.A = w.U; gp.W = h->v_patch_w; gp.C = w.QKV; gp.M = n * g * g; gp.N = W; gp.K = KP; gp.lda = KP; gp.ldc = W;
         gp.act = OFX_ACT_NONE; gp.out_kind = OFX_OUT_F32;
+        if (h->v_patch_w2) { gp.W = h->v_patch_w2; gp.K = 2 * KP; gp.a_wrap = KP; }
         TRY(ofx_launch_gemm(gp, dt, s));
         const bool fold = clip_fold(W);                                  // the pre-LN kernel then also emits layer 0's operand copy + statistics
         TRY(ofx_launch_vit_embed_ln((const float*)w.QKV, h->v_cls, h->v_pos, h->v_pre_g, h->v_pre_b, fold && g_ln_fold == 2 ? nullptr : w.X, n, S, W, d.ln_eps, s, fold ? w.XB : nullptr,
                                     fold ? w.S : nullptr, dt, fold && g_ln_fold == 2 ? w.XLO : nullptr));
         TRY(ofx_launch_iota_rows(w.idx, n, S, s));                        // CLS rows
         TRY(clip_layers(h->vl, w, rows, n, S, W, d.vit_mlp, d.vit_heads, d.vit_act, d.ln_eps, 0, nullptr, 0, dt, w.idx, s, fold, true));
-        LnArgs ln{w.XP, nullptr, h->v_post_g, h->v_post_b, w.PL, n, W, W, OFX_OUT_OP, d.ln_eps};
+        const int pk = h->v_proj_w3 ? 3 : 1;          // the output tail in three products: post-LayerNorm rows [hi | lo | hi] x [hi | hi | lo]
+        LnArgs ln{w.XP, nullptr, h->v_post_g, h->v_post_b, w.PL, n, W, pk * W, pk == 3 ? OFX_OUT_SPLIT3 : OFX_OUT_OP, d.ln_eps};
         TRY(ofx_launch_layernorm(ln, dt, s));
-        GemmArgs gj{}; gj.A = w.PL; gj.W = h->v_proj_w; gj.C = w.E; gj.M = n; gj.N = d.proj_dim; gj.K = W; gj.lda = W; gj.ldc = d.proj_dim;
-        gj.act = OFX_ACT_NONE; gj.out_kind = OFX_OUT_F32;
+        GemmArgs gj{}; gj.A = w.PL; gj.W = pk == 3 ? h->v_proj_w3 : h->v_proj_w; gj.C = w.E; gj.M = n; gj.N = d.proj_dim; gj.K = pk * W; gj.k_mult = pk; gj.lda = pk * W; gj.ldc = d.proj_dim;
+        gj.act = OFX_ACT_NONE; gj.out_kind = OFX_OUT_F32; gj.slab = w.slab; gj.slab_bytes = w.slab_bytes;
         TRY(ofx_launch_gemm(gj, dt, s));
         TRY(ofx_launch_l2norm_store(w.E, emb + (size_t)n0 * emb_ld, n, d.proj_dim, emb_ld, emb_col, normalize, s));
     }
@@ -734,11 +830,13 @@ extern "C" int ofx_clip_text_fwd(ofx_handle* h, const int64_t* ids, const int64_
     const int W = d.txt_width, dt = h->tw_dtype, rows = N * Tc;
     TRY(ofx_launch_text_embed(ids, h->t_tok, h->t_pos, w.X, N, T, Tc, W, d.txt_vocab, s));
     TRY(ofx_launch_text_eos_index(ids, w.idx, N, T, Tc, d.txt_eos_id, s));      // EOS rows
-    TRY(clip_layers(h->tl, w, rows, N, Tc, W, d.txt_mlp, d.txt_heads, d.txt_act, d.ln_eps, 1, attn_mask, T, dt, w.idx, s));
-    LnArgs ln{w.XP, nullptr, h->t_fin_g, h->t_fin_b, w.PL, N, W, W, OFX_OUT_OP, d.ln_eps};
+    const bool x3 = h->txt_x3 != 0;
+    const int pk = x3 ? 3 : 1;
+    TRY(clip_layers(h->tl, w, rows, N, Tc, W, d.txt_mlp, d.txt_heads, d.txt_act, d.ln_eps, 1, attn_mask, T, dt, w.idx, s, false, false, x3));
+    LnArgs ln{w.XP, nullptr, h->t_fin_g, h->t_fin_b, w.PL, N, W, pk * W, x3 ? OFX_OUT_SPLIT3 : OFX_OUT_OP, d.ln_eps};
     TRY(ofx_launch_layernorm(ln, dt, s));
-    GemmArgs gj{}; gj.A = w.PL; gj.W = h->t_proj_w; gj.C = w.E; gj.M = N; gj.N = d.proj_dim; gj.K = W; gj.lda = W; gj.ldc = d.proj_dim;
-    gj.act = OFX_ACT_NONE; gj.out_kind = OFX_OUT_F32;
+    GemmArgs gj{}; gj.A = w.PL; gj.W = h->t_proj_w; gj.C = w.E; gj.M = N; gj.N = d.proj_dim; gj.K = pk * W; gj.k_mult = pk; gj.lda = pk * W; gj.ldc = d.proj_dim;
+    gj.act = OFX_ACT_NONE; gj.out_kind = OFX_OUT_F32; gj.slab = w.slab; gj.slab_bytes = w.slab_bytes;
     TRY(ofx_launch_gemm(gj, dt, s));
     return ofx_launch_l2norm_store(w.E, emb, N, d.proj_dim, emb_ld, emb_col, normalize, s);
 }

@@ -24,6 +24,7 @@ struct AttnK {
     const int* cu;          // optional varlen mode (outfit sets): sequence b = rows cu[b] .. cu[b+1], at most 16 * NT of them
     int only_row0;          // varlen mode: compute and store query row 0 only (pruned last layer)
     DropArgs drop;          // varlen mode: attention-probability dropout (row = seq * n_head + head, col = query * 32 + key)
+    int split3_w;           // > 0: output rows are [hi(W) | lo(W) | hi(W)] (the A operand of a three-product K-concatenated GEMM), W = split3_w
 };
 
 constexpr int V_ROW = 160;                 // bytes per V row in LDS (64 x 2 B + 32 pad): tr-read conflict-free
@@ -184,6 +185,13 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(AttnK a) {      
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (T)ot[2 * h + (e >> 2)][u][e & 3];
                     *(v8*)(op + 8 * h) = o;
+                    if (a.split3_w) {                                   // wave-uniform
+                        v8 lo;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) lo[e] = (T)(ot[2 * h + (e >> 2)][u][e & 3] - (float)o[e]);
+                        *(v8*)(op + a.split3_w + 8 * h) = lo;
+                        *(v8*)(op + 2 * a.split3_w + 8 * h) = o;
+                    }
                 }
             }
         }
@@ -198,6 +206,10 @@ struct SetK {
     int nseq, n_head, D, ldo, out_kind, only_row0;
     float scale;
     DropArgs drop;
+    // fixed-length mode (three-product CLIP text tower): cu == nullptr, sequence b = rows b * fixed_S .. + fixed_S, with HF's
+    // causal AND key-padding mask (key_mask [nseq, mask_ld] int64, 0 = ignored)
+    int fixed_S, causal, mask_ld;
+    const int64_t* key_mask;
 };
 
 template <typename T, int SMAX, typename TI = float>      // TI: element type of qkv (float: scoring path; T: training tape)
@@ -208,8 +220,8 @@ __global__ __launch_bounds__(64) void set_attention_kernel(SetK a) {
     __shared__ __attribute__((aligned(16))) float sc[SMAX * (SMAX + 4)];
     const int lane = threadIdx.x;
     const int b = blockIdx.x / a.n_head, h = blockIdx.x % a.n_head;
-    const int r0 = a.cu[b];
-    int S = a.cu[b + 1] - r0;
+    const int r0 = a.cu ? a.cu[b] : b * a.fixed_S;
+    int S = a.cu ? a.cu[b + 1] - r0 : a.fixed_S;
     S = S < SMAX ? S : SMAX;
     const int nq = a.only_row0 ? 1 : S;
     const int D = a.D;
@@ -235,16 +247,19 @@ __global__ __launch_bounds__(64) void set_attention_kernel(SetK a) {
             const f32x4 x = qp[c], y = kp[c];
             d += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
         }
-        sc[i * (SMAX + 4) + j] = d * a.scale;
+        bool dead = a.causal && j > i;
+        if (!dead && a.key_mask) dead = a.key_mask[(size_t)b * a.mask_ld + j] == 0;
+        sc[i * (SMAX + 4) + j] = dead ? -INFINITY : d * a.scale;
     }
     __syncthreads();
     if (lane < nq) {
         float* row = sc + lane * (SMAX + 4);
         float m = -INFINITY;
         for (int j = 0; j < S; ++j) m = fmaxf(m, row[j]);
+        if (m == -INFINITY) m = 0.f;                  // a fully masked query row: probabilities 0 (as the MFMA kernel)
         float sum = 0.f;
         for (int j = 0; j < S; ++j) { const float e = expf(row[j] - m); row[j] = e; sum += e; }
-        const float inv = 1.0f / sum;
+        const float inv = sum > 0.f ? 1.0f / sum : 0.f;
         if (a.drop.thresh) for (int j = 0; j < S; ++j) row[j] *= inv * drop_mul(a.drop, blockIdx.x, lane * 32 + j);
         else for (int j = 0; j < S; ++j) row[j] *= inv;
     }
@@ -499,7 +514,8 @@ int ofx_launch_attention_mfma(const AttnArgs& g, int op_dtype, hipStream_t s) {
     AttnK k;
     k.qkv = (const char*)g.qkv; k.out = (char*)g.out; k.key_mask = g.key_mask; k.nseq = g.nseq; k.S = g.seq_len;
     k.n_head = g.n_head; k.ld = g.ld; k.ldo = g.ldo; k.k_off = g.k_off; k.v_off = g.v_off; k.mask_ld = g.mask_ld;
-    k.causal = g.causal; k.scale = g.scale; k.cu = g.cu_seqlens; k.only_row0 = g.only_row0; k.drop = g.drop;
+    k.causal = g.causal; k.scale = g.scale; k.cu = g.cu_seqlens; k.only_row0 = g.only_row0; k.drop = g.drop; k.split3_w = g.split3_w;
+    OFX_REQUIRE(g.split3_w == 0 || (g.split3_w % 8 == 0 && g.ldo >= 3 * g.split3_w), OFX_ESHAPE, "attention: split3 output needs ldo >= 3 W");
     const int grid = (g.nseq * g.n_head + 3) / 4;
     ProfScope prof(PROF_ATTN, s);
 #define AT(T, N) hipLaunchKernelGGL((attention_mfma_kernel<T, N>), dim3(grid), dim3(256), 0, s, k)
@@ -515,9 +531,11 @@ int ofx_launch_set_attention(const SetAttnArgs& g, int op_dtype, hipStream_t s) 
     OFX_REQUIRE(g.D == g.n_head * 64, OFX_ESHAPE, "set_attention: head_dim must be 64 (D=%d heads=%d)", g.D, g.n_head);
     OFX_REQUIRE(g.max_len >= 1 && g.max_len <= 32, OFX_ESHAPE, "set_attention: 1+items=%d exceeds 32", g.max_len);
     OFX_REQUIRE(g.ldo >= (g.out_kind == 2 ? 3 * g.D : g.D), OFX_ESHAPE, "set_attention: bad ldo=%d", g.ldo);
+    OFX_REQUIRE(g.cu_seqlens || (g.fixed_len >= 1 && g.fixed_len <= g.max_len), OFX_EINVAL, "set_attention: needs cu_seqlens or a fixed length <= max_len");
     SetK k;
     k.qkv = g.qkv; k.out = (char*)g.out; k.cu = g.cu_seqlens; k.nseq = g.nseq; k.n_head = g.n_head; k.D = g.D; k.ldo = g.ldo;
     k.out_kind = g.out_kind; k.only_row0 = g.only_row0; k.scale = g.scale; k.drop = g.drop;
+    k.fixed_S = g.fixed_len; k.causal = g.causal; k.mask_ld = g.mask_ld; k.key_mask = g.key_mask;
     const int grid = g.nseq * g.n_head;
     ProfScope prof(PROF_ATTN, s);
 #define SA(T, N) do { if (g.qkv_op) hipLaunchKernelGGL((set_attention_kernel<T, N, T>), dim3(grid), dim3(64), 0, s, k); \

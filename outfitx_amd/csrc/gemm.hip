@@ -253,6 +253,9 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
     }
     if ((kind == 2 || kind == 4) && g.N % 256) kind = 1;
     if (kind == 5 && g.N % 128) kind = 1;
+    // record label: logical shape (K without the split-weight / three-product concatenation), the K multiplier and
+    // kernel kind (1 128x128 [+ split-K / 64-row variants], 2 256x256, 3 256x128, 4 256x256 ping-pong, 6 dual-weight 256x256)
+    if (g_ofx_prof_on) { const int km = g.a_wrap ? g.K / g.a_wrap : (g.k_mult > 0 ? g.k_mult : 1); ofx_prof_set_tag(g.M, g.N, g.K / km, kind, km); }
     ProfScope prof(PROF_GEMM, s, 2.0 * g.M * g.N * g.K, true);      // events ride on the launches (OFX_PLAUNCH)
     if (kind == 2 || kind == 3 || kind == 4 || kind == 6) {
         k.group_m = g_gemm_group_m > 0 ? g_gemm_group_m : (kind == 3 ? 4 : 8);

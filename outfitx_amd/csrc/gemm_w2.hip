@@ -9,12 +9,12 @@
 // Structure (the ping-pong kernel's, gemm_pp.hip, at BK = 32 with three 48 KiB stages):
 //   waves 0-3 (group 0, rows 0-127) and 4-7 (group 1) run the same per-step program offset by ONE barrier slot: on every SIMD
 //   one wave reads its 16 fragments while the other runs its 64 MFMAs and issues its 6 LDS-DMA pieces of a later step.
-//     slot:      0     1      2        3        4        5
-//     group 0:  [W0]  [R0]   [M0 I2]  [R1]     [M1 I3]  [R2]    ...   I(s) = issue step s into stage s % 3
-//     group 1:  [W0]  [  ]   [R0]     [M0 I3]  [R1]     [M1 I4] ...
-//   Step s is read in slots 2s+1 (group 0) and 2s+2 (group 1); its stage is refilled with step s+3 from slot 2s+3 on (WAR: two
-//   barriers later for both groups).  Every wave waits for its own pieces of step s (counted vmcnt(6): the youngest step stays in
-//   flight) at the end of slot 2s, before the barrier that opens slot 2s+1 (RAW).
+//     slot:      0     1         2         3         4         5
+//     group 0:  [W0]  [R0 I2]   [M0]      [R1 I3]   [M1]      [R2 I4]  ...   I(s) = issue step s into stage s % 3
+//     group 1:  [W0]  [  ]      [R0 I2]   [M0]      [R1 I3]   [M1]     ...
+//   Step s is read in slots 2s+1 (group 0) and 2s+2 (group 1); its stage is refilled with step s+3 in slots 2s+3 / 2s+4 (WAR: both
+//   groups' reads ended before the barrier that closes slot 2s+2).  Every wave waits for its own pieces of step s (counted
+//   vmcnt(6): the youngest step stays in flight) before the barrier that closes slot 2s; step s is first read in slot 2s+1 (RAW).
 // LDS image of a stage: [A 256 rows | W_hi 256 rows | W_lo 256 rows] x 64 B; a wave-instruction moves 16 rows x 64 B; the 16-B
 // chunk c of row r sits at slot c ^ f(r >> 2), f(g) = (-g) & 3, applied on the DMA source address and on the ds_read_b128 side:
 // conflict-free for the hardware's lane groups of ds_read_b128 (MI355X_MICROARCH.md, LDS table).
@@ -103,53 +103,48 @@ __global__ __launch_bounds__(512, 2) void gemm_w2_kernel(KArgs p) {
         _Pragma("unroll") for (int i = 0; i < 8; ++i) af[i] = *(OFX_LDS v8*)(base_ + a_frag + i * 16 * 64);   \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) wl[j] = *(OFX_LDS v8*)(base_ + PART + w_frag + j * 16 * 64); \
     }
-    // 64 MFMAs (per A fragment: 4 hi then 4 lo) with the 6 pieces of step ISTEP threaded through, one per 10 MFMAs
-#define OFX_W2_MFMA(ISTEP)                                                                                   \
+    // 64 MFMAs (per A fragment: 4 hi then 4 lo): nothing else in the stream - the LDS-DMA pieces are issued from the READ slots,
+    // where the wave would otherwise wait for its fragments (an LDS-DMA issue costs the issuing wave ~100 cycles; threaded through
+    // the MFMAs it cost 0.3 us of every 0.8 us slot)
+#define OFX_W2_MFMA()                                                                                        \
     {                                                                                                        \
-        const int is_ = (ISTEP);                                                                             \
-        const int sc_ = is_ < nk ? is_ : nk - 1;                                                             \
-        OFX_LDS char* nb_ = lds + (is_ % NST) * STAGE;                                                       \
-        const char* ak_ = a_base + (size_t)sc_ * BK2 * 2;                                                    \
-        const char* wk_ = w_base + (size_t)sc_ * BK2 * 2;                                                    \
         __builtin_amdgcn_s_setprio(1);                                                                       \
         _Pragma("unroll") for (int m = 0; m < 64; ++m) {                                                     \
-            if (m % 10 == 0 && m / 10 < 6) OFX_W2_PIECE(m / 10, ak_, wk_, nb_)                               \
             const int i = (m >> 3) & 7, j = m & 3;                                                           \
             acc[i][j] = OpT<T>::mfma16((m & 4) ? wl[j] : wh[j], af[i], acc[i][j]);                           \
         }                                                                                                    \
         __builtin_amdgcn_s_setprio(0);                                                                       \
     }
 
+    issue_all(0); issue_all(1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            // step 0 landed (my pieces)
+    __builtin_amdgcn_s_barrier();                               // ---- end of slot 0
     if (wr == 0) {
-        issue_all(0); issue_all(1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");        // step 0 landed (my pieces)
-        __builtin_amdgcn_s_barrier();                           // ---- end of slot 0
         for (int t = 0; t < nk; ++t) {
-            // slot 2t+1: read step t
+            // slot 2t+1: read step t; refill the stage of step t-1 (group 1 read it in slot 2t) with step t+2
             OFX_W2_READ(t % NST)
+            issue_all(t + 2);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
-            // slot 2t+2: multiply step t, issue step t+2 (its stage held step t-1: read by group 1 in slot 2t)
-            OFX_W2_MFMA(t + 2)
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // my pieces of step t+1 landed
+            // slot 2t+2: multiply step t
+            OFX_W2_MFMA()
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // my pieces of step t+1 landed (step t+2 stays in flight)
             __builtin_amdgcn_s_barrier();
         }
         __builtin_amdgcn_s_barrier();                           // group 1's last MFMA slot
     } else {
-        issue_all(0); issue_all(1); issue_all(2);
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                           // ---- end of slot 0
         __builtin_amdgcn_s_barrier();                           // slot 1: group 0 reads step 0
         for (int t = 0; t < nk; ++t) {
-            // slot 2t+2: read step t
+            // slot 2t+2: read step t; refill the stage of step t-1 (read by group 0 in slot 2t-1, by this group in slot 2t)
             OFX_W2_READ(t % NST)
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // my pieces of step t+1 landed (step t+2 stays in flight)
+            issue_all(t + 2);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // my pieces of step t+1 landed: group 0 reads them in slot 2t+3
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
-            // slot 2t+3: multiply step t, issue step t+3 into the stage both groups have just read
-            OFX_W2_MFMA(t + 3)
+            // slot 2t+3: multiply step t
+            OFX_W2_MFMA()
             __builtin_amdgcn_s_barrier();
         }
     }

@@ -129,6 +129,7 @@ extern bool g_ofx_prof_on;
 extern int g_ofx_prof_mask;   // bit per category
 void ofx_prof_begin(int cat, hipStream_t s, double flops);
 void ofx_prof_end(hipStream_t s);
+void ofx_prof_set_tag(int M, int N, int K, int kind, int kmul);      // labels the NEXT record (GEMM dispatcher: shape and kernel kind)
 // ext = true: nothing is recorded on the stream; the scope's launches carry the two events themselves (OFX_PLAUNCH ->
 // hipExtLaunchKernelGGL start / stop events: the timestamps come from the dispatch packet's completion signal, so no marker
 // packets are put between the kernels).  The first launch of the scope takes the start event, the one flagged `last` the stop.
@@ -241,6 +242,7 @@ struct GemmArgs {
     // ---- split weights against ONE copy of A ("W2"): W = [N, K] with K = 2 a_wrap, row n = [hi(a_wrap) | lo(a_wrap)]; A is
     // [M, a_wrap] and its k index wraps, so C = A . (hi + lo)^T: ~22 significant weight bits for two MFMA products
     int a_wrap = 0;
+    int k_mult = 1;     // informational (profile records): K = k_mult x the logical depth (3: three-product K-concatenation; a_wrap implies 2)
 };
 int ofx_launch_gemm(const GemmArgs& g, int op_dtype /*OFX_BF16|OFX_F16*/, hipStream_t s);
 int ofx_gemm_splitk_plan(int M, int N, int K);
@@ -301,6 +303,7 @@ struct AttnArgs {
     const int* cu_seqlens = nullptr;
     int only_row0 = 0;
     DropArgs drop;
+    int split3_w = 0;         // > 0: out rows are [hi(W) | lo(W) | hi(W)], W = split3_w, ldo >= 3 W (A operand of a three-product GEMM)
 };
 int ofx_launch_attention_mfma(const AttnArgs& a, int op_dtype, hipStream_t s);
 
@@ -314,5 +317,8 @@ struct SetAttnArgs {
     float scale;
     DropArgs drop;         // attention-probability dropout (row = set * n_head + head, col = query * 32 + key)
     int qkv_op = 0;
+    // fixed-length mode (cu_seqlens == nullptr): every sequence has fixed_len <= 32 rows; optional causal AND key-padding mask
+    int fixed_len = 0, causal = 0, mask_ld = 0;
+    const int64_t* key_mask = nullptr;
 };
 int ofx_launch_set_attention(const SetAttnArgs& a, int op_dtype, hipStream_t s);

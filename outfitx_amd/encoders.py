@@ -214,7 +214,7 @@ class _TowerBase(nn.Module):
     def __init__(self):
         super().__init__()
         self._engines: Dict[Any, Engine] = {}
-        self.tower_precision = "bf16"
+        self.tower_precision = L.DEFAULT_TOWER_PRECISION
 
     @property
     def device(self) -> torch.device:

@@ -159,7 +159,7 @@ class OutfitX(nn.Module):
     Tasks = TypeVar("Tasks", OutfitComplementaryItemRetrievalTask, OutfitCompatibilityPredictionTask,
                     OutfitFillInTheBlankTask, OutfitPrecomputeEmbeddingTask)
 
-    def __init__(self, cfg: Optional[OutfitXConfig] = None, precision: str = "bf16x3", tower_precision: str = "bf16",
+    def __init__(self, cfg: Optional[OutfitXConfig] = None, precision: str = "bf16x3", tower_precision: str = L.DEFAULT_TOWER_PRECISION,
                  train_precision: str = "bf16"):
         super().__init__()
         self.cfg = cfg if cfg is not None else OutfitXConfig()
@@ -188,10 +188,11 @@ class OutfitX(nn.Module):
         # three-product bf16x3 scheme (kept for precomputed fp32 embeddings, where it holds 1e-5) buys nothing there; one f16
         # product (2^-12) is below the bf16 towers' input error and a third of the GEMM work (end-to-end error vs the oracle
         # unchanged at 5-7e-3, step 25.64 -> 24.98 ms; with f16 towers it would double 4e-4 to 8e-4, so it applies to bf16
-        # towers only).  None = always self.precision.
+        # towers only: the default 'f16w2' towers and plain 'f16' keep bf16x3).  None = always self.precision.
         self.tower_fed_precision: Optional[str] = "f16"
         _LIVE_MODELS.add(self)
-        self.train_precision = train_precision      # operand format of the training step (the reference trains under bf16 autocast)
+        self.train_precision = train_precision      # operand format of the training step (the reference trains under fp16 autocast on CUDA,
+                                                    # compatibility_prediction_trainer.py:63; bf16 has the same 8-bit-or-better products and fp32's range)
         self.item_encoder.set_precision(tower_precision)
         self._engines: Dict[Any, Engine] = {}
 

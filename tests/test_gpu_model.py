@@ -4,8 +4,9 @@ size-independent properties at BASELINE.json's full sizes.
 
 Tolerances (metric: max|Δ| / max|ref| over the batch, as DESIGN.md states):
   outfit transformer, precision 'bf16x3' (default)  : 1e-3   (north-star bound; measured ~1e-5)
-  outfit transformer, 'f16' / 'bf16' single product : 3e-3 / 3e-2  (operand-rounding floor)
-  CLIP towers 'bf16' / 'f16'                         : 3e-2 / 4e-3
+  outfit transformer, 'f16' / 'bf16' single product : 3e-3 / 3e-2  (operand-rounding floor; secondary modes)
+  CLIP towers, scheme 'f16w2' (DEFAULT, what bench.py runs): 1e-3 at the tower outputs AND end to end on the CP logit (five weight seeds)
+  CLIP towers 'f16' / 'bf16' single product          : 4e-3 / 3e-2  (secondary, faster modes: they do not meet the north star's 1e-3)
   argmin / top-k indices                             : bit-exact
 """
 import warnings
@@ -15,6 +16,7 @@ import pytest
 import torch
 
 from conftest import W_SEED, golden, rel_err
+from outfitx_amd._lib import DEFAULT_TOWER_PRECISION as DEFAULT_TOWERS
 from oracle import np_oracle as O
 from outfitx_amd import synth
 
@@ -103,20 +105,21 @@ def test_vit_tower_vs_reference_golden(model):
     g = golden("vit_n4")
     px = synth.pixel_values(int(g["seed"]), 4)
     enc = model.item_encoder.image_enc
-    for prec, tol in (("bf16", 3e-2), ("f16", 4e-3)):
+    assert enc.tower_precision == DEFAULT_TOWERS == "f16w2"
+    for prec, tol in ((DEFAULT_TOWERS, 1e-3), ("bf16", 3e-2), ("f16", 4e-3)):      # the default scheme holds the north star's bound
         enc.tower_precision = prec
         out = enc(cu(px).view(4, 1, 3, 224, 224), normalize=False).view(4, 512)
         e = rel_err(out.cpu().numpy(), g["image_embeds"])
         print(f"vit {prec}: {e:.2e}")
         assert e < tol
-    enc.tower_precision = "bf16"
+    enc.tower_precision = DEFAULT_TOWERS
 
 
 def test_text_tower_vs_reference_golden(model):
     g = golden("text_n8")
     ids, att = synth.token_batch(int(g["seed"]), 8, 64, g["n_real"])
     enc = model.item_encoder.text_enc
-    for prec, tol in (("bf16", 3e-2), ("f16", 4e-3)):
+    for prec, tol in ((DEFAULT_TOWERS, 1e-3), ("bf16", 3e-2), ("f16", 4e-3)):
         enc.tower_precision = prec
         dev_in = {"input_ids": cu(ids).view(8, 1, 64), "attention_mask": cu(att).view(8, 1, 64)}      # ids on device: all T tokens computed
         host_in = {"input_ids": torch.from_numpy(ids).view(8, 1, 64), "attention_mask": torch.from_numpy(att).view(8, 1, 64)}
@@ -124,7 +127,7 @@ def test_text_tower_vs_reference_golden(model):
         b = enc(host_in, normalize=False).view(8, 512).cpu().numpy()                                   # ids on host: truncated at EOS
         print(f"text {prec}: {rel_err(a, g['text_embeds']):.2e} / {rel_err(b, g['text_embeds']):.2e}")
         assert rel_err(a, g["text_embeds"]) < tol and rel_err(b, g["text_embeds"]) < tol
-    enc.tower_precision = "bf16"
+    enc.tower_precision = DEFAULT_TOWERS
 
 
 def test_item_encoder_cp_with_encoder_and_precompute(model):
@@ -134,23 +137,21 @@ def test_item_encoder_cp_with_encoder_and_precompute(model):
     px = synth.pixel_values(1239, B * L).reshape(B, L, 3, 224, 224)
     ids, att = synth.token_batch(1239, B * L, 64, np.array([4, 8, 6, 3, 9, 12]))
     texts = {"input_ids": torch.from_numpy(ids).view(B, L, 64), "attention_mask": torch.from_numpy(att).view(B, L, 64)}
-    model.item_encoder.set_precision("f16")
-    with torch.no_grad():
+    with torch.no_grad():                                       # default tower scheme (f16w2): the north star's 1e-3 throughout
         items = model.item_encoder(cu(px), texts)
         cp = model(task=CP, outfit_embedding=None, outfit_mask=cu(g["mask"]), encoder_input_dict={"images": cu(px), "texts": texts})
         pe = model(task=PE, images=cu(px[:, :1]), texts={k: v[:, :1] for k, v in texts.items()})
         model.item_encoder.cfg.aggregation_method = "mean"
         mean = model.item_encoder(cu(px), texts)
         model.item_encoder.cfg.aggregation_method = "concat"
-    model.item_encoder.set_precision("bf16")
     assert items.shape == (B, L, 1024)
-    assert rel_err(items.cpu().numpy(), g["item_emb"]) < 4e-3
+    assert rel_err(items.cpu().numpy(), g["item_emb"]) < 1e-3
     h = items.view(B, L, 2, 512).norm(dim=-1).cpu().numpy()
     assert np.abs(h - 1).max() < 1e-5                          # each modality half is unit-norm
-    assert rel_err(cp.cpu().numpy(), g["cp_logits"]) < 2e-2
-    assert rel_err(pe.cpu().numpy(), g["precomputed"]) < 4e-3
+    assert rel_err(cp.cpu().numpy(), g["cp_logits"]) < 1e-3
+    assert rel_err(pe.cpu().numpy(), g["precomputed"]) < 1e-3
     assert tuple(mean.shape) == g["items_mean"].shape           # the reference's literal 'mean' semantics
-    assert rel_err(mean.cpu().numpy(), g["items_mean"]) < 4e-3
+    assert rel_err(mean.cpu().numpy(), g["items_mean"]) < 1e-3
     with pytest.raises(ValueError):
         model.item_encoder([[np.zeros((224, 224, 3), np.uint8)], []], texts)
 
@@ -465,7 +466,7 @@ def test_hi_lo_residual_stream_matches_the_fp32_one(model):
                     ref = ref / np.linalg.norm(ref, axis=-1, keepdims=True)
                     assert rel_err(outs[0][0].reshape(3, -1), ref) < 3e-2
         finally:
-            enc.set_precision("bf16")
+            enc.set_precision(DEFAULT_TOWERS)
 
 
 def test_layernorm_folding_matches_the_materialised_path(model):
@@ -546,6 +547,8 @@ def test_set_transformer_precision_follows_the_embedding_source(model):
     ids, att = synth.token_batch(77, B * L, 64, 8)
     texts = {"input_ids": torch.from_numpy(ids).view(B, L, 64), "attention_mask": torch.from_numpy(att).view(B, L, 64)}
     mask = np.zeros((B, L), bool)
+    assert model._tower_fed() is None                      # default towers (f16w2): the set transformer stays bf16x3
+    model.item_encoder.set_precision("bf16")
     assert model.tower_fed_precision == "f16" and model._tower_fed() == "f16"
     with torch.no_grad():
         a = model(task=CP, outfit_embedding=None, outfit_mask=cu(mask), encoder_input_dict={"images": cu(px), "texts": texts}).cpu().numpy()
@@ -559,9 +562,44 @@ def test_set_transformer_precision_follows_the_embedding_source(model):
         try:
             assert model._tower_fed() is None              # f16 towers: the set transformer's own f16 error would show
         finally:
-            model.item_encoder.set_precision("bf16")
+            model.item_encoder.set_precision(DEFAULT_TOWERS)
     ref = O.cp_forward(O.item_encoder(px, ids.reshape(B, L, 64), att.reshape(B, L, 64), synth.vision_weights(W_SEED), synth.text_weights(W_SEED)),
                        mask, synth.outfit_transformer_weights(W_SEED))
     assert not np.array_equal(a, b)
     assert rel_err(a, b) < 3e-3
     assert rel_err(a, ref) < 3e-2 and rel_err(b, ref) < 3e-2
+
+
+@pytest.mark.parametrize("wseed", [1, 2, 3, 4, 5, 6])
+def test_cfg2_end_to_end_within_1e3_on_every_weight_seed(wseed):
+    """BASELINE configs[1] end to end (images + token ids -> towers -> fuser -> set transformer -> CP logit) in the DEFAULT operand
+    scheme - the one bench.py measures - against the fp32 oracle O.cp_forward(O.item_encoder(...)), on six independent weight
+    draws (the error is dominated by a fixed, per-weight-set perturbation, so the seed, not the input batch, is what varies it;
+    seed 6 is the worst of the twelve the CPU emulation tests/studies/operand_scheme_cpu.py scanned).  Bound: the north star's
+    1e-3 on max|d| / max|ref| over the batch (8 outfits x 8 items, texts padded to 64 tokens as the reference feeds them)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    from src.models import OutfitX
+    from src.models.configs import ItemEncoderConfig, OutfitXConfig
+    CP = tasks()[0]
+    m = OutfitX(OutfitXConfig(item_encoder=ItemEncoderConfig(type="clip")))
+    assert m.item_encoder.image_enc.tower_precision == DEFAULT_TOWERS and m.precision == "bf16x3"
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.full_state_dict(wseed).items()}, strict=True)
+    m = m.cuda().eval()
+    B, L = 8, 8
+    g = torch.Generator(); g.manual_seed(9000 + wseed)
+    u8 = torch.randint(0, 256, (B, L, 3, 224, 224), generator=g, dtype=torch.uint8)
+    mean = torch.tensor(synth.CLIP_MEAN).view(1, 1, 3, 1, 1); std = torch.tensor(synth.CLIP_STD).view(1, 1, 3, 1, 1)
+    px = ((u8.float() * (1 / 255.0) - mean) / std).contiguous()
+    ids, att = synth.token_batch(9000 + wseed, B * L, 64, 8)
+    texts = {"input_ids": torch.from_numpy(ids).view(B, L, 64), "attention_mask": torch.from_numpy(att).view(B, L, 64)}
+    mask = np.zeros((B, L), bool)
+    with torch.no_grad():
+        got = m(task=CP, outfit_embedding=None, outfit_mask=cu(mask), encoder_input_dict={"images": px.cuda(), "texts": texts}).cpu().numpy()
+    emb = O.item_encoder(px.numpy(), ids.reshape(B, L, 64), att.reshape(B, L, 64), synth.vision_weights(wseed), synth.text_weights(wseed))
+    ref = O.cp_forward(emb, mask, synth.outfit_transformer_weights(wseed))
+    e = rel_err(got, ref)
+    print(f"cfg2 end to end, weight seed {wseed}: {e:.2e}")
+    assert e < 1e-3, e
+    del m
+    torch.cuda.empty_cache()

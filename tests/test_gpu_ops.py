@@ -74,7 +74,7 @@ def test_gemm_split_weights(force, dt, M, N, K):
     and the 128x128 kernel with a wrapping A index; exact arithmetic on the rounded operands, fp32 accumulation."""
     g = np.random.default_rng(M + 3 * N + K)
     A = to_op(g.standard_normal((M, K), dtype=np.float32), dt)
-    W2, Wv = _split_w(g.standard_normal((N, K), dtype=np.float32) / np.sqrt(K), dt)
+    W2, Wv = _split_w((g.standard_normal((N, K), dtype=np.float32) / np.float32(np.sqrt(K))).astype(np.float32), dt)
     bias = dev(g.standard_normal(N, dtype=np.float32))
     res = dev(g.standard_normal((M, N), dtype=np.float32))
     out = torch.full((M, N), float("nan"), device="cuda")

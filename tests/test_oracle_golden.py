@@ -78,6 +78,39 @@ def test_item_encoder_and_cp_with_encoder(ot_weights, vit_weights, txt_weights):
         O.aggregate_embeddings(items, items, "sum")
 
 
+def test_torch_restatement_is_pinned_to_the_reference_goldens(ot_weights, vit_weights, txt_weights):
+    """oracle/torch_ref.py (the plain-PyTorch fp32 restatement bench.py times as the CPU baseline) against the same golden
+    vectors: CP logits (padded and ragged sets), both towers, the fused item encoder + CP path."""
+    import torch
+    from oracle import torch_ref as T
+    for tag in ("ot_cfg1", "ot_ragged"):
+        g = golden(tag)
+        B, seed = int(g["B"]), int(g["seed"])
+        n = g["n_items"] if g["n_items"].ndim else int(g["n_items"])
+        emb, mask = synth.outfit_batch(seed, B, 16, n)
+        with torch.no_grad():
+            cp = T.TorchRef(ot_weights).cp(torch.from_numpy(emb), torch.from_numpy(mask)).numpy()
+        assert rel_err(cp, g["cp_logits"]) < TOL
+    g = golden("vit_n4")
+    with torch.no_grad():
+        out = T.TorchRef(vit_weights).vit(torch.from_numpy(synth.pixel_values(int(g["seed"]), 4))).numpy()
+    assert rel_err(out, g["image_embeds"]) < TOL
+    g = golden("text_n8")
+    ids, att = synth.token_batch(int(g["seed"]), 8, 64, g["n_real"])
+    with torch.no_grad():
+        out = T.TorchRef(txt_weights).text(torch.from_numpy(ids), torch.from_numpy(att)).numpy()
+    assert rel_err(out, g["text_embeds"]) < TOL
+    g = golden("item_encoder")
+    B, L = 2, 3
+    px = synth.pixel_values(1239, B * L).reshape(B, L, 3, 224, 224)
+    ids, att = synth.token_batch(1239, B * L, 64, np.array([4, 8, 6, 3, 9, 12]))
+    with torch.no_grad():
+        items = T.item_encoder(T.TorchRef(vit_weights), T.TorchRef(txt_weights), torch.from_numpy(px), torch.from_numpy(ids).view(B, L, 64),
+                               torch.from_numpy(att).view(B, L, 64))
+        cp = T.TorchRef(ot_weights).cp(items, torch.from_numpy(g["mask"])).numpy()
+    assert rel_err(items.numpy(), g["item_emb"]) < TOL and rel_err(cp, g["cp_logits"]) < 5e-5
+
+
 def test_scoring():
     g = golden("scoring")
     y = (synth.item_embeddings(1240, "y_hat", 64) * 3.0).astype(np.float32)

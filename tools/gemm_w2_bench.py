@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Split-weight GEMM micro-benchmark on the ViT shapes: single product vs the dual-weight kernel vs the 128x128 kernel with a
+wrapping A index, interleaved rounds in one process, random f16 data.   python tools/gemm_w2_bench.py [name-filter ...]"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from outfitx_amd import _lib as L
+
+SHAPES = [("vit out", 102400, 768, 768, "r"), ("vit fc2", 102400, 768, 3072, "r"), ("patch", 100352, 768, 3072, "f"),
+          ("vit qkv", 102400, 2304, 768, "b"), ("vit fc1", 102400, 3072, 768, "g")]
+
+
+def main():
+    lib = L.load()
+    only = sys.argv[1:]
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    for name, M, N, K, ep in SHAPES:
+        if only and not any(o in name for o in only):
+            continue
+        A = torch.randn(M, K, device="cuda", generator=g).half()
+        Wf = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+        W = Wf.half()
+        W2 = torch.empty(N, 2 * K, device="cuda", dtype=torch.float16)
+        L.check(lib.ofx_convert(Wf.data_ptr(), W2.data_ptr(), N, K, 3, 2, s))
+        C = torch.empty(M, N, device="cuda", dtype=torch.float16 if ep in "bg" else torch.float32)
+        if ep == "r":
+            C.normal_(generator=g)
+        bias = torch.randn(N, device="cuda", generator=g)
+        resid = C.data_ptr() if ep == "r" else None
+        act, okind = (1 if ep == "g" else 0), (1 if ep in "bg" else 0)
+        runs = {"x1": lambda: lib.ofx_gemm(A.data_ptr(), W.data_ptr(), C.data_ptr(), bias.data_ptr(), resid, M, N, K, K, N, N, act, okind, 2, s),
+                "w2": lambda: lib.ofx_gemm_w2(A.data_ptr(), W2.data_ptr(), C.data_ptr(), bias.data_ptr(), resid, M, N, K, K, N, N, act, okind, 2, s)}
+        res = {k: [] for k in runs}
+        for rnd in range(6):
+            for k, fn in runs.items():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    L.check(fn())
+                e1.record(); e1.synchronize()
+                if rnd:
+                    res[k].append(e0.elapsed_time(e1) / 5)
+        t1, t2 = np.median(res["x1"]), np.median(res["w2"])
+        print(f"{name:8s} M={M} N={N} K={K} ep={ep} | x1 {t1*1e3:7.1f} us {2*M*N*K/t1/1e9:6.0f} TF | w2 {t2*1e3:7.1f} us "
+              f"{2*M*N*K/t2/1e9:6.0f} TF useful, {4*M*N*K/t2/1e9:6.0f} TF executed | w2/x1 {t2/t1:.2f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
