@@ -487,9 +487,10 @@ def test_layernorm_folding_matches_the_materialised_path(model):
                     outs.append((enc.image_enc(px).cpu().numpy(), enc.text_enc(tok).cpu().numpy()))
             finally:
                 lib.ofx_tune(6, 2)
-        for a, b in zip(*outs):
-            assert not np.array_equal(a, b)                  # the two paths really differ in rounding
-            assert rel_err(a, b) < 2e-2
+        for i, (a, b) in enumerate(zip(*outs)):
+            # the two paths really differ in rounding - in the ViT; the default scheme's three-product text tower never folds
+            assert (not np.array_equal(a, b)) if i == 0 else np.array_equal(a, b)
+            assert rel_err(a, b) < 2e-3
 
 
 def test_text_dedup_runs_the_tower_on_distinct_rows_only(model):
