@@ -245,7 +245,8 @@ def main():
         executed = fl[0] / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         # per-shape table of the sampled step: shape -> kernel -> launches, us per launch, useful TF/s (2 M N K_logical) and its
         # fraction of the dense peak, executed TF/s (x kmul: split weights run 2, three-product GEMMs 3 MFMA products per term)
-        KIND = {1: "gemm_128x128_kernel", 2: "gemm_big_kernel<2,4,2>", 3: "gemm_big_kernel<2,2,1>", 4: "gemm_pp_kernel", 6: "gemm_w2_kernel"}
+        KIND = {1: "gemm_128x128_kernel", 2: "gemm_big_kernel<2,4,2>", 3: "gemm_big_kernel<2,2,1>", 4: "gemm_pp_kernel", 6: "gemm_w2_kernel",
+                7: "fused_qkv_attn_kernel (N = q|k|v columns; its attention FLOPs are not in useful_tflops)"}
         shapes = {}
         for i in range(nrec):
             r = recs[i]

@@ -232,7 +232,8 @@ int ofx_profile_records(ofx_prof_record* out, int cap);
 /* Process-wide tuning knobs (benchmarks / tests only).  knob 0: GEMM rasterisation group (row panels per L2 group, default 8);
  * knob 6: 2 (default) folds the CLIP towers' LayerNorms into the neighbouring GEMM epilogues AND keeps their residual stream as an
  * operand-type (hi, lo) pair updated in place (no fp32 stream between the layers), 1 folds with an fp32 stream, 0 materialises them;
- * knob 8: 1 (default) the ViT's last layer computes queries for the CLS rows only, 0 runs the full QKV GEMM. */
+ * knob 8: 1 (default) the ViT's last layer computes queries for the CLS rows only, 0 runs the full QKV GEMM;
+ * knob 9: 1 (default) the ViT's layers run the fused QKV-projection + attention kernel, 0 the GEMM -> HBM -> attention-kernel pair. */
 int ofx_tune(int knob, int value);
 /* Diagnostics: when buf != NULL the big-tile GEMM writes {shader cycles, 100 MHz ticks} of its main loop per block (16 B each). */
 void ofx_debug_gemm_clock(void* buf);
@@ -262,6 +263,12 @@ int ofx_attention(const void* qkv, void* out, const int64_t* key_mask, int nseq,
 int ofx_set_attention(const float* qkv, void* out, const int* cu_seqlens, int nseq, int n_head, int D, int ldo,
                       int out_kind, int max_len, int only_row0, float scale, int op_dtype, ofx_stream stream);
 /* fp32 [rows, cols] -> operand type; mode 0 plain, 1 [hi|lo|hi] (activation split), 2 [hi|hi|lo] (weight split) */
+/* Fused QKV projection + scaled-dot-product attention of a CLIP ViT layer (HF CLIPAttention's q/k/v_proj + softmax(q k^T * scale) v,
+ * reached from clip_image_encoder.py:74-76), q | k | v staged in LDS only: X [nseq * seq_len, ldx] operand type, Wqkv [3 width, width]
+ * (q | k | v rows), bias [3 width]; optional LayerNorm-fold consumer inputs row_stat [rows, 2] (mean, rstd) + col_sum [3 width];
+ * out [nseq * seq_len, ldo] operand type (heads concatenated).  seq_len in [33, 64], width = n_head * 64, no mask.  X and out must not alias. */
+int ofx_fused_qkv_attention(const void* X, const void* Wqkv, const float* bias, const float* row_stat, const float* col_sum, void* out,
+                            int nseq, int seq_len, int width, int n_head, int ldx, int ldo, float scale, int op_dtype, ofx_stream stream);
 int ofx_convert(const float* src, void* dst, int rows, int cols, int mode, int op_dtype, ofx_stream stream);
 
 #ifdef __cplusplus

@@ -603,6 +603,9 @@ extern "C" int ofx_cir_prefix(ofx_handle* h, const float* txt, int B, float* out
 // ------------------------------------------------------------------------------------ CLIP towers
 // One CLIP encoder layer on `rows` rows.  When `pool_idx` is given (last layer) everything after the attention
 // runs only on the n pooled rows (CLS / EOS): they are the only ones the tower's output depends on.
+int g_fuse_qkv = 1;     // ofx_tune(9, v): 1 = ViT layers run the fused QKV-projection + attention kernel (q | k | v stay in LDS), 0 = GEMM -> HBM -> attention kernel
+int ofx_launch_fused_qkv_attn(const void* X, const void* Wqkv, const float* bias, const float* row_stat, const float* col_sum, void* out,
+                              int n_img, int S, int Wm, int heads, int ldx, int ldo, float scale, int op_dtype, hipStream_t s);
 int g_prune_q = 1;      // ofx_tune(8, v): 1 = the ViT's last layer computes queries for the CLS rows only
 int g_ln_fold = 2;      // ofx_tune(6, v) (default 2): 0 = materialise every LayerNorm, 1 = fold the towers' LayerNorms into the GEMM epilogues,
                         // 2 = fold AND keep the residual stream as an operand-type (hi, lo) pair (no fp32 stream between the layers)
@@ -612,16 +615,29 @@ int g_ln_fold = 2;      // ofx_tune(6, v) (default 2): 0 = materialise every Lay
 static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, int S, int W, int MLP, int heads, int act,
                       float eps, int causal, const int64_t* key_mask, int mask_ld, int dt, const int* pool_idx, hipStream_t s, bool fold = false,
                       bool pool_first = false) {
+    // fused QKV projection + attention (non-pooled ViT layers: one 33..64-token tile per sequence, no mask): q | k | v never reach HBM
+    const bool fused = g_fuse_qkv && !pool_idx && !causal && !key_mask && S >= 33 && S <= 64;
+    if (fused) {
+        if (fold) {
+            TRY(ofx_launch_fused_qkv_attn(w.XB, L.w_qkv_f, L.bf_qkv, w.S, L.cs_qkv, w.H, nseq, S, W, heads, W, W, 0.125f, dt, s));
+        } else {
+            LnArgs ln{w.X, nullptr, L.g1, L.be1, w.U, rows, W, W, OFX_OUT_OP, eps};        // the MLP buffer is idle here; the kernel must not read what it writes
+            TRY(ofx_launch_layernorm(ln, dt, s));
+            TRY(ofx_launch_fused_qkv_attn(w.U, L.w_qkv, L.b_qkv, nullptr, nullptr, w.H, nseq, S, W, heads, W, W, 0.125f, dt, s));
+        }
+    }
     GemmArgs g1{}; g1.C = w.QKV; g1.M = rows; g1.N = 3 * W; g1.K = W; g1.lda = W;
     g1.ldc = 3 * W; g1.act = OFX_ACT_NONE; g1.out_kind = OFX_OUT_OP;
-    if (fold) {
+    if (fused) {
+    } else if (fold) {
         g1.A = w.XB; g1.W = L.w_qkv_f; g1.bias = L.bf_qkv; g1.row_stat = w.S; g1.col_sum = L.cs_qkv;
     } else {
         LnArgs ln{w.X, nullptr, L.g1, L.be1, w.H, rows, W, W, OFX_OUT_OP, eps};
         TRY(ofx_launch_layernorm(ln, dt, s));
         g1.A = w.H; g1.W = L.w_qkv; g1.bias = L.b_qkv;
     }
-    if (pool_idx && pool_first && g_prune_q) {
+    if (fused) {
+    } else if (pool_idx && pool_first && g_prune_q) {
         // last layer, pooled row = first row of every sequence (ViT CLS): only those rows' queries are ever used.  K | V for all
         // rows (weight rows W .. 3W), then Q for the nseq pooled rows through strided A / C / statistics.  The other rows' Q
         // columns keep stale workspace bytes; their attention outputs are never read (the tail gathers the pooled rows only).
@@ -634,8 +650,10 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
         TRY(ofx_launch_gemm(q, dt, s));
     } else
         TRY(ofx_launch_gemm(g1, dt, s));
-    AttnArgs at{w.QKV, w.H, key_mask, nseq, S, heads, 3 * W, W, W, 2 * W, mask_ld, causal, 0.125f};
-    TRY(ofx_launch_attention_mfma(at, dt, s));
+    if (!fused) {
+        AttnArgs at{w.QKV, w.H, key_mask, nseq, S, heads, 3 * W, W, W, 2 * W, mask_ld, causal, 0.125f};
+        TRY(ofx_launch_attention_mfma(at, dt, s));
+    }
     float* X = w.X; char* H = w.H; char* U = w.U; int M = rows;
     if (pool_idx) {
         TRY(ofx_launch_gather_rows(w.H, pool_idx, w.HP, nseq, W * 2, W * 2, s));
@@ -1220,6 +1238,7 @@ extern "C" int ofx_tune(int knob, int value) {
         case 6: g_ln_fold = value; return OFX_OK;
         case 7: g_train_mfma_attn = value; return OFX_OK;
         case 8: g_prune_q = value; return OFX_OK;
+        case 9: g_fuse_qkv = value; return OFX_OK;
         default: ofx_set_error("ofx_tune: unknown knob %d", knob); return OFX_EINVAL;
     }
 }
@@ -1258,6 +1277,10 @@ extern "C" int ofx_attention(const void* qkv, void* out, const int64_t* key_mask
                              int ldo, int k_off, int v_off, int mask_ld, int causal, float scale, int op_dtype, ofx_stream stream) {
     AttnArgs a{qkv, out, key_mask, nseq, seq_len, n_head, ld, ldo, k_off, v_off, mask_ld, causal, scale};
     return ofx_launch_attention_mfma(a, op_dtype, (hipStream_t)stream);
+}
+extern "C" int ofx_fused_qkv_attention(const void* X, const void* Wqkv, const float* bias, const float* row_stat, const float* col_sum, void* out,
+                                       int nseq, int seq_len, int width, int n_head, int ldx, int ldo, float scale, int op_dtype, ofx_stream stream) {
+    return ofx_launch_fused_qkv_attn(X, Wqkv, bias, row_stat, col_sum, out, nseq, seq_len, width, n_head, ldx, ldo, scale, op_dtype, (hipStream_t)stream);
 }
 extern "C" int ofx_set_attention(const float* qkv, void* out, const int* cu_seqlens, int nseq, int n_head, int D, int ldo,
                                  int out_kind, int max_len, int only_row0, float scale, int op_dtype, ofx_stream stream) {
