@@ -148,6 +148,9 @@ def main():
                     "fc2 GEMMs, three-product text tower and projection - meets 1e-3 vs the fp32 oracle) | f16 | bf16 (single product, faster, 5e-4 / 4e-3 at the tower outputs)")
     ap.add_argument("--cpu-outfits", type=int, default=8, help="outfits of the batch checked against the fp32 oracle (0 = skip the oracle check and the CPU baseline)")
     ap.add_argument("--cpu-cfg2-outfits", type=int, default=2, help="sample size of the CPU baseline's cfg2 leg")
+    ap.add_argument("--vit-streams", type=int, default=1, help="split the image batch over this many HIP streams (CLIPImageEncoder.vit_streams)")
+    ap.add_argument("--overlap-towers", type=int, default=1, help="1 (default): the text tower runs on a side HIP stream beside the ViT (ItemEncoder.overlap_towers; "
+                    "31.85 vs 32.85 ms/step); the ONE step sampled for the roofline and the breakdown step run single-stream so that launch times do not overlap")
     ap.add_argument("--secondary", default="bf16", help="tower scheme of the secondary (non-headline) measurement after the timed region ('' = skip)")
     ap.add_argument("--ln-fold", type=int, default=2, help="2 (product default): towers' LayerNorms folded into the GEMM epilogues and the residual stream kept as a (hi, lo) operand-type pair; 1: folded, fp32 stream; 0: materialised (A/B)")
     a = ap.parse_args()
@@ -180,6 +183,8 @@ def main():
                     tower_precision=a.tower_precision)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.full_state_dict(W_SEED).items()}, strict=True)
     model = model.to(dev).eval()
+    model.item_encoder.image_enc.vit_streams = a.vit_streams
+    model.item_encoder.overlap_towers = bool(a.overlap_towers)
 
     B, n = a.outfits, a.items
     seed = 1236 + rank
@@ -214,10 +219,12 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         if i == sample:
+            model.item_encoder.overlap_towers = False        # per-launch events of concurrent kernels would count the shared time twice
             lib.ofx_profile_enable(1)
         out = step()
         if i == sample:
             lib.ofx_profile_enable(0)
+            model.item_encoder.overlap_towers = bool(a.overlap_towers)
     fence()
     elapsed = time.perf_counter() - t0
     recs = (L.ProfRecord * 4096)()
@@ -226,7 +233,9 @@ def main():
     L.check(lib.ofx_profile_read(ms, fl, cnt), "ofx_profile_read")
     # one extra, untimed step with every category bracketed: the per-step breakdown
     lib.ofx_profile_enable(15)
+    model.item_encoder.overlap_towers = False
     step(); fence()
+    model.item_encoder.overlap_towers = bool(a.overlap_towers)
     bms, bfl, bcnt = (C.c_double * 4)(), (C.c_double * 4)(), (C.c_longlong * 4)()
     L.check(lib.ofx_profile_read(bms, bfl, bcnt), "ofx_profile_read")
     lib.ofx_profile_enable(0)

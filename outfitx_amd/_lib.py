@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libofx_hip.so")
+# OFX_LIB: an alternative build of the SAME library (tools only: the ablation build `make DIAG=1 LIB=outfitx_amd/libofx_hip_diag.so OBJ=build/obj_diag`)
+LIB_PATH = os.environ.get("OFX_LIB") or os.path.join(_HERE, "libofx_hip.so")
 
 OFX_OK = 0
 F32, BF16, F16 = 0, 1, 2

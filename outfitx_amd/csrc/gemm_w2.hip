@@ -22,7 +22,7 @@
 
 namespace {
 
-template <typename T>
+template <typename T, int ABL = 0>      // ABL (make DIAG=1, wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads after step 0, 3 both, 5 DMA issued BEFORE the fragment reads
 __global__ __launch_bounds__(512, 2) void gemm_w2_kernel(KArgs p) {
     typedef typename OpT<T>::v8 v8;
     constexpr int TM = 256, TN = 256, BK2 = 32, PART = TM * BK2 * 2, STAGE = 3 * PART, NST = 3;      // 16 KiB per operand, 48 KiB per stage
@@ -122,8 +122,9 @@ __global__ __launch_bounds__(512, 2) void gemm_w2_kernel(KArgs p) {
     if (wr == 0) {
         for (int t = 0; t < nk; ++t) {
             // slot 2t+1: read step t; refill the stage of step t-1 (group 1 read it in slot 2t) with step t+2
-            OFX_W2_READ(t % NST)
-            issue_all(t + 2);
+            if (ABL == 0 || ABL == 2) issue_all(t + 2);         // before the reads: 760 vs 775 us on the fc2 shape (tools/gemm_w2_bench.py, DIAG build)
+            if (ABL < 2 || ABL == 5 || t == 0) OFX_W2_READ(t % NST)
+            if (ABL == 5) issue_all(t + 2);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -137,8 +138,9 @@ __global__ __launch_bounds__(512, 2) void gemm_w2_kernel(KArgs p) {
         __builtin_amdgcn_s_barrier();                           // slot 1: group 0 reads step 0
         for (int t = 0; t < nk; ++t) {
             // slot 2t+2: read step t; refill the stage of step t-1 (read by group 0 in slot 2t-1, by this group in slot 2t)
-            OFX_W2_READ(t % NST)
-            issue_all(t + 2);
+            if (ABL == 0 || ABL == 2) issue_all(t + 2);         // before the reads: 760 vs 775 us on the fc2 shape (tools/gemm_w2_bench.py, DIAG build)
+            if (ABL < 2 || ABL == 5 || t == 0) OFX_W2_READ(t % NST)
+            if (ABL == 5) issue_all(t + 2);
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // my pieces of step t+1 landed: group 0 reads them in slot 2t+3
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -162,22 +164,29 @@ __global__ __launch_bounds__(512, 2) void gemm_w2_kernel(KArgs p) {
     epilogue2_dispatch<T>(p, ep, acc, gm0, gn0, lane, st);
 }
 
-template <typename T>
+template <typename T, int ABL = 0>
 static int launch_w2(KArgs& k, int M, int N, hipStream_t s) {
     constexpr int LDSB = 3 * 3 * 256 * 32 * 2;          // 144 KiB
     static DeviceOnce attr;
     TRY(attr.run([]() -> int {
-        OFX_HIP(hipFuncSetAttribute((const void*)gemm_w2_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+        OFX_HIP(hipFuncSetAttribute((const void*)gemm_w2_kernel<T, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
         return OFX_OK;
     }));
     k.tiles_n = N / 256; k.tiles_m = (M + 255) / 256; k.nwg = k.tiles_m * k.tiles_n;
-    OFX_PLAUNCH(true, gemm_w2_kernel<T>, dim3(k.nwg), dim3(512), LDSB, s, k);
+    OFX_PLAUNCH(true, (gemm_w2_kernel<T, ABL>), dim3(k.nwg), dim3(512), LDSB, s, k);
     return OFX_OK;
 }
 
 }  // namespace
 
+extern int g_gemm_ablate;
 int ofx_gemm_launch_w2(void* kargs, int op_dtype, int M, int N, hipStream_t s) {
     KArgs& k = *(KArgs*)kargs;
+#ifdef OFX_DIAG
+    if (g_gemm_ablate == 1) return launch_w2<f16_t, 1>(k, M, N, s);
+    if (g_gemm_ablate == 2) return launch_w2<f16_t, 2>(k, M, N, s);
+    if (g_gemm_ablate == 3) return launch_w2<f16_t, 3>(k, M, N, s);
+    if (g_gemm_ablate == 5) return launch_w2<f16_t, 5>(k, M, N, s);
+#endif
     return op_dtype == OFX_F16 ? launch_w2<f16_t>(k, M, N, s) : launch_w2<bf16_t>(k, M, N, s);
 }

@@ -287,9 +287,30 @@ class CLIPImageEncoder(_TowerBase):
             return None, arrs, len(images)
         return clip_preprocess(flat, self.model.config.image_size), None, len(images)
 
+    # > 1: a tensor batch of >= 512 images is split into that many contiguous parts, each run on its own HIP stream with its own
+    # workspace.  The tower's GEMMs are one 160 KB-LDS block per CU, so a kernel's last, partly filled round of tiles (6 % of a
+    # 1,200-tile out-proj / fc2 launch on 256 CUs) and its store-burst epilogues leave CUs idle that the other stream's kernels fill.
+    vit_streams = 1
+
     def _run(self, px, arrs, out: torch.Tensor, col: int, normalize: bool) -> None:
         eng = self._engine("vision")
-        if arrs is None:
+        if arrs is None and self.vit_streams > 1 and px.shape[0] >= 512:
+            cur = torch.cuda.current_stream(self.device)
+            pool = getattr(self, "_side_streams", None)
+            if pool is None or len(pool) < self.vit_streams:
+                pool = self._side_streams = [torch.cuda.Stream(self.device) for _ in range(self.vit_streams)]
+            n = px.shape[0]
+            step = -(-n // self.vit_streams)
+            for i in range(self.vit_streams):
+                a, b = i * step, min(n, (i + 1) * step)
+                if a >= b:
+                    continue
+                pool[i].wait_stream(cur)
+                with torch.cuda.stream(pool[i]):
+                    eng.vit(px[a:b], out[a:b], col, normalize)
+            for i in range(self.vit_streams):
+                cur.wait_stream(pool[i])
+        elif arrs is None:
             eng.vit(px, out, col, normalize)
         elif self.fused_preprocess:      # resample -> patch-embedding operand, no pixel tensor (ofx_vit_b32_fwd_u8)
             eng.vit_u8(arrs, CLIP_MEAN, CLIP_STD, out, col, normalize)

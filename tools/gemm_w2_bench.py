@@ -29,8 +29,19 @@ def main():
         bias = torch.randn(N, device="cuda", generator=g)
         resid = C.data_ptr() if ep == "r" else None
         act, okind = (1 if ep == "g" else 0), (1 if ep in "bg" else 0)
+        abl = [int(v) for v in os.environ.get("OFX_W2_ABLATE", "").split(",") if v]
+        def ablated(a):
+            def f():
+                lib.ofx_tune(1, a)
+                try:
+                    return lib.ofx_gemm_w2(A.data_ptr(), W2.data_ptr(), C.data_ptr(), bias.data_ptr(), resid, M, N, K, K, N, N, act, okind, 2, s)
+                finally:
+                    lib.ofx_tune(1, 0)
+            return f
         runs = {"x1": lambda: lib.ofx_gemm(A.data_ptr(), W.data_ptr(), C.data_ptr(), bias.data_ptr(), resid, M, N, K, K, N, N, act, okind, 2, s),
                 "w2": lambda: lib.ofx_gemm_w2(A.data_ptr(), W2.data_ptr(), C.data_ptr(), bias.data_ptr(), resid, M, N, K, K, N, N, act, okind, 2, s)}
+        for a_ in abl:
+            runs[f"abl{a_}"] = ablated(a_)
         res = {k: [] for k in runs}
         for rnd in range(6):
             for k, fn in runs.items():
@@ -43,7 +54,8 @@ def main():
                     res[k].append(e0.elapsed_time(e1) / 5)
         t1, t2 = np.median(res["x1"]), np.median(res["w2"])
         print(f"{name:8s} M={M} N={N} K={K} ep={ep} | x1 {t1*1e3:7.1f} us {2*M*N*K/t1/1e9:6.0f} TF | w2 {t2*1e3:7.1f} us "
-              f"{2*M*N*K/t2/1e9:6.0f} TF useful, {4*M*N*K/t2/1e9:6.0f} TF executed | w2/x1 {t2/t1:.2f}", flush=True)
+              f"{2*M*N*K/t2/1e9:6.0f} TF useful, {4*M*N*K/t2/1e9:6.0f} TF executed | w2/x1 {t2/t1:.2f}"
+              + "".join(f" | abl{a_} {np.median(res[f'abl{a_}'])*1e3:7.1f} us" for a_ in abl), flush=True)
 
 
 if __name__ == "__main__":
