@@ -204,6 +204,11 @@ int ofx_cp_train_bwd_into(ofx_handle* h, void* tape, size_t tape_bytes, const fl
                           int n_ptrs, int accumulate, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream);
 int ofx_cir_train_bwd_into(ofx_handle* h, void* tape, size_t tape_bytes, const float* dy, int B, int L, float* const* grad_ptrs,
                            int n_ptrs, int accumulate, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream);
+/* Data-parallel overlap: arm one hipEvent_t per outfit-transformer layer (events[l], n = n_layers; n = 0 disarms) for the NEXT
+ * ofx_*_train_bwd* call on this handle only.  That call records events[l] on its stream as soon as the 12 gradient tensors of layer l
+ * (Win, bin, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2) are final - layers finish last-to-first - so the host can start that
+ * layer's gradient all-reduce on another stream while the backward of the layers below still runs (outfitx_amd/trainer.py). */
+int ofx_train_arm_layer_events(ofx_handle* h, void* const* events, int n);
 /* out[rows, cols] fp32 = keep-mask / (1 - p) of dropout site `site` (layer l: 4l + {0 attention [B*heads, 32*i + j], 1 dropout1,
  * 2 FFN, 3 dropout2}; 4 * n_layers = head), exactly as the kernels compute it.  Test / debugging aid. */
 int ofx_dropout_mask(float dropout_p, unsigned seed, int site, int rows, int cols, float* out, ofx_stream stream);

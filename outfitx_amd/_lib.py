@@ -87,6 +87,7 @@ SIGNATURES = {
     "ofx_cir_train_bwd": (_i, [_vp, _vp, _sz, _vp, _i, _i, _vp, _sz, _vp, _sz, _f, C.c_uint, _vp]),
     "ofx_cp_train_bwd_into": (_i, [_vp, _vp, _sz, _vp, _i, _i, C.POINTER(_vp), _i, _i, _vp, _sz, _f, C.c_uint, _vp]),
     "ofx_cir_train_bwd_into": (_i, [_vp, _vp, _sz, _vp, _i, _i, C.POINTER(_vp), _i, _i, _vp, _sz, _f, C.c_uint, _vp]),
+    "ofx_train_arm_layer_events": (_i, [_vp, C.POINTER(_vp), _i]),
     "ofx_dropout_mask": (_i, [_f, C.c_uint, _i, _i, _i, _vp, _vp]),
     "ofx_focal_loss": (_i, [_vp, _vp, _i, _f, _f, _f, _vp, _vp, _vp]),
     "ofx_focal_loss_ex": (_i, [_vp, _vp, _i, _f, _f, _f, _i, _vp, _vp, _vp, _vp]),

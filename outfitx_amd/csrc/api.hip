@@ -167,6 +167,8 @@ struct ofx_handle {
     int tw_dtype;
     int vit_w2_mask = 0, txt_x3 = 0, proj_x3 = 0;    // operand scheme (ofx_model_desc); x3 towers hold ONLY the K-concatenated [hi | hi | lo] weight copies
     void* v_patch_w2 = nullptr; void* v_proj_w3 = nullptr;
+    // training: events armed for the NEXT backward call (ofx_train_arm_layer_events), one per outfit-transformer layer
+    std::vector<hipEvent_t> bwd_events;
     Arena a_vis; bool vis_ready = false;
     std::vector<ClipLayer> vl;
     void *v_patch_w, *v_proj_w; float *v_cls, *v_pos, *v_pre_g, *v_pre_b, *v_post_g, *v_post_b;
@@ -1088,9 +1090,18 @@ extern "C" int ofx_cir_train_bwd_into(ofx_handle* h, void* tape_mem, size_t tape
     OFX_REQUIRE(h && grad_ptrs && n_ptrs == 5 + 12 * h->d.n_layers, OFX_EINVAL, "cir_train_bwd_into: expected %d destinations", h ? 5 + 12 * h->d.n_layers : 0);
     return set_train_bwd_core(h, tape_mem, tape_bytes, dy, B, L, nullptr, 0, ws, ws_bytes, dropout_p, seed, stream, 1, grad_ptrs, accumulate);
 }
+extern "C" int ofx_train_arm_layer_events(ofx_handle* h, void* const* events, int n) {
+    OFX_REQUIRE(h, OFX_EINVAL, "train_arm_layer_events: NULL handle");
+    OFX_REQUIRE(n == 0 || (events && n == h->d.n_layers), OFX_EINVAL, "train_arm_layer_events: expected %d events (one per layer) or 0, got %d", h->d.n_layers, n);
+    h->bwd_events.assign((hipEvent_t*)events, (hipEvent_t*)events + n);
+    return OFX_OK;
+}
 static int set_train_bwd_core(ofx_handle* h, void* tape_mem, size_t tape_bytes, const float* dlogits, int B, int L, float* grads,
                               size_t grad_floats, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, ofx_stream stream, int head,
                               float* const* grad_ptrs, int accumulate) {
+    // per-layer completion events (data-parallel overlap): consumed by this call whatever its outcome
+    std::vector<hipEvent_t> layer_ev;
+    if (h) layer_ev.swap(h->bwd_events);
     OFX_REQUIRE(h && h->out_ready && h->ot_kmul == 1, OFX_ESTATE, "cp_train_bwd: needs packed single-product weights");
     OFX_REQUIRE(tape_mem && dlogits && (grads || grad_ptrs) && ws && B > 0, OFX_EINVAL, "cp_train_bwd: bad argument");
     OFX_REQUIRE(d_outfit_act_is_mish(h), OFX_ESTATE, "cp_train_bwd: only the Mish activation has a backward epilogue");
@@ -1173,6 +1184,9 @@ static int set_train_bwd_core(ofx_handle* h, void* tape_mem, size_t tape_bytes, 
         // dXin = LayerNorm-1 backward + (dXmid at the prefix rows); its column sums = bias gradient of the layer below's linear2
         TRY(ofx_launch_ln_bwd(w.dH, t.Xin, t.st1, Ly.g1, dX2, w.rowmap, dX, w.gXb, G(g0 + 8), G(g0 + 9), lastl > 0 ? G(g0 - 12 + 7) : nullptr, w.part, D, m_dev, M, dt,
                               lastl > 0 ? site(lastl - 1, 3) : nodrop, s, acc));
+        // all 12 gradient tensors of the last layer are final (its linear2 bias gradient comes from this very LayerNorm backward of the
+        // layer ABOVE - none here - i.e. from the head path): a data-parallel host may start reducing them now
+        if (!layer_ev.empty()) OFX_HIP(hipEventRecord(layer_ev[lastl], s));
     }
     for (int l = lastl - 1; l >= 0; --l) {
         const OutfitLayer& Ly = h->ol[l];
@@ -1195,6 +1209,7 @@ static int set_train_bwd_core(ofx_handle* h, void* tape_mem, size_t tape_bytes, 
         // dXin; its column sums are the bias gradient of the layer below's linear2
         TRY(ofx_launch_ln_bwd(w.dH, t.Xin, t.st1, Ly.g1, dX2, nullptr, dX, w.gXb, G(g0 + 8), G(g0 + 9), l > 0 ? G(g0 - 12 + 7) : nullptr, w.part, D, m_dev, M, dt,
                               l > 0 ? site(l - 1, 3) : nodrop, s, acc));
+        if (!layer_ev.empty()) OFX_HIP(hipEventRecord(layer_ev[l], s));      // layer l's gradients are final (its b2 came from layer l+1's LayerNorm-1 backward)
     }
     // CIR: the prefix is [target_item_image_emb | text]: d target_item_image_emb = sum_b dX0[cu[b]][:D/2]
     if (head == 1) return ofx_launch_colsum(dX, 0, D, T.cu, nullptr, G(1), nullptr, nullptr, D / 2, w.part, D / 2, nullptr, B, dt, s, 0, acc);

@@ -253,6 +253,12 @@ class Engine:
                                               _ptr(ws), ws.numel(), float(dropout_p), int(seed) & 0xFFFFFFFF, _stream(self.device)), "ofx_cp_train_bwd")
         return g
 
+    def arm_layer_events(self, events) -> None:
+        """events: one torch.cuda.Event per outfit-transformer layer (each recorded at least once, so that its HIP handle exists);
+        the NEXT backward call records events[l] when layer l's gradients are final (ofx_train_arm_layer_events)."""
+        arr = (C.c_void_p * len(events))(*[int(e.cuda_event) for e in events])
+        L.check(self.lib.ofx_train_arm_layer_events(self.h, arr, len(events)), "ofx_train_arm_layer_events")
+
     def train_bwd_into(self, head: str, tape: torch.Tensor, dhead: torch.Tensor, B: int, Lq: int, dests, accumulate: bool,
                        dropout_p: float = 0.0, seed: int = 0) -> None:
         """Backward of the CP ('cp') or CIR ('cir') path writing every gradient straight into `dests` (one fp32 contiguous

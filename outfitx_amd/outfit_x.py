@@ -299,6 +299,11 @@ class OutfitX(nn.Module):
         eng, row0 = self._run_encoder(outfit_embedding, outfit_mask, precision=prec)
         return eng.cp_head(row0)
 
+    def arm_bwd_layer_events(self, events) -> None:
+        """Data-parallel overlap (trainer.CPTrainer): the next backward of the training step records events[l] when layer l's
+        gradients are final."""
+        self._engine(self.train_precision).arm_layer_events(events)
+
     def _cp_train_forward(self, outfit_embedding, outfit_mask):
         """CP trainer step (compatibility_prediction_trainer.py:57-81): forward with a tape, backward in libofx_hip.so."""
         t = self.cfg.transformer

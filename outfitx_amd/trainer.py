@@ -10,9 +10,12 @@ for one process per GPU over RCCL/xGMI rather than DistributedDataParallel:
   epoch end: all-gather logits / labels / loss -> AUC, accuracy, precision, recall, F1 (same formulas as :406-436).
 
 Differences from DDP by design (MI355X / xGMI, point-to-point links, per-link bound rings):
-  * gradients live in ONE contiguous fp32 arena (`FlatGrads`; every p.grad is a view), so the reduction is a single large
-    RCCL all-reduce (~205 MB for the 51 M trainable parameters) instead of ~25 MB buckets, and the clip norm is one
-    reduction over the arena instead of 75 per-tensor norms;
+  * gradients live in ONE contiguous fp32 arena (`FlatGrads`; every p.grad is a view): the clip norm is one reduction over the
+    arena instead of 75 per-tensor norms, and the all-reduce goes out as one contiguous slice per encoder layer (34 MB each,
+    6 + 1 collectives for the 205 MB) STARTED WHILE THE BACKWARD STILL RUNS: `ofx_train_arm_layer_events` makes the hand-written
+    backward record a HIP event when layer l's gradients are final (layers finish last-to-first), and the slice's RCCL
+    all-reduce is enqueued on a side stream behind that event - 5/6 of the reduction overlaps the backward of the layers below
+    (xGMI is point-to-point: 34 MB slices are still bandwidth-, not latency-bound per link);
   * the all-reduce runs once per OPTIMIZER step; DDP without no_sync() (what the reference does) reduces on every
     micro-batch, 4x the traffic at accumulation_steps = 4;
   * no per-step all_gather_object / barrier pair (reference C4/C5): error propagation is the job of the
@@ -71,6 +74,25 @@ class FlatGrads:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             self.flat.div_(dist.get_world_size(group))
+
+    def slices(self, groups: Sequence[Sequence[torch.nn.Parameter]]):
+        """groups: lists of parameters, each list contiguous in the arena (an encoder layer's 12 tensors) -> ([(lo, hi)] per group,
+        [(lo, hi)] of everything not covered), in floats."""
+        off = {id(p): (o, o + (p.numel() + 63) // 64 * 64) for p, o in zip(self.params, self.offsets)}
+        out = []
+        for g in groups:
+            rs = sorted(off[id(p)] for p in g if id(p) in off)
+            if not rs or any(a[1] != b[0] for a, b in zip(rs, rs[1:])):
+                raise ValueError("a gradient bucket must be a contiguous run of the arena")
+            out.append((rs[0][0], rs[-1][1]))
+        rest, cur = [], 0
+        for lo, hi in sorted(out):
+            if lo > cur:
+                rest.append((cur, lo))
+            cur = max(cur, hi)
+        if cur < self.flat.numel():
+            rest.append((cur, self.flat.numel()))
+        return out, rest
 
     def clip_norm_(self, max_norm: float) -> torch.Tensor:
         """torch.nn.utils.clip_grad_norm_ semantics (L2, eps 1e-6, coefficient clamped to 1); stays on the device."""
@@ -155,6 +177,64 @@ class CPTrainer:
         # valid because nothing here relies on autograd hooks (DDP would)
         if hasattr(model, "_cp_train_forward"):
             model.grad_sink = True
+        # per-layer gradient slices for the overlapped reduction (None: the model has no encoder-layer structure -> one all-reduce)
+        self.layer_slices = self.rest_slices = None
+        layers = getattr(getattr(model, "transformer_encoder", None), "layers", None)
+        if layers is not None:
+            try:
+                self.layer_slices, self.rest_slices = self.grads.slices([[p for p in l.parameters() if p.requires_grad] for l in layers])
+            except ValueError:
+                self.layer_slices = None
+        self.overlap_reduce = True
+        self._layer_events = None
+        self._comm_stream = None
+
+    def _world(self) -> int:
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def _arm_overlap(self) -> bool:
+        """Before the backward of an accumulation window's LAST micro-batch: arm the per-layer completion events (HIP model only)."""
+        if not (self.overlap_reduce and self.layer_slices and self._world() > 1 and hasattr(self.model, "arm_bwd_layer_events")
+                and self.grads.flat.is_cuda):
+            return False
+        if self._layer_events is None:
+            self._layer_events = [torch.cuda.Event() for _ in self.layer_slices]
+            for e in self._layer_events:
+                e.record()                                   # materialises the HIP handle
+            self._comm_stream = torch.cuda.Stream(self.grads.flat.device)
+        self.model.arm_bwd_layer_events(self._layer_events)
+        return True
+
+    def _reduce_mean(self, overlapped: bool) -> None:
+        """Mean of the gradient arena over the ranks.  overlapped: layer l's slice is reduced on the side stream as soon as its event
+        fires (the backward of the layers below is still running on the main stream); else slice by slice after the backward (CPU /
+        gloo, stub models) or as one collective when the model has no layer structure.  Same sums either way."""
+        world = self._world()
+        if world <= 1:
+            return
+        flat = self.grads.flat
+        if not self.layer_slices:
+            self.grads.all_reduce_mean_(self.group)
+            return
+        works = []
+        if overlapped:
+            main, comm = torch.cuda.current_stream(flat.device), self._comm_stream
+            for l in reversed(range(len(self.layer_slices))):
+                lo, hi = self.layer_slices[l]
+                comm.wait_event(self._layer_events[l])
+                with torch.cuda.stream(comm):
+                    works.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            comm.wait_stream(main)                           # heads / tokens: final only when the whole backward is done
+            with torch.cuda.stream(comm):
+                for lo, hi in self.rest_slices:
+                    works.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            for w in works:
+                w.wait()
+            main.wait_stream(comm)
+        else:
+            for lo, hi in list(reversed(self.layer_slices)) + list(self.rest_slices):
+                dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+        flat.div_(world)
 
     def micro_step(self, batch: dict, step: int):
         """One micro-batch: forward, loss / accumulation_steps, backward; optimizer step on the accumulation boundary.
@@ -165,9 +245,11 @@ class CPTrainer:
         labels = batch["label"].to(dev, non_blocking=True)
         y_hat = self.model(**inp).squeeze(dim=-1)
         loss = self.loss_fn(y_hat=y_hat, y_true=labels)
+        boundary = (step + 1) % c.accumulation_steps == 0 or step + 1 == self.steps_per_epoch
+        overlapped = boundary and self._arm_overlap()
         (loss / c.accumulation_steps).backward()
-        if (step + 1) % c.accumulation_steps == 0 or step + 1 == self.steps_per_epoch:
-            self.grads.all_reduce_mean_(self.group)
+        if boundary:
+            self._reduce_mean(overlapped)
             self.last_grad_norm = self.grads.clip_norm_(c.max_grad_norm)
             self.optimizer.step()
             self.scheduler.step()

@@ -59,9 +59,15 @@ class Stub(torch.nn.Module):                 # stands in for OutfitX: same call 
         super().__init__()
         torch.manual_seed(1)
         self.a = torch.nn.Linear(16, 8); self.b = torch.nn.Linear(8, 1)
+        # an encoder-layer structure like OutfitX's: the trainer reduces the gradients slice by slice, one per layer + the rest
+        self.transformer_encoder = torch.nn.Module()
+        self.transformer_encoder.layers = torch.nn.ModuleList([torch.nn.Linear(16, 16) for _ in range(3)])
     def forward(self, task, outfit_embedding, outfit_mask):
         keep = (~outfit_mask).float().unsqueeze(-1)
-        pooled = (outfit_embedding * keep).sum(1) / keep.sum(1).clamp(min=1)
+        x = outfit_embedding
+        for l in self.transformer_encoder.layers:
+            x = x + torch.tanh(l(x))
+        pooled = (x * keep).sum(1) / keep.sum(1).clamp(min=1)
         return self.b(torch.nn.functional.mish(self.a(pooled)))
 
 def focal(y_hat, y_true):                    # src/losses/focal_loss.py:26-41 in torch ops (the fused kernel needs a HIP device)
@@ -87,6 +93,9 @@ STEPS, BSZ = 5, 8                            # 5 micro-steps: the last optimizer
 half = BSZ // world
 m = Stub()
 tr = CPTrainer(m, steps_per_epoch=STEPS, cfg=cfg, loss_fn=focal)
+assert tr.layer_slices is not None and len(tr.layer_slices) == 3 and tr.rest_slices       # per-layer slices + the head parameters
+covered = sorted(tr.layer_slices + tr.rest_slices)
+assert covered[0][0] == 0 and covered[-1][1] == tr.grads.flat.numel() and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
 metrics = None
 for ep in range(2):
     metrics = tr.train_epoch(batches(rank * half, (rank + 1) * half, STEPS, BSZ))

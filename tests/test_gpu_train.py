@@ -381,7 +381,7 @@ def test_training_step_properties_at_config5_size():
     EXACTLY (powers of two commute with every rounding); (2) gradients of a batch = sum of the gradients of its two halves
     (outfits are independent), to fp32 accumulation-order rounding - checked with split-K off, because a different K
     partition re-associates the fp32 sums, which flips a few bf16 roundings of the activations, and single-product bf16 then
-    differs at its own 1e-2 noise level between batch compositions (tools/_dbg_halves2.py); (3) two runs are bit-identical
+    differs at its own 1e-2 noise level between batch compositions (round-1 scratch script, git 81b82dd); (3) two runs are bit-identical
     (deterministic reductions)."""
     from outfitx_amd import _lib as L
     from src.models.datatypes import OutfitCompatibilityPredictionTask as CP
@@ -518,6 +518,46 @@ def test_training_step_under_distributed_data_parallel():
     assert set(got) >= set(want)
     for k in want:
         assert torch.equal(got[k], want[k]), k
+
+
+def test_overlapped_gradient_reduction_equals_the_plain_one():
+    """trainer.CPTrainer with more than one rank reduces layer l's gradient slice on a side stream behind the HIP event that the
+    backward records when that layer is final (ofx_train_arm_layer_events).  Here on ONE device: a world-size-1 RCCL group with the
+    trainer told the world is 2 (so every slice goes through an async all-reduce on the comm stream and is then halved) - the
+    parameters after three optimizer steps must be bit-identical to the slice-by-slice reduction after the backward, every armed
+    event must have fired, and an armed backward must leave the gradients themselves unchanged."""
+    import socket
+    import torch.distributed as dist
+    from outfitx_amd.trainer import CPTrainConfig, CPTrainer
+    from src.models.datatypes import OutfitCompatibilityPredictionTask as CP
+    emb, mask = synth.outfit_batch(91, 24, 16, synth.ragged_lengths(91, 24, 1, 12))
+    lab = torch.from_numpy((np.random.default_rng(9).random(24) < 0.5).astype(np.float32))
+    batch = {"input_dict": {"task": CP, "outfit_embedding": torch.from_numpy(emb), "outfit_mask": torch.from_numpy(mask)}, "label": lab}
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        finals = []
+        for overlap in (True, False):
+            m = make_model("bf16")
+            tr = CPTrainer(m, steps_per_epoch=6, cfg=CPTrainConfig(learning_rate=1e-3, accumulation_steps=2, n_epochs=1, fused_optimizer=False),
+                           params=list(trainable(m).values()))
+            assert tr.layer_slices is not None and len(tr.layer_slices) == 6
+            tr.overlap_reduce = overlap
+            tr._world = lambda: 2
+            for i in range(6):
+                tr.micro_step(batch, i)
+            torch.cuda.synchronize()
+            if overlap:
+                assert tr._layer_events is not None and all(e.query() for e in tr._layer_events)
+            else:
+                assert tr._layer_events is None
+            finals.append({k: v.detach().clone() for k, v in trainable(m).items()})
+        for k in finals[0]:
+            assert torch.equal(finals[0][k], finals[1][k]), k
+    finally:
+        dist.destroy_process_group()
 
 
 def test_reference_trainer_step_verbatim():
