@@ -274,6 +274,10 @@ int ofx_set_attention(const float* qkv, void* out, const int* cu_seqlens, int ns
  * out [nseq * seq_len, ldo] operand type (heads concatenated).  seq_len in [33, 64], width = n_head * 64, no mask.  X and out must not alias. */
 int ofx_fused_qkv_attention(const void* X, const void* Wqkv, const float* bias, const float* row_stat, const float* col_sum, void* out,
                             int nseq, int seq_len, int width, int n_head, int ldx, int ldo, float scale, int op_dtype, ofx_stream stream);
+/* fp32-arithmetic attention over fixed-length sequences of <= 64 rows (the three-product CLIP text tower): qkv fp32 [nseq * seq_len, 3 D]
+ * (q | k | v), HF's causal AND key-padding mask (key_mask [nseq, mask_ld] int64, 0 = ignored, may be NULL); out as ofx_set_attention. */
+int ofx_attention_f32(const float* qkv, void* out, const int64_t* key_mask, int nseq, int seq_len, int n_head, int D, int ldo, int out_kind,
+                      int mask_ld, int causal, float scale, int op_dtype, ofx_stream stream);
 int ofx_convert(const float* src, void* dst, int rows, int cols, int mode, int op_dtype, ofx_stream stream);
 
 #ifdef __cplusplus

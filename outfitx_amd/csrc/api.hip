@@ -703,10 +703,11 @@ static int clip_layer_x3(const ClipLayer& L, const ClipWs& w, int rows, int nseq
     LnArgs ln{w.X, nullptr, L.g1, L.be1, w.H, rows, W, 3 * W, OFX_OUT_SPLIT3, eps};
     TRY(ofx_launch_layernorm(ln, dt, s));
     GemmArgs g1{}; g1.A = w.H; g1.W = L.w_qkv; g1.C = w.QKV; g1.bias = L.b_qkv; g1.M = rows; g1.N = 3 * W; g1.K = 3 * W; g1.k_mult = 3; g1.lda = 3 * W;
-    // sequences of <= 32 rows (item texts: category names): q | k | v stay fp32 and the attention runs in fp32 arithmetic (the outfit
-    // transformer's set kernel with HF's causal AND key-padding mask); longer ones round q | k | v once to the operand type for
-    // the single-tile MFMA kernel (3e-4 at the text embedding, tests/studies/operand_scheme_cpu.py)
-    const bool f32_attn = S <= 32;
+    // q | k | v stay fp32 and the attention runs in fp32 arithmetic (the outfit transformer's set kernel with HF's causal AND
+    // key-padding mask, up to 64 rows per sequence): rounding q, k, v, P to the operand type alone leaves 3.5e-4 at the text embedding
+    // (tests/studies/operand_scheme_cpu.py); the single-tile MFMA kernel stays as the fallback beyond 64 rows (never reached:
+    // ofx_clip_text_fwd caps the computed tokens at 64)
+    const bool f32_attn = S <= 64;
     g1.ldc = 3 * W; g1.act = OFX_ACT_NONE; g1.out_kind = f32_attn ? OFX_OUT_F32 : OFX_OUT_OP;
     TRY(ofx_launch_gemm(g1, dt, s));
     if (f32_attn) {
@@ -1300,6 +1301,12 @@ extern "C" int ofx_fused_qkv_attention(const void* X, const void* Wqkv, const fl
 extern "C" int ofx_set_attention(const float* qkv, void* out, const int* cu_seqlens, int nseq, int n_head, int D, int ldo,
                                  int out_kind, int max_len, int only_row0, float scale, int op_dtype, ofx_stream stream) {
     SetAttnArgs a{qkv, out, cu_seqlens, nseq, n_head, D, ldo, out_kind, max_len, only_row0, scale};
+    return ofx_launch_set_attention(a, op_dtype, (hipStream_t)stream);
+}
+extern "C" int ofx_attention_f32(const float* qkv, void* out, const int64_t* key_mask, int nseq, int seq_len, int n_head, int D, int ldo, int out_kind,
+                                 int mask_ld, int causal, float scale, int op_dtype, ofx_stream stream) {
+    SetAttnArgs a{qkv, out, nullptr, nseq, n_head, D, ldo, out_kind, seq_len, 0, scale};
+    a.fixed_len = seq_len; a.causal = causal; a.key_mask = key_mask; a.mask_ld = mask_ld;
     return ofx_launch_set_attention(a, op_dtype, (hipStream_t)stream);
 }
 extern "C" int ofx_convert(const float* src, void* dst, int rows, int cols, int mode, int op_dtype, ofx_stream stream) {

@@ -529,7 +529,8 @@ int ofx_launch_attention_mfma(const AttnArgs& g, int op_dtype, hipStream_t s) {
 
 int ofx_launch_set_attention(const SetAttnArgs& g, int op_dtype, hipStream_t s) {
     OFX_REQUIRE(g.D == g.n_head * 64, OFX_ESHAPE, "set_attention: head_dim must be 64 (D=%d heads=%d)", g.D, g.n_head);
-    OFX_REQUIRE(g.max_len >= 1 && g.max_len <= 32, OFX_ESHAPE, "set_attention: 1+items=%d exceeds 32", g.max_len);
+    OFX_REQUIRE(g.max_len >= 1 && g.max_len <= (g.cu_seqlens ? 32 : 64), OFX_ESHAPE, "set_attention: %d rows per sequence exceed %d", g.max_len, g.cu_seqlens ? 32 : 64);
+    OFX_REQUIRE(g.max_len <= 32 || !g.drop.thresh, OFX_ESHAPE, "set_attention: dropout columns are keyed query * 32 + key");
     OFX_REQUIRE(g.ldo >= (g.out_kind == 2 ? 3 * g.D : g.D), OFX_ESHAPE, "set_attention: bad ldo=%d", g.ldo);
     OFX_REQUIRE(g.cu_seqlens || (g.fixed_len >= 1 && g.fixed_len <= g.max_len), OFX_EINVAL, "set_attention: needs cu_seqlens or a fixed length <= max_len");
     SetK k;
@@ -540,8 +541,8 @@ int ofx_launch_set_attention(const SetAttnArgs& g, int op_dtype, hipStream_t s) 
     ProfScope prof(PROF_ATTN, s);
 #define SA(T, N) do { if (g.qkv_op) hipLaunchKernelGGL((set_attention_kernel<T, N, T>), dim3(grid), dim3(64), 0, s, k); \
                       else hipLaunchKernelGGL((set_attention_kernel<T, N, float>), dim3(grid), dim3(64), 0, s, k); } while (0)
-    if (op_dtype == OFX_F16) { if (g.max_len <= 20) SA(f16_t, 20); else SA(f16_t, 32); }
-    else { if (g.max_len <= 20) SA(bf16_t, 20); else SA(bf16_t, 32); }
+    if (op_dtype == OFX_F16) { if (g.max_len <= 20) SA(f16_t, 20); else if (g.max_len <= 32) SA(f16_t, 32); else SA(f16_t, 64); }
+    else { if (g.max_len <= 20) SA(bf16_t, 20); else if (g.max_len <= 32) SA(bf16_t, 32); else SA(bf16_t, 64); }
 #undef SA
     OFX_LAUNCH_CHECK();
     return OFX_OK;

@@ -296,6 +296,33 @@ def test_attention_mfma(dt, S, H, causal, masked):
     assert rel_err(out.double().cpu().numpy(), want) < (6e-3 if dt == "bf16" else 8e-4)
 
 
+@pytest.mark.parametrize("S,causal,masked", [(8, 1, 1), (20, 1, 0), (33, 1, 1), (64, 1, 1), (64, 0, 1), (50, 0, 0)])
+def test_attention_f32_fixed_length_causal_and_key_mask(S, causal, masked):
+    """The fp32 set-attention kernel in its fixed-length mode (three-product text tower): HF's causal AND key-padding mask, up to 64
+    rows per sequence, [hi | lo | hi] output - against float64 softmax attention."""
+    n, H = 6, 8
+    D = H * 64
+    g = np.random.default_rng(S + 3 * causal + masked)
+    qkv = g.standard_normal((n * S, 3 * D), dtype=np.float32)
+    att = np.ones((n, 77), np.int64)
+    if masked:
+        for i in range(n):
+            att[i, g.integers(1, S + 1):] = 0
+    out = torch.zeros(n * S, 3 * D, dtype=torch.float16, device="cuda")
+    qd, ad = dev(qkv), dev(att)
+    L.check(L.load().ofx_attention_f32(qd.data_ptr(), out.data_ptr(), ad.data_ptr() if masked else None, n, S, H, D, 3 * D, 2, 77, causal, 0.125, DT["f16"], stream()))
+    x = qkv.astype(np.float64).reshape(n, S, 3, H, 64).transpose(2, 0, 3, 1, 4)
+    dead = np.zeros((n, 1, S, S), bool)
+    if masked:
+        dead |= (att[:, None, None, :S] == 0)
+    if causal:
+        dead |= np.triu(np.ones((S, S), bool), 1)[None, None]
+    want = _attn_ref(x[0], x[1], x[2], 0.125, dead).transpose(0, 2, 1, 3).reshape(n * S, D)
+    o = out.double().cpu().numpy()
+    assert np.array_equal(o[:, :D], o[:, 2 * D:])                       # [hi | lo | hi]
+    assert rel_err(o[:, :D] + o[:, D:2 * D], want) < 2e-6               # hi + lo = 22 bits of an fp32 result
+
+
 @pytest.mark.parametrize("fold", [0, 1])
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("n,S,H", [(1, 50, 12), (5, 50, 12), (13, 50, 12), (7, 64, 4), (9, 33, 2)])
