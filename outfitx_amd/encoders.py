@@ -467,7 +467,9 @@ class ItemEncoder(nn.Module):
                 "OutfitXConfig(item_encoder=ItemEncoderConfig(type='clip'))")
         self.image_enc = CLIPImageEncoder(model_name_or_path=cfg.clip_model_name)
         self.text_enc = CLIPTextEncoder(model_name_or_path=cfg.clip_model_name)
-        self.overlap_towers = False   # side-stream text tower: measured neutral-to-negative on cfg2, kept as an option
+        # side-stream text tower: its small kernels fill the tile-quantisation tails of the big ViT GEMMs.  Neutral with round 1's
+        # 1.3 ms single-product text tower; with the three-product one (5 ms) 31.85 vs 32.85 ms per cfg2 step (bench.py --overlap-towers)
+        self.overlap_towers = True
         self._streams: Dict[Any, Any] = {}
 
     def _side_stream(self, dev):
