@@ -270,13 +270,30 @@ def main():
                           "us_per_launch": round(t_ * 1e3 / c_, 1), "ms_per_step": round(t_, 3), "useful_tflops": round(useful, 1),
                           "frac_useful": round(useful / PEAK_BF16_TFLOPS, 4), "executed_tflops": round(useful * km_, 1)})
         traffic, traffic_src = None, None   # PMC counters cannot be read inside a timed run: the committed rocprofv3 --pmc passes of this same command
-        for f_ in ("r02_traffic_pmc.json",):
-            try:
-                with open(os.path.join(ROOT, "profiles", f_)) as f:
-                    traffic = round(json.load(f)["gemm_hbm_bytes_per_launch"]); traffic_src = f_
-                    break
-            except Exception:
-                pass
+        try:
+            with open(os.path.join(ROOT, "profiles", "r02_mfma_util.json")) as f:
+                traffic = round(json.load(f)["gemm_kernels"]["gemm_hbm_bytes_per_launch"]); traffic_src = "r02_mfma_util.json"
+        except Exception:
+            pass
+
+        def alg_bytes(M_, N_, K_, km_, kind_):
+            """Algorithmic HBM bytes of one GEMM launch: every operand read once, every output written once.  A = M x K operand rows
+            (x3 wide in the three-product form), W = N x K x products, output by what the launch produces."""
+            a_b = M_ * K_ * 2 * (3 if km_ == 3 else 1)
+            w_b = N_ * K_ * 2 * km_
+            if kind_ == 7:                       # fused QKV + attention: writes the attention output [M, N / 3] in the operand type
+                o_b = M_ * (N_ // 3) * 2
+            elif km_ == 2 and N_ == 768 and K_ == 3072 and M_ > 100000 and M_ % 49 == 0:
+                o_b = M_ * N_ * 4                # patch embedding: fp32 output
+            elif km_ == 2:
+                o_b = M_ * N_ * 8                # out-proj / fc2 on the (hi, lo) residual stream: 4 B read + 4 B written per element
+            elif km_ == 3:
+                o_b = M_ * N_ * (8 if N_ in (512, 1024) else 6)      # fp32 residual read + write; else [hi | lo | hi] or fp32 q|k|v
+            else:
+                o_b = M_ * N_ * 2
+            return a_b + w_b + o_b
+        alg_total = sum(alg_bytes(M_, N_, K_, km_, kind_) * c_ for (M_, N_, K_, km_, kind_), (c_, t_) in shapes.items())
+        alg_per_launch = alg_total / max(gemm_launches, 1)
         scheme = {"f16w2": "f16w2 = f16 MFMA operands; split (hi, lo) weights (2 products per weight) on the ViT patch-embedding / out-proj / fc2 GEMMs; text tower, "
                            "ViT projection tail and the outfit transformer in three-product arithmetic",
                   "f16": "f16, one MFMA product per term", "bf16": "bf16, one MFMA product per term"}.get(a.tower_precision, a.tower_precision)
@@ -297,7 +314,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "every dense contraction of the step: " + " / ".join(sorted({t_["kernel"] for t_ in table})),
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                         "traffic_note": f"bytes/launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/{traffic_src} (separate --pmc passes)" if traffic else "no PMC pass committed for this build yet",
+                         "traffic_note": f"bytes/launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/{traffic_src} (separate rocprofv3 --pmc passes of this command, tools/profile_r02.sh)" if traffic else "no PMC pass committed for this build yet",
+                         "algorithmic_bytes_per_launch": round(alg_per_launch),
+                         "traffic_over_algorithmic": round(traffic / alg_per_launch, 3) if traffic else None,
                          "note": "achieved = ALGORITHMIC (useful, pad-free, one product per term) GEMM FLOPs of the step / summed GEMM launch time of one sampled step; "
                                  "executed_tflops counts the extra MFMA products the 1e-3-compliant scheme spends (split weights x2, three-product x3)",
                          "executed_tflops": round(executed, 2), "executed_frac": round(executed / PEAK_BF16_TFLOPS, 4),

@@ -13,8 +13,8 @@
 //   3. waves 0 .. G-1 each run one image's attention exactly as attention_mfma_kernel does (S^T = K Q^T on the matrix core, a
 //      query's scores in one lane quad: wavefront softmax; P re-used in place as the operand of O^T = V^T P^T; V by transposed
 //      LDS reads) with every fragment read from LDS, and store the image's [S x 64] output slice.
-// The 12 head-blocks of an image group are consecutive on ONE XCD (bijective XCD remap, head fastest), so the group's 384 KB
-// activation tile is fetched into that XCD's L2 once.
+// Block order (bijective XCD remap, then units of 6 image groups x half the heads): the blocks resident on an XCD share six 384 KB
+// activation tiles and six heads' weights (4.1 MB, the size of that XCD's L2).
 #include "gemm_common.h"
 
 namespace {
@@ -50,7 +50,14 @@ __global__ __launch_bounds__(512, 2) void fused_qkv_attn_kernel(FusedK p) {
         const int nx = 8, q = p.nwg / nx, r = p.nwg % nx, x = bid % nx, i = bid / nx;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
     }
-    const int grp = bid / p.heads, head = bid % p.heads;
+    // L2 working set (4 MiB per XCD, 32 resident blocks): a unit of 36 consecutive blocks = 6 image groups x HALF the heads
+    // (6 activation tiles 2.3 MB + 6 heads' weights 1.8 MB), the next unit the same groups x the other half - the activation
+    // tiles are fetched once, the weight halves once per 6 groups (head-fastest over all 12 heads needed all 3.5 MB of weights
+    // plus the tiles at once and re-fetched the weights per group: 985 MB of fabric traffic per launch against 318 MB algorithmic)
+    const int hh = p.heads % 2 == 0 ? p.heads / 2 : p.heads, halves = p.heads / hh, per_unit = 6 * hh;
+    const int unit = bid / per_unit, in_unit = bid % per_unit;
+    const int grp = (unit / halves) * 6 + in_unit / hh, head = (unit % halves) * hh + in_unit % hh;
+    if (grp * p.G >= p.n_img) return;                 // ragged last group batch (block-uniform, before any barrier)
     const int M = p.n_img * p.S;
     const int m0 = grp * p.G * p.S;
     const int n_live_img = min(p.G, p.n_img - grp * p.G);
@@ -307,7 +314,8 @@ int ofx_launch_fused_qkv_attn(const void* X, const void* Wqkv, const float* bias
     FusedK k;
     k.X = (const char*)X; k.Wqkv = (const char*)Wqkv; k.out = (char*)out; k.bias = bias; k.row_stat = row_stat; k.col_sum = col_sum;
     k.n_img = n_img; k.S = S; k.Wm = Wm; k.heads = heads; k.ldx = ldx; k.ldo = ldo; k.G = FQ_TM / S; k.scale = scale;
-    k.nwg = ((n_img + k.G - 1) / k.G) * heads;
+    const int groups = (n_img + k.G - 1) / k.G;
+    k.nwg = ((groups + 5) / 6) * 6 * heads;            // whole units of 6 groups (blocks of the ragged tail exit at once)
     static DeviceOnce attr;
     TRY(attr.run([]() -> int {
         OFX_HIP(hipFuncSetAttribute((const void*)fused_qkv_attn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, FQ_LDS));
