@@ -10,7 +10,9 @@ from outfitx_amd import _lib as L
 SHAPES = [("vit qkv", 102400, 2304, 768, "b"), ("vit out", 102400, 768, 768, "r"), ("vit fc1", 102400, 3072, 768, "g"),
           ("vit fc2", 102400, 768, 3072, "r"), ("patch", 100352, 768, 3072, "f"), ("txt qkv", 16384, 1536, 512, "b"),
           ("txt out", 16384, 512, 512, "r"), ("txt fc1", 16384, 2048, 512, "g"), ("txt fc2", 16384, 512, 2048, "r"),
-          ("set qkv x3", 2304, 3072, 3072, "f"), ("set fc2 x3", 2304, 1024, 6144, "r")]
+          ("set qkv x3", 2304, 3072, 3072, "f"), ("set fc2 x3", 2304, 1024, 6144, "r"),
+          # the three-product text tower (K' = 3K): qkv (fp32 out), out-proj, fc1, fc2
+          ("t3 qkv", 16384, 1536, 1536, "f"), ("t3 out", 16384, 512, 1536, "r"), ("t3 fc1", 16384, 2048, 1536, "g"), ("t3 fc2", 16384, 512, 6144, "r")]
 
 
 def main():
