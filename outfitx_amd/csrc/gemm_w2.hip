@@ -22,7 +22,7 @@
 
 namespace {
 
-template <typename T, int ABL = 0>      // ABL (make DIAG=1, wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads after step 0, 3 both, 5 DMA issued BEFORE the fragment reads
+template <typename T, int ABL = 0>      // ABL (make DIAG=1; 1-3 give wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads after step 0, 3 both, 5 DMA issued AFTER the fragment reads (the first shipped order)
 __global__ __launch_bounds__(512, 2) void gemm_w2_kernel(KArgs p) {
     typedef typename OpT<T>::v8 v8;
     constexpr int TM = 256, TN = 256, BK2 = 32, PART = TM * BK2 * 2, STAGE = 3 * PART, NST = 3;      // 16 KiB per operand, 48 KiB per stage

@@ -68,9 +68,7 @@ for k, s in sorted(stats.items(), key=lambda kv: -kv[1]["total_ns"]):
     row = {"kernel": k, "calls": s["calls"], "avg_us": round(s["total_ns"] / s["calls"] / 1e3, 1), "total_ms": round(s["total_ns"] / 1e6, 3),
            "mfma_util": round(busy / (gui * 1024.0), 4) if gui else None,
            "mfma_tflops_executed": round(mops * scale / t / 1e12, 1) if mops else 0.0,
-           "hbm_bytes_per_call": round(byts / max(s["calls"], 1)), "hbm_gb_s": round(byts / t / 1e9, 1) if byts else 0.0,
-           "clock_ghz_in_pmc_pass": round(gui / (c.get("_ns", 0) or 1), 3) if False else None}
-    row.pop("clock_ghz_in_pmc_pass")
+           "hbm_bytes_per_call": round(byts / max(s["calls"], 1)), "hbm_gb_s": round(byts / t / 1e9, 1) if byts else 0.0}
     rows.append(row)
     tot["ns"] += s["total_ns"]; tot["busy"] += busy; tot["gui"] += gui; tot["mops"] += mops * scale; tot["bytes"] += byts
 gemm = [r for r in rows if "gemm" in r["kernel"] or "fused_qkv" in r["kernel"]]
