@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define OFX_ABI_VERSION 2
+#define OFX_ABI_VERSION 3
 
 enum { OFX_OK = 0, OFX_EINVAL = -1, OFX_ESHAPE = -2, OFX_EHIP = -3, OFX_EWORKSPACE = -4, OFX_ESTATE = -5 };
 enum ofx_dtype { OFX_F32 = 0, OFX_BF16 = 1, OFX_F16 = 2 };
@@ -63,8 +63,11 @@ typedef struct ofx_model_desc {
     /* Operand scheme of the towers beyond one product per term (all zero = single product everywhere):
      * vit_w2_mask: OFX_W2_* bits - these ViT GEMMs multiply against split (hi, lo) weights, two MFMA products per weight;
      * txt_x3:      the text tower runs three products per term (hi*hi + lo*hi + hi*lo, K-concatenated);
-     * proj_x3:     the ViT's post-LayerNorm + visual_projection tail runs three products per term. */
-    int vit_w2_mask, txt_x3, proj_x3;
+     * proj_x3:     the ViT's post-LayerNorm + visual_projection tail runs three products per term;
+     * vit_x3:      the whole ViT runs three products per term (fp32 residual stream, materialised LayerNorms; the MFMA attention core
+     *              stays on once-rounded q, k, v, P): ~1.5e-4 end to end on any weight draw at 1.9x the time of the default scheme;
+     *              vit_w2_mask then only matters for the patch embedding. */
+    int vit_w2_mask, txt_x3, proj_x3, vit_x3;
 } ofx_model_desc;
 enum { OFX_W2_PATCH = 1, OFX_W2_OUT = 4, OFX_W2_FC2 = 16 };
 

@@ -19,16 +19,19 @@ PREC_BF16, PREC_F16, PREC_BF16X3 = 0, 1, 2
 OUT_F32, OUT_OP, OUT_SPLIT3 = 0, 1, 2
 OP_SET_ENCODER, OP_VIT, OP_TEXT, OP_TOPK = 0, 1, 2, 3
 PRECISIONS = {"bf16": PREC_BF16, "f16": PREC_F16, "fp16": PREC_F16, "bf16x3": PREC_BF16X3}
-# CLIP tower operand schemes: name -> (operand type, vit_w2_mask, txt_x3, proj_x3).
+# CLIP tower operand schemes: name -> (operand type, vit_w2_mask, txt_x3, proj_x3, vit_x3).
 #   "bf16" / "f16": one MFMA product per term everywhere (fastest; 4e-3 / 5e-4 typical at the tower outputs).
 #   "f16w2" (default): f16 operands; the ViT's patch-embedding, out-proj and fc2 GEMMs multiply against split (hi, lo) weights
 #   (two products per weight), the text tower and the ViT's projection tail run three products per term - the scheme that
 #   holds the end-to-end CP logit within 1e-3 of the fp32 reference on every weight seed tried (tests/studies/operand_scheme_cpu.py).
 W2_PATCH, W2_OUT, W2_FC2 = 1, 4, 16
 TOWER_SCHEMES = {
-    "bf16": (PREC_BF16, 0, 0, 0), "f16": (PREC_F16, 0, 0, 0), "fp16": (PREC_F16, 0, 0, 0),
-    "f16w2": (PREC_F16, W2_PATCH | W2_OUT | W2_FC2, 1, 1),
-    "bf16w2": (PREC_BF16, W2_PATCH | W2_OUT | W2_FC2, 1, 1),
+    "bf16": (PREC_BF16, 0, 0, 0, 0), "f16": (PREC_F16, 0, 0, 0, 0), "fp16": (PREC_F16, 0, 0, 0, 0),
+    "f16w2": (PREC_F16, W2_PATCH | W2_OUT | W2_FC2, 1, 1, 0),
+    "bf16w2": (PREC_BF16, W2_PATCH | W2_OUT | W2_FC2, 1, 1, 0),
+    # every tower GEMM in three products (the patch embedding against split weights; the ViT's MFMA attention core stays on f16
+    # q, k, v, P): 1.3-1.8e-4 end to end on the default scheme's worst seeds, 1.9x the time (60.5 vs 32 ms per cfg2 step)
+    "f16x3": (PREC_F16, W2_PATCH, 1, 1, 1), "bf16x3": (PREC_BF16, W2_PATCH, 1, 1, 1),
 }
 DEFAULT_TOWER_PRECISION = "f16w2"
 ACTS = {"none": ACT_NONE, "quick_gelu": ACT_QUICK_GELU, "gelu": ACT_GELU, "mish": ACT_MISH}
@@ -43,7 +46,7 @@ class ModelDesc(C.Structure):
         "d_model", "n_head", "d_ffn", "n_layers", "max_items", "outfit_act", "outfit_precision",
         "vit_width", "vit_layers", "vit_heads", "vit_mlp", "vit_patch", "vit_image", "vit_act",
         "txt_width", "txt_layers", "txt_heads", "txt_mlp", "txt_vocab", "txt_max_pos", "txt_act", "txt_eos_id",
-        "proj_dim", "tower_precision")] + [("ln_eps", C.c_float)] + [(n, C.c_int) for n in ("vit_w2_mask", "txt_x3", "proj_x3")]
+        "proj_dim", "tower_precision")] + [("ln_eps", C.c_float)] + [(n, C.c_int) for n in ("vit_w2_mask", "txt_x3", "proj_x3", "vit_x3")]
 
 
 class ProfRecord(C.Structure):
@@ -125,7 +128,7 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)        # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.ofx_abi_version() != 2:
+    if lib.ofx_abi_version() != 3:
         raise OfxError("libofx_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

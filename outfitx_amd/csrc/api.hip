@@ -165,7 +165,7 @@ struct ofx_handle {
     float *outfit_token, *tgt_img_emb, *cp_w, *cp_b; void* cir_w; void* cir_w_t = nullptr;   // cir_w_t: W^T operand copy (training dgrad)
     // towers
     int tw_dtype;
-    int vit_w2_mask = 0, txt_x3 = 0, proj_x3 = 0;    // operand scheme (ofx_model_desc); x3 towers hold ONLY the K-concatenated [hi | hi | lo] weight copies
+    int vit_w2_mask = 0, txt_x3 = 0, proj_x3 = 0, vit_x3 = 0;    // operand scheme (ofx_model_desc); x3 towers hold ONLY the K-concatenated [hi | hi | lo] weight copies
     void* v_patch_w2 = nullptr; void* v_proj_w3 = nullptr;
     // training: events armed for the NEXT backward call (ofx_train_arm_layer_events), one per outfit-transformer layer
     std::vector<hipEvent_t> bwd_events;
@@ -208,7 +208,7 @@ extern "C" ofx_handle* ofx_create(int device, const ofx_model_desc* desc) {
     h->ot_kmul = d.outfit_precision == OFX_PREC_BF16X3 ? 3 : 1;
     h->ot_ffn_pad = pad128(d.d_ffn);
     h->tw_dtype = d.tower_precision == OFX_PREC_F16 ? OFX_F16 : OFX_BF16;
-    h->vit_w2_mask = d.vit_w2_mask; h->txt_x3 = d.txt_x3 != 0; h->proj_x3 = d.proj_x3 != 0;
+    h->vit_w2_mask = d.vit_w2_mask; h->txt_x3 = d.txt_x3 != 0; h->vit_x3 = d.vit_x3 != 0; h->proj_x3 = d.proj_x3 != 0 || h->vit_x3;
     return h;
 }
 
@@ -355,7 +355,8 @@ extern "C" int ofx_pack_vision_weights(ofx_handle* h, const void* const* P, int 
     for (int i = 0; i < n; ++i) OFX_REQUIRE(P[i], OFX_EINVAL, "pack_vision: tensor %d is NULL", i);
     hipStream_t s = (hipStream_t)stream;
     const size_t W = d.vit_width, MLP = d.vit_mlp, KP = 3 * (size_t)d.vit_patch * d.vit_patch, g = d.vit_image / d.vit_patch, S = g * g + 1, PD = d.proj_dim;
-    TRY(h->a_vis.reserve(clip_layer_bytes(W, MLP, h->vit_w2_mask) * d.vit_layers + 6 * W * KP + 8 * PD * W + 4 * (W + S * W + 4 * W) + 18 * 256));
+    const bool vx3 = h->vit_x3 != 0;
+    TRY(h->a_vis.reserve(clip_layer_bytes(W, MLP, h->vit_w2_mask, vx3) * d.vit_layers + 6 * W * KP + 8 * PD * W + 4 * (W + S * W + 4 * W) + 18 * 256));
     Arena& A = h->a_vis;
     CopyBatch copies;
     const int dt = h->tw_dtype;
@@ -367,7 +368,7 @@ extern "C" int ofx_pack_vision_weights(ofx_handle* h, const void* const* P, int 
     h->v_pre_g = A.take<float>(W); TRY(copy_f32(h->v_pre_g, P[3], W, s));
     h->v_pre_b = A.take<float>(W); TRY(copy_f32(h->v_pre_b, P[4], W, s));
     h->vl.resize(d.vit_layers);
-    for (int l = 0; l < d.vit_layers; ++l) TRY(pack_clip_layer(A, h->vl[l], P + 5 + 16 * l, W, MLP, dt, s, h->vit_w2_mask));
+    for (int l = 0; l < d.vit_layers; ++l) TRY(pack_clip_layer(A, h->vl[l], P + 5 + 16 * l, W, MLP, dt, s, h->vit_w2_mask, vx3));
     const void* const* t = P + 5 + 16 * d.vit_layers;
     h->v_post_g = A.take<float>(W); TRY(copy_f32(h->v_post_g, t[0], W, s));
     h->v_post_b = A.take<float>(W); TRY(copy_f32(h->v_post_b, t[1], W, s));
@@ -464,7 +465,7 @@ size_t vit_bytes(const ofx_handle* h, int n, ClipWs* w, void* ws, size_t cap) {
     const size_t g = d.vit_image / d.vit_patch, S = g * g + 1, KP = 3 * (size_t)d.vit_patch * d.vit_patch;
     Bump b(ws, cap);
     // the patch matrix aliases U and the fp32 patch-GEMM output aliases QKV (both dead before the layers start)
-    size_t r = carve_clip(b, (size_t)n * S, n, d.vit_width, d.vit_mlp, d.proj_dim, (size_t)n * g * g * KP * 2, (size_t)n * g * g * d.vit_width * 4, w, 1, 2);
+    size_t r = carve_clip(b, (size_t)n * S, n, d.vit_width, d.vit_mlp, d.proj_dim, (size_t)n * g * g * KP * 2, (size_t)n * g * g * d.vit_width * 4, w, h->vit_x3 ? 3 : 1, h->vit_x3 ? 3 : 2);
     return align_up(r, 256);
 }
 size_t txt_bytes(const ofx_handle* h, int n, int Tc, ClipWs* w, void* ws, size_t cap) {
@@ -699,7 +700,7 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
 // writing [hi | lo | hi] rows, weights packed [hi | hi | lo] (the outfit transformer's bf16x3 scheme in the towers' operand type).
 // q | k | v leave the projection rounded once to the operand type for the MFMA attention, whose output is again (hi, lo).
 static int clip_layer_x3(const ClipLayer& L, const ClipWs& w, int rows, int nseq, int S, int W, int MLP, int heads, int act,
-                         float eps, int causal, const int64_t* key_mask, int mask_ld, int dt, const int* pool_idx, hipStream_t s) {
+                         float eps, int causal, const int64_t* key_mask, int mask_ld, int dt, const int* pool_idx, hipStream_t s, bool mfma_attn = false) {
     LnArgs ln{w.X, nullptr, L.g1, L.be1, w.H, rows, W, 3 * W, OFX_OUT_SPLIT3, eps};
     TRY(ofx_launch_layernorm(ln, dt, s));
     GemmArgs g1{}; g1.A = w.H; g1.W = L.w_qkv; g1.C = w.QKV; g1.bias = L.b_qkv; g1.M = rows; g1.N = 3 * W; g1.K = 3 * W; g1.k_mult = 3; g1.lda = 3 * W;
@@ -707,7 +708,9 @@ static int clip_layer_x3(const ClipLayer& L, const ClipWs& w, int rows, int nseq
     // key-padding mask, up to 64 rows per sequence): rounding q, k, v, P to the operand type alone leaves 3.5e-4 at the text embedding
     // (tests/studies/operand_scheme_cpu.py); the single-tile MFMA kernel stays as the fallback beyond 64 rows (never reached:
     // ofx_clip_text_fwd caps the computed tokens at 64)
-    const bool f32_attn = S <= 64;
+    // (the ViT in its three-product mode keeps the MFMA attention: 2,048 images x 12 heads of 50 tokens in fp32 VALU arithmetic would
+    // cost more than the layer's GEMMs, and the attention core's operand rounding is the smallest term of its budget, 6e-5)
+    const bool f32_attn = S <= 64 && !mfma_attn;
     g1.ldc = 3 * W; g1.act = OFX_ACT_NONE; g1.out_kind = f32_attn ? OFX_OUT_F32 : OFX_OUT_OP;
     TRY(ofx_launch_gemm(g1, dt, s));
     if (f32_attn) {
@@ -748,7 +751,7 @@ static int clip_layers(const std::vector<ClipLayer>& Ls, const ClipWs& w, int ro
                        const int* pool_idx, hipStream_t s, bool stats_ready = false, bool pool_first = false, bool x3 = false) {
     if (x3) {
         for (size_t l = 0; l < Ls.size(); ++l)
-            TRY(clip_layer_x3(Ls[l], w, rows, nseq, S, W, MLP, heads, act, eps, causal, key_mask, mask_ld, dt, l + 1 == Ls.size() ? pool_idx : nullptr, s));
+            TRY(clip_layer_x3(Ls[l], w, rows, nseq, S, W, MLP, heads, act, eps, causal, key_mask, mask_ld, dt, l + 1 == Ls.size() ? pool_idx : nullptr, s, !causal && !key_mask));
         return OFX_OK;
     }
     const bool fold = clip_fold(W);
@@ -792,11 +795,11 @@ static int vit_core(ofx_handle* h, const float* pixels, const RawImages* raw, in
         gp.act = OFX_ACT_NONE; gp.out_kind = OFX_OUT_F32;
         if (h->v_patch_w2) { gp.W = h->v_patch_w2; gp.K = 2 * KP; gp.a_wrap = KP; }
         TRY(ofx_launch_gemm(gp, dt, s));
-        const bool fold = clip_fold(W);                                  // the pre-LN kernel then also emits layer 0's operand copy + statistics
+        const bool fold = clip_fold(W) && !h->vit_x3;                    // the pre-LN kernel then also emits layer 0's operand copy + statistics
         TRY(ofx_launch_vit_embed_ln((const float*)w.QKV, h->v_cls, h->v_pos, h->v_pre_g, h->v_pre_b, fold && g_ln_fold == 2 ? nullptr : w.X, n, S, W, d.ln_eps, s, fold ? w.XB : nullptr,
                                     fold ? w.S : nullptr, dt, fold && g_ln_fold == 2 ? w.XLO : nullptr));
         TRY(ofx_launch_iota_rows(w.idx, n, S, s));                        // CLS rows
-        TRY(clip_layers(h->vl, w, rows, n, S, W, d.vit_mlp, d.vit_heads, d.vit_act, d.ln_eps, 0, nullptr, 0, dt, w.idx, s, fold, true));
+        TRY(clip_layers(h->vl, w, rows, n, S, W, d.vit_mlp, d.vit_heads, d.vit_act, d.ln_eps, 0, nullptr, 0, dt, w.idx, s, fold, true, h->vit_x3 != 0));
         const int pk = h->v_proj_w3 ? 3 : 1;          // the output tail in three products: post-LayerNorm rows [hi | lo | hi] x [hi | hi | lo]
         LnArgs ln{w.XP, nullptr, h->v_post_g, h->v_post_b, w.PL, n, W, pk * W, pk == 3 ? OFX_OUT_SPLIT3 : OFX_OUT_OP, d.ln_eps};
         TRY(ofx_launch_layernorm(ln, dt, s));

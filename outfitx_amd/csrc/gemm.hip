@@ -164,31 +164,42 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
 
 }  // namespace
 
-// Split-K plan for the 128x128 kernel: used when the tile grid leaves most of the chip idle and K is deep.
-// Returns the number of K splits (1 = none).  Shared by the launcher and the workspace sizing (api.hip).
-// cost model (us), measured on the 128x128 kernel (tools/_exp_small_m.py): ~1.06 us per k-tile and wave of 512 co-resident
-// blocks; a split adds the slab written once and read once (~5 TB/s) and the reduce launch.  M = 2304 x N = 1024 (144
-// blocks) is faster UNSPLIT (17 vs 26 us); M = 288 (24 blocks, K = 3072) wants 8 splits (51 -> 13 us).
-static int splitk_plan_cost(int M, int N, int K, double* cost) {
-    const long blocks = (long)((M + 127) / 128) * (N / 128);
-    const int nk = K / 64;
-    int best = 1;
-    double best_t = (double)((blocks + 511) / 512) * nk * 1.06;
-    if (g_gemm_splitk != 0 && N % 128 == 0 && K % 64 == 0 && blocks < 256 && nk >= 16) {
-        for (int s = 2; s <= 8 && s <= nk / 4; ++s) {
-            const int kps = (nk + s - 1) / s;
-            if ((nk + kps - 1) / kps != s) continue;          // every split owns at least one k-tile
-            const double t = (double)((blocks * s + 511) / 512) * kps * 1.06 + 2.0 * s * M * N * 4.0 / 5.0e6 + 3.0;
-            if (t < best_t) { best_t = t; best = s; }
+// Plan for problems the big-tile kernels cannot fill (small M): tile height (128 rows, 2 blocks per CU = 512 slots; or 64 rows, 3 per
+// CU = 768 slots) x deterministic split-K over blockIdx.y.  Cost model (us), measured on these kernels: ~1.06 / ~0.65 us per k-tile
+// and round of co-resident 128- / 64-row blocks; a split adds the fp32 slab written once and read once (~5 TB/s) and the reduce
+// launch.  M = 2304 x N = 1024 (144 blocks) is faster UNSPLIT (17 vs 26 us); M = 288 (K = 3072) wants the split.
+// g_gemm_splitk: 0 = never split, 1 = plan, >= 2 = forced (experiments: low byte = splits, bit 8 = 64-row tiles).
+struct SmallPlan { int tile64, splits; double cost; };
+static SmallPlan plan_small(int M, int N, int K, bool allow_split, bool allow64) {
+    const int nk = K / BK;
+    SmallPlan best{0, 1, 1e30};
+    if (g_gemm_splitk >= 2) {
+        SmallPlan f{(g_gemm_splitk >> 8) & 1, g_gemm_splitk & 0xff, 0.0};
+        if (f.tile64 && !allow64) f.tile64 = 0;
+        if (!allow_split || f.splits > nk) f.splits = 1;
+        const int kps = (nk + f.splits - 1) / f.splits;
+        f.splits = (nk + kps - 1) / kps;                       // every split owns at least one k-tile
+        return f;
+    }
+    for (int t64 = 0; t64 <= (allow64 ? 1 : 0); ++t64) {
+        const long blocks = (long)((M + (t64 ? 63 : 127)) / (t64 ? 64 : 128)) * (N / 128);
+        const long slots = t64 ? 768 : 512;
+        const double per = t64 ? 0.65 : 1.06;
+        for (int sp = 1; sp <= 16; ++sp) {
+            if (sp > 1 && !(allow_split && g_gemm_splitk != 0 && blocks < 256 && nk >= 16 && sp <= nk / 4)) break;
+            const int kps = (nk + sp - 1) / sp;
+            if ((nk + kps - 1) / kps != sp) continue;
+            double t = (double)((blocks * sp + slots - 1) / slots) * kps * per + (t64 ? 1.0 : 0.0);
+            if (sp > 1) t += 2.0 * sp * M * N * 4.0 / 5.0e6 + 3.0;
+            if (t < best.cost) best = SmallPlan{t64, sp, t};
         }
     }
-    if (cost) *cost = best_t;
     return best;
 }
-int ofx_gemm_splitk_plan(int M, int N, int K) { return splitk_plan_cost(M, N, K, nullptr); }
+int ofx_gemm_splitk_plan(int M, int N, int K) { return plan_small(M, N, K, true, M > 64).splits; }
 size_t ofx_gemm_splitk_bytes(int M, int N, int K) {
-    const int s = ofx_gemm_splitk_plan(M, N, K);
-    return s > 1 ? (size_t)s * M * N * 4 : 0;
+    const int sp = g_gemm_splitk >= 2 ? 16 : ofx_gemm_splitk_plan(M, N, K);
+    return sp > 1 ? (size_t)sp * M * N * 4 : 0;
 }
 
 
@@ -270,28 +281,26 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
         int gm = g_gemm_group_m;
         if (gm <= 0) { gm = (int)((3u << 20) / ((size_t)BM * g.K * 2) / 2); gm = gm < 1 ? 1 : (gm > 8 ? 8 : gm); }
         k.group_m = gm;
-        const int splits = (g.slab && !g.xb_out && !g.stat_part && !g.row_stat) ? ofx_gemm_splitk_plan(g.M, g.N, g.K) : 1;
+        const bool can_split = g.slab && !g.xb_out && !g.stat_part && !g.row_stat;
+        const bool can64 = (kind == 5) || (kind == 1 && g_gemm_kernel == 0 && g.M > 64 && (long)k.tiles_m * k.tiles_n <= 384);
+        SmallPlan pl = plan_small(g.M, g.N, g.K, can_split, can64);
+        if (kind == 5) pl.tile64 = 1;
+        const int splits = pl.splits;
         k.splits = splits; k.slab = (float*)g.slab; k.m_slab = g.M;
         k.kt_per_split = splits > 1 ? (g.K / BK + splits - 1) / splits : 0;
         if (splits > 1) OFX_REQUIRE(g.slab_bytes >= (size_t)splits * g.M * g.N * 4, OFX_EWORKSPACE, "gemm: split-K slab too small");
-        // 64-row tiles when the 128^2 grid would leave most CUs idle and no split-K is planned (the training step's M ~ 2k GEMMs with
-        // N = 1024: 144 -> 288 blocks; tools/_exp_small_m.py); kind 5 forces them
-        // (~0.65 us per k-tile and wave of 768 co-resident 64x128 blocks, measured) against the best 128^2 plan
-        const long blocks128 = (long)k.tiles_m * k.tiles_n;
-        bool use64 = kind == 5;
-        if (kind == 1 && g_gemm_kernel == 0 && blocks128 <= 384 && g.M > 64) {      // one wave of 768 co-resident 64-row blocks: never slower than 128^2 (measured)
-            double t128;
-            splitk_plan_cost(g.M, g.N, g.K, &t128);
-            if (splits == 1) t128 = (double)((blocks128 + 511) / 512) * (g.K / BK) * 1.06;
-            const long blocks64 = (long)((g.M + 63) / 64) * k.tiles_n;
-            use64 = (double)((blocks64 + 767) / 768) * (g.K / BK) * 0.65 + 1.0 < t128;
-        }
-        if (use64) {
-            k.splits = 1; k.kt_per_split = 0;
+        if (pl.tile64) {        // 64-row tiles, three blocks per CU: grids that would leave CUs idle with 128-row tiles (with or without split-K)
             k.tiles_m = (g.M + 63) / 64; k.nwg = k.tiles_m * k.tiles_n; k.group_m = 2 * gm;
-            const dim3 grid64(k.nwg, 1);
-            if (op_dtype == OFX_F16) OFX_PLAUNCH(true, (gemm_128x128_kernel<f16_t, 0, 2>), grid64, dim3(256), GEMM64_LDS_BYTES, s, k);
-            else OFX_PLAUNCH(true, (gemm_128x128_kernel<bf16_t, 0, 2>), grid64, dim3(256), GEMM64_LDS_BYTES, s, k);
+            const dim3 grid64(k.nwg, splits);
+            const bool one64 = splits <= 1;
+            if (op_dtype == OFX_F16) OFX_PLAUNCH(one64, (gemm_128x128_kernel<f16_t, 0, 2>), grid64, dim3(256), GEMM64_LDS_BYTES, s, k);
+            else OFX_PLAUNCH(one64, (gemm_128x128_kernel<bf16_t, 0, 2>), grid64, dim3(256), GEMM64_LDS_BYTES, s, k);
+            if (splits > 1) {
+                size_t tot = (size_t)g.M * (g.N / 4);
+                int rg = (int)((tot + 255) / 256); if (rg > 2048) rg = 2048;
+                if (op_dtype == OFX_F16) OFX_PLAUNCH(true, splitk_reduce_kernel<f16_t>, dim3(rg), dim3(256), 0, s, k);
+                else OFX_PLAUNCH(true, splitk_reduce_kernel<bf16_t>, dim3(rg), dim3(256), 0, s, k);
+            }
             OFX_LAUNCH_CHECK();
             return OFX_OK;
         }

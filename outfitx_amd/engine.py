@@ -30,7 +30,7 @@ def _f32c(t: torch.Tensor, device) -> torch.Tensor:
 class Engine:
     """One per (module, device).  `precision`: MFMA operand format of the outfit transformer
     ('bf16x3' | 'bf16' | 'f16'); `tower_precision`: operand scheme of the CLIP towers (a key of _lib.TOWER_SCHEMES:
-    'f16w2' (default, 1e-3-compliant) | 'f16' | 'bf16' | 'bf16w2')."""
+    'f16w2' (default, 1e-3-compliant) | 'f16x3' (every tower GEMM three-product) | 'f16' | 'bf16' | 'bf16w2')."""
 
     def __init__(self, device: torch.device, desc: Optional[L.ModelDesc] = None,
                  precision: str = "bf16x3", tower_precision: str = L.DEFAULT_TOWER_PRECISION):
@@ -42,7 +42,7 @@ class Engine:
         d.outfit_precision = L.PRECISIONS[precision]
         if tower_precision not in L.TOWER_SCHEMES:
             raise ValueError(f"unknown tower_precision {tower_precision!r}; one of {sorted(L.TOWER_SCHEMES)}")
-        d.tower_precision, d.vit_w2_mask, d.txt_x3, d.proj_x3 = L.TOWER_SCHEMES[tower_precision]
+        d.tower_precision, d.vit_w2_mask, d.txt_x3, d.proj_x3, d.vit_x3 = L.TOWER_SCHEMES[tower_precision]
         self.desc = d
         self.h = self.lib.ofx_create(self.device.index, C.byref(d))
         if not self.h:

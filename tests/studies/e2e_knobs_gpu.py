@@ -15,7 +15,7 @@ seeds = [int(a) for a in sys.argv[1:]] or [4, 6]
 B, n = 8, 8
 mean = torch.tensor(synth.CLIP_MEAN).view(1, 1, 3, 1, 1); std = torch.tensor(synth.CLIP_STD).view(1, 1, 3, 1, 1)
 variants = [("default", "f16w2", {}), ("fold=1", "f16w2", {6: 1}), ("fold=0", "f16w2", {6: 0}), ("fuse=0", "f16w2", {9: 0}), ("fold=0,fuse=0", "f16w2", {6: 0, 9: 0}),
-            ("f16 single", "f16", {}), ("f16w2x (all ViT GEMMs split)", "f16w2x", {})]
+            ("f16 single", "f16", {}), ("f16x3 (all tower GEMMs three-product)", "f16x3", {})]
 for ws in seeds:
     g = torch.Generator(); g.manual_seed(9000 + ws)
     u8 = torch.randint(0, 256, (B, n, 3, 224, 224), generator=g, dtype=torch.uint8)

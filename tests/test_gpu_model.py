@@ -106,8 +106,8 @@ def test_vit_tower_vs_reference_golden(model):
     px = synth.pixel_values(int(g["seed"]), 4)
     enc = model.item_encoder.image_enc
     assert enc.tower_precision == DEFAULT_TOWERS == "f16w2"
-    for prec, tol in ((DEFAULT_TOWERS, 1e-3), ("bf16", 3e-2), ("f16", 4e-3)):      # the default scheme holds the north star's bound
-        enc.tower_precision = prec
+    for prec, tol in ((DEFAULT_TOWERS, 1e-3), ("f16x3", 3e-4), ("bf16", 3e-2), ("f16", 4e-3)):      # the default scheme holds the north star's bound;
+        enc.tower_precision = prec                      # f16x3: what is left is the MFMA attention core's f16 q, k, v, P (1.2e-4 measured)
         out = enc(cu(px).view(4, 1, 3, 224, 224), normalize=False).view(4, 512)
         e = rel_err(out.cpu().numpy(), g["image_embeds"])
         print(f"vit {prec}: {e:.2e}")
@@ -119,7 +119,7 @@ def test_text_tower_vs_reference_golden(model):
     g = golden("text_n8")
     ids, att = synth.token_batch(int(g["seed"]), 8, 64, g["n_real"])
     enc = model.item_encoder.text_enc
-    for prec, tol in ((DEFAULT_TOWERS, 1e-3), ("bf16", 3e-2), ("f16", 4e-3)):
+    for prec, tol in ((DEFAULT_TOWERS, 1e-3), ("f16x3", 5e-5), ("bf16", 3e-2), ("f16", 4e-3)):
         enc.tower_precision = prec
         dev_in = {"input_ids": cu(ids).view(8, 1, 64), "attention_mask": cu(att).view(8, 1, 64)}      # ids on device: all T tokens computed
         host_in = {"input_ids": torch.from_numpy(ids).view(8, 1, 64), "attention_mask": torch.from_numpy(att).view(8, 1, 64)}
@@ -583,8 +583,7 @@ def _outlier_channels(sd):
     return sd
 
 
-@pytest.mark.parametrize("wseed", [1, 2, 3, 4, 5, 6, -3])
-def test_cfg2_end_to_end_within_1e3_on_every_weight_seed(wseed):
+def _cfg2_end_to_end(wseed, towers, bound):
     """BASELINE configs[1] end to end (images + token ids -> towers -> fuser -> set transformer -> CP logit) in the DEFAULT operand
     scheme - the one bench.py measures - against the fp32 oracle O.cp_forward(O.item_encoder(...)), on six independent weight
     draws (the error is dominated by a fixed, per-weight-set perturbation, so the seed, not the input batch, is what varies it;
@@ -597,8 +596,9 @@ def test_cfg2_end_to_end_within_1e3_on_every_weight_seed(wseed):
     CP = tasks()[0]
     outliers = wseed < 0                 # seed -3: weight seed 3 with massive residual-stream channels (f16 operands, (hi, lo) stream and
     wseed = abs(wseed)                   # LayerNorm folding must keep the small channels' precision next to the large ones)
-    m = OutfitX(OutfitXConfig(item_encoder=ItemEncoderConfig(type="clip")))
-    assert m.item_encoder.image_enc.tower_precision == DEFAULT_TOWERS and m.precision == "bf16x3"
+    m = OutfitX(OutfitXConfig(item_encoder=ItemEncoderConfig(type="clip"))) if towers is None else \
+        OutfitX(OutfitXConfig(item_encoder=ItemEncoderConfig(type="clip")), tower_precision=towers)
+    assert m.item_encoder.image_enc.tower_precision == (towers or DEFAULT_TOWERS) and m.precision == "bf16x3"
     sd = synth.full_state_dict(wseed)
     if outliers:
         sd = _outlier_channels(sd)
@@ -619,7 +619,20 @@ def test_cfg2_end_to_end_within_1e3_on_every_weight_seed(wseed):
     emb = O.item_encoder(px.numpy(), ids.reshape(B, L, 64), att.reshape(B, L, 64), Wv, synth.text_weights(wseed))
     ref = O.cp_forward(emb, mask, synth.outfit_transformer_weights(wseed))
     e = rel_err(got, ref)
-    print(f"cfg2 end to end, weight seed {wseed}{' + outlier channels' if outliers else ''}: {e:.2e}")
-    assert e < 1e-3, e
+    print(f"cfg2 end to end ({towers or DEFAULT_TOWERS}), weight seed {wseed}{' + outlier channels' if outliers else ''}: {e:.2e}")
+    assert e < bound, e
     del m
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("wseed", [1, 2, 3, 4, 5, 6, -3])
+def test_cfg2_end_to_end_within_1e3_on_every_weight_seed(wseed):
+    _cfg2_end_to_end(wseed, None, 1e-3)
+
+
+@pytest.mark.parametrize("wseed", [4, 6])
+def test_cfg2_end_to_end_three_product_towers(wseed):
+    """tower_precision='f16x3' (every tower GEMM in three products, the ViT's attention core still on f16 q, k, v, P): the weight
+    seeds on which the default scheme sits closest to the bound (4: 7.9e-4, 6: 4.3e-4) measure 1.3e-4 / 1.8e-4 - the slower mode
+    (60.5 vs 32 ms per cfg2 step) for callers who want a 5x margin on any weight draw."""
+    _cfg2_end_to_end(wseed, "f16x3", 4e-4)
