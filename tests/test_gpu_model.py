@@ -95,7 +95,7 @@ def test_cp_full_size_cfg3_vs_oracle_and_batch_invariance(model):
         shuf = model(task=CP, outfit_embedding=cu(emb[perm]), outfit_mask=cu(mask[perm])).cpu().numpy()
         solo = model(task=CP, outfit_embedding=cu(emb[5:6]), outfit_mask=cu(mask[5:6])).cpu().numpy()
     assert np.array_equal(full[perm], shuf)                 # same kernels, same per-row arithmetic: bit-identical
-    assert rel_err(solo, full[5:6]) < 1e-5                   # batch of 1 takes the split-K GEMM path: other fp32 summation order
+    assert rel_err(solo, full[5:6]) < 5e-5                   # batch of 1 takes the 64-row split-K GEMM path (up to 16 K slices): other fp32 summation order at bf16x3's 2^-16 floor
     sub = np.arange(0, B, 22)[:48]
     want = O.cp_forward(emb[sub], mask[sub], synth.outfit_transformer_weights(W_SEED))
     assert rel_err(full[sub], want) < 1e-3
