@@ -560,6 +560,33 @@ def test_overlapped_gradient_reduction_equals_the_plain_one():
         dist.destroy_process_group()
 
 
+def test_rccl_packed_record_allgather_world1():
+    """parallel.sharded_topk's ONE collective - all_gather_into_tensor of the packed (global index int64 | distance fp32) byte record -
+    on RCCL itself (a world-size-1 group on this device: the byte dtype and the flat-output form are what must be accepted), and the
+    unpacking round trip."""
+    import socket
+    import torch.distributed as dist
+    nq, k = 37, 50
+    idx = torch.randint(0, 100000, (nq, k), dtype=torch.int64, device="cuda")
+    dst = torch.rand(nq, k, device="cuda")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        nb_i, nb_d = idx.numel() * 8, dst.numel() * 4
+        rec = torch.empty(nb_i + nb_d, dtype=torch.uint8, device="cuda")
+        rec[:nb_i] = idx.view(torch.uint8).reshape(-1); rec[nb_i:] = dst.view(torch.uint8).reshape(-1)
+        flat = torch.empty(nb_i + nb_d, dtype=torch.uint8, device="cuda")
+        dist.all_gather_into_tensor(flat, rec)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    allrec = flat.view(1, -1)
+    assert torch.equal(allrec[:, :nb_i].contiguous().view(torch.int64).view(1, nq, k)[0], idx)
+    assert torch.equal(allrec[:, nb_i:].contiguous().view(torch.float32).view(1, nq, k)[0], dst)
+
+
 def test_reference_trainer_step_verbatim():
     """The reference's train_epoch body (compatibility_prediction_trainer.py:57-81) line for line against our model: autocast,
     FocalLoss, /accumulation, GradScaler.scale(loss).backward(), unscale_, clip_grad_norm_, scaler.step, update, zero_grad,
