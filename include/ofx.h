@@ -69,7 +69,7 @@ typedef struct ofx_model_desc {
      *              vit_w2_mask then only matters for the patch embedding. */
     int vit_w2_mask, txt_x3, proj_x3, vit_x3;
 } ofx_model_desc;
-enum { OFX_W2_PATCH = 1, OFX_W2_OUT = 4, OFX_W2_FC2 = 16 };
+enum { OFX_W2_PATCH = 1, OFX_W2_QKV = 2, OFX_W2_OUT = 4, OFX_W2_FC1 = 8, OFX_W2_FC2 = 16 };
 
 /* Fills *d with the configuration of the reference's type='clip' model. */
 void ofx_default_desc(ofx_model_desc* d);

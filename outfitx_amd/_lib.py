@@ -24,11 +24,13 @@ PRECISIONS = {"bf16": PREC_BF16, "f16": PREC_F16, "fp16": PREC_F16, "bf16x3": PR
 #   "f16w2" (default): f16 operands; the ViT's patch-embedding, out-proj and fc2 GEMMs multiply against split (hi, lo) weights
 #   (two products per weight), the text tower and the ViT's projection tail run three products per term - the scheme that
 #   holds the end-to-end CP logit within 1e-3 of the fp32 reference on every weight seed tried (tests/studies/operand_scheme_cpu.py).
-W2_PATCH, W2_OUT, W2_FC2 = 1, 4, 16
+W2_PATCH, W2_QKV, W2_OUT, W2_FC1, W2_FC2 = 1, 2, 4, 8, 16
 TOWER_SCHEMES = {
     "bf16": (PREC_BF16, 0, 0, 0, 0), "f16": (PREC_F16, 0, 0, 0, 0), "fp16": (PREC_F16, 0, 0, 0, 0),
     "f16w2": (PREC_F16, W2_PATCH | W2_OUT | W2_FC2, 1, 1, 0),
     "bf16w2": (PREC_BF16, W2_PATCH | W2_OUT | W2_FC2, 1, 1, 0),
+    # every ViT weight split (qkv then runs as dual-weight GEMM + attention kernel instead of the fused kernel)
+    "f16w2x": (PREC_F16, W2_PATCH | W2_QKV | W2_OUT | W2_FC1 | W2_FC2, 1, 1, 0),
     # every tower GEMM in three products (the patch embedding against split weights; the ViT's MFMA attention core stays on f16
     # q, k, v, P): 1.3-1.8e-4 end to end on the default scheme's worst seeds, 1.9x the time (60.5 vs 32 ms per cfg2 step)
     "f16x3": (PREC_F16, W2_PATCH, 1, 1, 1), "bf16x3": (PREC_BF16, W2_PATCH, 1, 1, 1),

@@ -151,7 +151,9 @@ struct ClipLayer { void *w_qkv, *w_o, *w_fc1, *w_fc2; float *b_qkv, *b_o, *b_fc1
                    // LayerNorm-folded copies: W . gamma (rounded), column sums of the rounded rows, bias + W beta
                    void *w_qkv_f, *w_fc1_f; float *cs_qkv, *bf_qkv, *cs_fc1, *bf_fc1;
                    // split-weight copies [hi | lo] (GemmArgs::a_wrap) of the GEMMs in the tower's w2 mask; null otherwise
-                   void *w_o2 = nullptr, *w_fc22 = nullptr; };
+                   void *w_o2 = nullptr, *w_fc22 = nullptr;
+                   // ... of the LayerNorm consumers: folded (W . gamma split, column sums of hi + lo) and plain (LayerNorms materialised)
+                   void *w_qkv_f2 = nullptr, *w_fc1_f2 = nullptr, *w_qkv2 = nullptr, *w_fc12 = nullptr; float *cs_qkv2 = nullptr, *cs_fc12 = nullptr; };
 
 }  // namespace
 
@@ -200,7 +202,7 @@ extern "C" ofx_handle* ofx_create(int device, const ofx_model_desc* desc) {
     if (d.tower_precision != OFX_PREC_BF16 && d.tower_precision != OFX_PREC_F16) return bad("tower_precision must be BF16 or F16");
     if (d.outfit_precision < 0 || d.outfit_precision > 2) return bad("bad outfit_precision");
     if (d.n_layers < 1 || d.vit_layers < 1 || d.txt_layers < 1 || d.d_ffn < 1) return bad("layer counts / d_ffn must be positive");
-    if (d.vit_w2_mask & ~(OFX_W2_PATCH | OFX_W2_OUT | OFX_W2_FC2)) return bad("vit_w2_mask: only the patch, out-proj and fc2 GEMMs have split-weight copies");
+    if (d.vit_w2_mask & ~(OFX_W2_PATCH | OFX_W2_QKV | OFX_W2_OUT | OFX_W2_FC1 | OFX_W2_FC2)) return bad("vit_w2_mask: unknown bit");
     if (hipSetDevice(device) != hipSuccess) return bad("hipSetDevice failed");
     ofx_handle* h = new ofx_handle();
     h->device = device; h->d = d;
@@ -327,6 +329,7 @@ static int pack_clip_layer(Arena& A, ClipLayer& L, const void* const* q, size_t 
     L.g2 = A.take<float>(W); TRY(copy_f32(L.g2, q[14], W, s));
     L.be2 = A.take<float>(W); TRY(copy_f32(L.be2, q[15], W, s));
     L.w_qkv_f = L.w_fc1_f = nullptr; L.cs_qkv = L.bf_qkv = L.cs_fc1 = L.bf_fc1 = nullptr; L.w_o2 = L.w_fc22 = nullptr;
+    L.w_qkv_f2 = L.w_fc1_f2 = L.w_qkv2 = L.w_fc12 = nullptr; L.cs_qkv2 = L.cs_fc12 = nullptr;
     if (x3) return OFX_OK;
     // folded copies (q, k, v order as above: HF stores k, v, q, out in q[0..7])
     char* wf = A.take<char>(2 * 3 * W * W);
@@ -340,12 +343,30 @@ static int pack_clip_layer(Arena& A, ClipLayer& L, const void* const* q, size_t 
     // split-weight copies: row n = [hi(K) | lo(K)]
     if (w2_mask & OFX_W2_OUT) { L.w_o2 = A.take<char>(4 * W * W); TRY(ofx_launch_pack_rows((const float*)q[6], L.w_o2, W, W, W, W, W, 3, dt, s)); }
     if (w2_mask & OFX_W2_FC2) { L.w_fc22 = A.take<char>(4 * W * MLP); TRY(ofx_launch_pack_rows((const float*)q[12], L.w_fc22, W, W, MLP, MLP, MLP, 3, dt, s)); }
+    if (w2_mask & OFX_W2_QKV) {        // q | k | v blocks of [hi | lo] rows (row stride 2 W), folded and plain
+        char* f2 = A.take<char>(4 * 3 * W * W); L.w_qkv_f2 = f2; L.cs_qkv2 = A.take<float>(3 * W);
+        float* bf_scratch = A.take<float>(3 * W);       // bias + W beta is the same as the single copy's: recomputed into scratch
+        char* p2 = A.take<char>(4 * 3 * W * W); L.w_qkv2 = p2;
+        const int src[3] = {4, 0, 2}, bsrc[3] = {5, 1, 3};
+        for (int i = 0; i < 3; ++i) {
+            TRY(ofx_launch_fold_pack((const float*)q[src[i]], (const float*)q[8], (const float*)q[9], (const float*)q[bsrc[i]], f2 + (size_t)i * 4 * W * W,
+                                     L.cs_qkv2 + i * W, bf_scratch + i * W, Wi, Wi, dt, s, 1));
+            TRY(ofx_launch_pack_rows((const float*)q[src[i]], p2 + (size_t)i * 4 * W * W, W, W, W, W, W, 3, dt, s));
+        }
+    }
+    if (w2_mask & OFX_W2_FC1) {
+        L.w_fc1_f2 = A.take<char>(4 * MLP * W); L.cs_fc12 = A.take<float>(MLP);
+        float* bf_scratch = A.take<float>(MLP);
+        TRY(ofx_launch_fold_pack((const float*)q[10], (const float*)q[14], (const float*)q[15], (const float*)q[11], L.w_fc1_f2, L.cs_fc12, bf_scratch, (int)MLP, Wi, dt, s, 1));
+        L.w_fc12 = A.take<char>(4 * MLP * W); TRY(ofx_launch_pack_rows((const float*)q[10], L.w_fc12, MLP, MLP, W, W, W, 3, dt, s));
+    }
     return OFX_OK;
 }
 static size_t clip_layer_bytes(size_t W, size_t MLP, int w2_mask = 0, bool x3 = false) {
     if (x3) return 6 * (4 * W * W + 2 * W * MLP) + 4 * (9 * W + MLP) + 32 * 256;
     return 2 * (4 * W * W + 2 * W * MLP) + 4 * (9 * W + MLP) + 2 * (3 * W * W + W * MLP) + 4 * (6 * W + 2 * MLP) +
-           ((w2_mask & OFX_W2_OUT) ? 4 * W * W : 0) + ((w2_mask & OFX_W2_FC2) ? 4 * W * MLP : 0) + 34 * 256;
+           ((w2_mask & OFX_W2_OUT) ? 4 * W * W : 0) + ((w2_mask & OFX_W2_FC2) ? 4 * W * MLP : 0) +
+           ((w2_mask & OFX_W2_QKV) ? 24 * W * W + 24 * W : 0) + ((w2_mask & OFX_W2_FC1) ? 8 * W * MLP + 8 * MLP : 0) + 44 * 256;
 }
 
 extern "C" int ofx_pack_vision_weights(ofx_handle* h, const void* const* P, int n, ofx_stream stream) {
@@ -619,7 +640,8 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
                       float eps, int causal, const int64_t* key_mask, int mask_ld, int dt, const int* pool_idx, hipStream_t s, bool fold = false,
                       bool pool_first = false) {
     // fused QKV projection + attention (non-pooled ViT layers: one 33..64-token tile per sequence, no mask): q | k | v never reach HBM
-    const bool fused = g_fuse_qkv && !pool_idx && !causal && !key_mask && S >= 33 && S <= 64;
+    const bool qkv_w2 = L.w_qkv_f2 != nullptr;     // split q | k | v weights: the dual-weight GEMM + the attention kernel (the fused kernel is single-product)
+    const bool fused = g_fuse_qkv && !qkv_w2 && !pool_idx && !causal && !key_mask && S >= 33 && S <= 64;
     if (fused) {
         if (fold) {
             TRY(ofx_launch_fused_qkv_attn(w.XB, L.w_qkv_f, L.bf_qkv, w.S, L.cs_qkv, w.H, nseq, S, W, heads, W, W, 0.125f, dt, s));
@@ -631,13 +653,16 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
     }
     GemmArgs g1{}; g1.C = w.QKV; g1.M = rows; g1.N = 3 * W; g1.K = W; g1.lda = W;
     g1.ldc = 3 * W; g1.act = OFX_ACT_NONE; g1.out_kind = OFX_OUT_OP;
+    size_t wrow = (size_t)W * 2;                   // bytes per weight row of g1.W
     if (fused) {
     } else if (fold) {
         g1.A = w.XB; g1.W = L.w_qkv_f; g1.bias = L.bf_qkv; g1.row_stat = w.S; g1.col_sum = L.cs_qkv;
+        if (qkv_w2) { g1.W = L.w_qkv_f2; g1.col_sum = L.cs_qkv2; g1.K = 2 * W; g1.a_wrap = W; wrow *= 2; }
     } else {
         LnArgs ln{w.X, nullptr, L.g1, L.be1, w.H, rows, W, W, OFX_OUT_OP, eps};
         TRY(ofx_launch_layernorm(ln, dt, s));
         g1.A = w.H; g1.W = L.w_qkv; g1.bias = L.b_qkv;
+        if (qkv_w2) { g1.W = L.w_qkv2; g1.K = 2 * W; g1.a_wrap = W; wrow *= 2; }
     }
     if (fused) {
     } else if (pool_idx && pool_first && g_prune_q) {
@@ -645,7 +670,7 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
         // rows (weight rows W .. 3W), then Q for the nseq pooled rows through strided A / C / statistics.  The other rows' Q
         // columns keep stale workspace bytes; their attention outputs are never read (the tail gathers the pooled rows only).
         GemmArgs kv = g1;
-        kv.W = (const char*)g1.W + (size_t)W * W * 2; kv.bias = g1.bias + W; kv.C = (char*)w.QKV + (size_t)W * 2; kv.N = 2 * W;
+        kv.W = (const char*)g1.W + (size_t)W * wrow; kv.bias = g1.bias + W; kv.C = (char*)w.QKV + (size_t)W * 2; kv.N = 2 * W;
         if (fold) kv.col_sum = g1.col_sum + W;
         TRY(ofx_launch_gemm(kv, dt, s));
         GemmArgs q = g1;
@@ -678,10 +703,12 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
     if (fold2) {
         TRY(ofx_launch_stats_finalize(w.P, W / 64, W, eps, w.S, M, s));
         g3.A = w.XB; g3.W = L.w_fc1_f; g3.bias = L.bf_fc1; g3.row_stat = w.S; g3.col_sum = L.cs_fc1;
+        if (L.w_fc1_f2) { g3.W = L.w_fc1_f2; g3.col_sum = L.cs_fc12; g3.K = 2 * W; g3.a_wrap = W; }
     } else {
         LnArgs ln2{X, nullptr, L.g2, L.be2, H, M, W, W, OFX_OUT_OP, eps};
         TRY(ofx_launch_layernorm(ln2, dt, s));
         g3.A = H; g3.W = L.w_fc1; g3.bias = L.b_fc1;
+        if (L.w_fc12) { g3.W = L.w_fc12; g3.K = 2 * W; g3.a_wrap = W; }
     }
     if (pool_idx) { g3.slab = w.slab; g3.slab_bytes = w.slab_bytes; }
     TRY(ofx_launch_gemm(g3, dt, s));

@@ -422,17 +422,25 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* part, 
     stat[2 * (size_t)r + 1] = rsqrtf(var + eps);
 }
 // Pack time: W'[n,:] = round(W[n,:] * gamma), col_sum[n] = sum_k W'[n,k] (of the ROUNDED values), bias'[n] = bias[n] + sum_k beta[k] W[n,k].
+// split != 0: row n of Wf is [hi(K) | lo(K)] (hi = round(W gamma), lo = round(W gamma - hi): GemmArgs::a_wrap) and col_sum sums hi + lo.
 template <typename T>
 __global__ __launch_bounds__(256) void fold_pack_kernel(const float* Wsrc, const float* gamma, const float* beta, const float* bias, T* Wf,
-                                                       float* col_sum, float* bias_f, int N, int K) {
+                                                       float* col_sum, float* bias_f, int N, int K, int split) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int ld = split ? 2 * K : K;
     for (int n = blockIdx.x * 4 + w; n < N; n += gridDim.x * 4) {
         float cs = 0.f, bb = 0.f;
         for (int k = lane; k < K; k += 64) {
             const float wv = Wsrc[(size_t)n * K + k];
-            const T r = (T)(wv * gamma[k]);
-            Wf[(size_t)n * K + k] = r;
+            const float wg = wv * gamma[k];
+            const T r = (T)wg;
+            Wf[(size_t)n * ld + k] = r;
             cs += (float)r;
+            if (split) {
+                const T lo = (T)(wg - (float)r);
+                Wf[(size_t)n * ld + K + k] = lo;
+                cs += (float)lo;
+            }
             bb += beta[k] * wv;
         }
         cs = wave_sum(cs); bb = wave_sum(bb);
@@ -556,9 +564,9 @@ int ofx_launch_stats_finalize(const float* part, int slots, int W, float eps, fl
     return OFX_OK;
 }
 int ofx_launch_fold_pack(const float* Wsrc, const float* gamma, const float* beta, const float* bias, void* Wf, float* col_sum, float* bias_f,
-                         int N, int K, int op_dtype, hipStream_t s) {
-    if (op_dtype == OFX_F16) hipLaunchKernelGGL(fold_pack_kernel<f16_t>, dim3(rows_grid(N)), dim3(256), 0, s, Wsrc, gamma, beta, bias, (f16_t*)Wf, col_sum, bias_f, N, K);
-    else hipLaunchKernelGGL(fold_pack_kernel<bf16_t>, dim3(rows_grid(N)), dim3(256), 0, s, Wsrc, gamma, beta, bias, (bf16_t*)Wf, col_sum, bias_f, N, K);
+                         int N, int K, int op_dtype, hipStream_t s, int split) {
+    if (op_dtype == OFX_F16) hipLaunchKernelGGL(fold_pack_kernel<f16_t>, dim3(rows_grid(N)), dim3(256), 0, s, Wsrc, gamma, beta, bias, (f16_t*)Wf, col_sum, bias_f, N, K, split);
+    else hipLaunchKernelGGL(fold_pack_kernel<bf16_t>, dim3(rows_grid(N)), dim3(256), 0, s, Wsrc, gamma, beta, bias, (bf16_t*)Wf, col_sum, bias_f, N, K, split);
     OFX_LAUNCH_CHECK();
     return OFX_OK;
 }

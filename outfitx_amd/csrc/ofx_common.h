@@ -287,7 +287,7 @@ int ofx_launch_row_stats_cast(const float* X, void* Xb, float* stat, int rows, i
 int ofx_launch_gather_hilo(const void* hi, const void* lo, const int* idx, float* dst, int rows, int W, int op_dtype, hipStream_t s);
 int ofx_launch_stats_finalize(const float* part, int slots, int W, float eps, float* stat, int rows, hipStream_t s);
 int ofx_launch_fold_pack(const float* Wsrc, const float* gamma, const float* beta, const float* bias, void* Wf, float* col_sum, float* bias_f,
-                         int N, int K, int op_dtype, hipStream_t s);
+                         int N, int K, int op_dtype, hipStream_t s, int split = 0);
 int ofx_launch_gather_row0(const float* X, const int* cu, float* out, int B, int D, hipStream_t s);
 int ofx_launch_cir_prefix(const float* img_emb, const float* txt, float* out, int B, int D, hipStream_t s);
 int ofx_launch_cp_head(const float* row0, const float* w, const float* bias, float* logits, int B, int D, hipStream_t s);
