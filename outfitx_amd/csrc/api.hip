@@ -680,6 +680,7 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
         TRY(ofx_launch_gemm(g1, dt, s));
     if (!fused) {
         AttnArgs at{w.QKV, w.H, key_mask, nseq, S, heads, 3 * W, W, W, 2 * W, mask_ld, causal, 0.125f};
+        at.only_row0 = (pool_idx && pool_first && g_prune_q) ? 1 : 0;       // pruned last layer of the ViT: only the CLS query row is read afterwards
         TRY(ofx_launch_attention_mfma(at, dt, s));
     }
     float* X = w.X; char* H = w.H; char* U = w.U; int M = rows;

@@ -84,12 +84,15 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(AttnK a) {      
             neg[t][r] = dead ? -INFINITY : 0.f;
         }
 
+    // only_row0: query row 0 alone is wanted (pruned last layers: the CLS row / the set's prefix row) -> only query tile 0 is computed
+    const int nu = a.only_row0 ? 1 : NT;
     // ---- S^T[key][query]: st[t][u][r] = score(query 16u + r16, key 16t + 4q4 + r)
     f32x4 st[NT][NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
+            if (u >= nu) continue;
             f32x4 c = {neg[t][0], neg[t][1], neg[t][2], neg[t][3]};      // the mask rides in as the accumulator: -inf + finite = -inf
             c = OpT<T>::mfma16(kf[t][0], qf[u][0], c);
             st[t][u] = OpT<T>::mfma16(kf[t][1], qf[u][1], c);
@@ -110,6 +113,7 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(AttnK a) {      
     v8 pf[NT][KS];
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
+        if (u >= nu) continue;
         const int query = 16 * u + r16;
         float m = -INFINITY;
 #pragma unroll
@@ -165,6 +169,7 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(AttnK a) {      
             }
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
+            if (u >= nu) continue;
             f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) c = OpT<T>::mfma16(vf[ks], pf[u][ks], c);
@@ -176,6 +181,7 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(AttnK a) {      
     if (live) {
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
+            if (u >= nu) continue;
             const int query = 16 * u + r16;
             if (query < (a.only_row0 ? 1 : S)) {
                 T* op = (T*)a.out + (size_t)(row_first + query) * a.ldo + head * 64 + 16 * q4;
