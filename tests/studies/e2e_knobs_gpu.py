@@ -14,7 +14,7 @@ lib = L.load()
 seeds = [int(a) for a in sys.argv[1:]] or [4, 6]
 B, n = 8, 8
 mean = torch.tensor(synth.CLIP_MEAN).view(1, 1, 3, 1, 1); std = torch.tensor(synth.CLIP_STD).view(1, 1, 3, 1, 1)
-variants = [("default", "f16w2", {}), ("fold=1", "f16w2", {6: 1}), ("fold=0", "f16w2", {6: 0}), ("fuse=0", "f16w2", {9: 0}), ("fold=0,fuse=0", "f16w2", {6: 0, 9: 0}),
+variants = [("default", "f16w2", {}), ("fold=1", "f16w2", {6: 1}), ("fold=0", "f16w2", {6: 0}), ("fuse=0", "f16w2", {9: 0}), ("fold=0,fuse=0", "f16w2", {6: 0, 9: 0}), ("prune_q=0", "f16w2", {8: 0}), ("splitk=0", "f16w2", {5: 0}),
             ("f16 single", "f16", {}), ("f16x3 (all tower GEMMs three-product)", "f16x3", {})]
 for ws in seeds:
     g = torch.Generator(); g.manual_seed(9000 + ws)
@@ -38,7 +38,7 @@ for ws in seeds:
             with torch.no_grad():
                 got = m(task=CP, outfit_embedding=None, outfit_mask=torch.from_numpy(mask).cuda(), encoder_input_dict={"images": px.cuda(), "texts": texts}).cpu().numpy()
         finally:
-            lib.ofx_tune(6, 2); lib.ofx_tune(9, 1)
+            lib.ofx_tune(6, 2); lib.ofx_tune(9, 1); lib.ofx_tune(8, 1); lib.ofx_tune(5, 1)
         row[name] = float(np.abs(got - ref).max() / np.abs(ref).max())
         del m; torch.cuda.empty_cache()
     print(json.dumps({"weight_seed": ws, **{k: float(f"{v:.3g}") for k, v in row.items()}}), flush=True)
