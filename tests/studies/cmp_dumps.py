@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Compare two dump_e2e.py outputs (and both against the fp32 oracle): python tools/cmp_dumps.py a.npz b.npz seed"""
+"""Compare two dump_e2e.py outputs (and both against the fp32 oracle): python tests/studies/cmp_dumps.py a.npz b.npz seed"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from outfitx_amd import synth
 from oracle import np_oracle as O

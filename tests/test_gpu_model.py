@@ -627,8 +627,8 @@ def _cfg2_end_to_end(wseed, towers, bound):
 
 @pytest.mark.parametrize("wseed", [1, 2, 3, 4, 5, 6, 14, 20, -3])
 def test_cfg2_end_to_end_within_1e3_on_every_weight_seed(wseed):
-    """Seeds 1-6 plus the two worst of the forty the CPU emulation scanned (14: 9.7e-4 on the GPU - the scheme's measured edge,
-    DESIGN.md section 2 - and 20: 6.1e-4) and seed 3 with massive residual-stream channels."""
+    """Seeds 1-6 plus two of the worst of the forty measured on the GPU (profiles/r02_seed_sweep_gpu.json: 14 reads 9.7e-4 - the
+    scheme's measured edge) and seed 3 with massive residual-stream channels."""
     _cfg2_end_to_end(wseed, None, 1e-3)
 
 
