@@ -241,7 +241,9 @@ int ofx_profile_records(ofx_prof_record* out, int cap);
  * knob 6: 2 (default) folds the CLIP towers' LayerNorms into the neighbouring GEMM epilogues AND keeps their residual stream as an
  * operand-type (hi, lo) pair updated in place (no fp32 stream between the layers), 1 folds with an fp32 stream, 0 materialises them;
  * knob 8: 1 (default) the ViT's last layer computes queries for the CLS rows only, 0 runs the full QKV GEMM;
- * knob 9: 1 (default) the ViT's layers run the fused QKV-projection + attention kernel, 0 the GEMM -> HBM -> attention-kernel pair. */
+ * knob 9: 1 (default) the ViT's layers run the fused QKV-projection + attention kernel, 0 the GEMM -> HBM -> attention-kernel pair;
+ * knob 10: 1 (default) small-batch outfit-transformer GEMMs (split-K plans) leave their second pass to the consumer kernel (set
+ *          attention sums the q | k | v slabs; reduce + LayerNorm in one launch), 0 the separate reduce and LayerNorm launches. */
 int ofx_tune(int knob, int value);
 /* Diagnostics: when buf != NULL the big-tile GEMM writes {shader cycles, 100 MHz ticks} of its main loop per block (16 B each). */
 void ofx_debug_gemm_clock(void* buf);

@@ -511,6 +511,7 @@ extern "C" size_t ofx_workspace_bytes(ofx_handle* h, int op, int n, int len) {
 
 // --------------------------------------------------------------------------- outfit transformer
 // The set input in either form: a padded [B, L, D] tensor + mask, or (indexed / varlen) item rows of a device-resident table.
+int g_set_fuse = 3;          // ofx_tune(10, v): bit 0 / bit 1 = small-batch outfit transformer lets the consumers do the split-K second passes (attention sums q | k | v slabs, reduce + LayerNorm in one launch)
 int g_train_mfma_attn = 1;   // ofx_tune(7, v): single-product precisions (training; scoring in bf16 / f16) use the MFMA varlen attention (1) or the fp32 set kernels (0)
 
 struct SetInput {
@@ -555,11 +556,18 @@ static int set_encoder_core(ofx_handle* h, const SetInput& in, const float* pref
     if (!prefix) { prefix = h->outfit_token; prefix_stride = 0; }
     TRY(build_set(h, in, prefix, prefix_stride, w.cu, w.X, B, L, s));
     const int* m_dev = w.cu + B;
+    // Small batches (split-K plans): the GEMMs' second passes ride on their consumers - the set attention sums the q | k | v slabs,
+    // the out-proj / linear2 reduce also emits the LayerNorm that follows it - 8 launches per layer instead of 11 (g_set_fuse)
+    const bool fuse_att = (g_set_fuse & 1) != 0, fuse = (g_set_fuse & 2) != 0;
+    bool ln1_done = false;                              // layer l's norm1 output already written by layer l-1's linear2 reduce
     for (int l = 0; l < d.n_layers; ++l) {
         const OutfitLayer& Ly = h->ol[l];
         const bool last = l + 1 == d.n_layers;          // only row 0 of every outfit feeds the heads (outfit_x.py:142,170)
-        LnArgs ln{w.X, nullptr, Ly.g1, Ly.be1, w.H, M, D, km * D, okind, d.ln_eps};
-        TRY(ofx_launch_layernorm_dev(ln, m_dev, dt, s));
+        if (!ln1_done) {
+            LnArgs ln{w.X, nullptr, Ly.g1, Ly.be1, w.H, M, D, km * D, okind, d.ln_eps};
+            TRY(ofx_launch_layernorm_dev(ln, m_dev, dt, s));
+        }
+        ln1_done = false;
         GemmArgs g1{}; g1.A = w.H; g1.W = Ly.w_in; g1.C = w.QKV; g1.bias = Ly.b_in; g1.resid = nullptr; g1.m_dev = m_dev;
         g1.M = M; g1.N = 3 * D; g1.K = km * D; g1.k_mult = km; g1.lda = km * D; g1.ldc = 3 * D; g1.ldr = 0; g1.act = OFX_ACT_NONE;
         // single-product precisions: q|k|v stay in the operand type and the varlen MFMA attention runs (as in the training forward);
@@ -567,6 +575,8 @@ static int set_encoder_core(ofx_handle* h, const SetInput& in, const float* pref
         const bool mfma_attn = km == 1 && g_train_mfma_attn;
         g1.out_kind = mfma_attn ? OFX_OUT_OP : OFX_OUT_F32;
         g1.slab = w.slab; g1.slab_bytes = w.slab_bytes;
+        int qkv_splits = 1;
+        if (fuse_att && !mfma_attn) g1.defer_splits = &qkv_splits;
         TRY(ofx_launch_gemm(g1, dt, s));
         if (mfma_attn) {
             AttnArgs at{w.QKV, w.H, nullptr, B, L + 1, d.n_head, 3 * D, D, D, 2 * D, 0, 0, 0.125f};
@@ -574,6 +584,7 @@ static int set_encoder_core(ofx_handle* h, const SetInput& in, const float* pref
             TRY(ofx_launch_attention_mfma(at, dt, s));
         } else {
             SetAttnArgs sa{w.QKV, w.H, w.cu, B, d.n_head, D, km * D, okind, L + 1, last ? 1 : 0, 0.125f};
+            if (qkv_splits > 1) { sa.qkv = w.slab; sa.splits = qkv_splits; sa.plane = (size_t)M * 3 * D; sa.bias = Ly.b_in; }
             TRY(ofx_launch_set_attention(sa, dt, s));
         }
         float* X = w.X; char* H = w.H; char* U = w.U; int Ml = M; const int* md = m_dev;
@@ -585,9 +596,13 @@ static int set_encoder_core(ofx_handle* h, const SetInput& in, const float* pref
         GemmArgs g2{}; g2.A = H; g2.W = Ly.w_out; g2.C = X; g2.bias = Ly.b_out; g2.resid = X; g2.m_dev = md;
         g2.M = Ml; g2.N = D; g2.K = km * D; g2.k_mult = km; g2.lda = km * D; g2.ldc = D; g2.ldr = D; g2.act = OFX_ACT_NONE; g2.out_kind = OFX_OUT_F32;
         g2.slab = w.slab; g2.slab_bytes = w.slab_bytes;
+        bool ln2_done = false;
+        if (fuse) { g2.ln_gamma = Ly.g2; g2.ln_beta = Ly.be2; g2.ln_out = H; g2.ln_ld = km * D; g2.ln_kind = okind; g2.ln_eps = d.ln_eps; g2.ln_done = &ln2_done; }
         TRY(ofx_launch_gemm(g2, dt, s));
-        LnArgs ln2{X, nullptr, Ly.g2, Ly.be2, H, Ml, D, km * D, okind, d.ln_eps};
-        TRY(ofx_launch_layernorm_dev(ln2, md, dt, s));
+        if (!ln2_done) {
+            LnArgs ln2{X, nullptr, Ly.g2, Ly.be2, H, Ml, D, km * D, okind, d.ln_eps};
+            TRY(ofx_launch_layernorm_dev(ln2, md, dt, s));
+        }
         GemmArgs g3{}; g3.A = H; g3.W = Ly.w_1; g3.C = U; g3.bias = Ly.b_1; g3.resid = nullptr; g3.m_dev = md;
         g3.M = Ml; g3.N = Fp; g3.K = km * D; g3.k_mult = km; g3.lda = km * D; g3.ldc = km * Fp; g3.ldr = 0; g3.act = d.outfit_act; g3.out_kind = okind;
         g3.slab = w.slab; g3.slab_bytes = w.slab_bytes;
@@ -595,6 +610,10 @@ static int set_encoder_core(ofx_handle* h, const SetInput& in, const float* pref
         GemmArgs g4{}; g4.A = U; g4.W = Ly.w_2; g4.C = X; g4.bias = Ly.b_2; g4.resid = X; g4.m_dev = md;
         g4.M = Ml; g4.N = D; g4.K = km * Fp; g4.k_mult = km; g4.lda = km * Fp; g4.ldc = D; g4.ldr = D; g4.act = OFX_ACT_NONE; g4.out_kind = OFX_OUT_F32;
         g4.slab = w.slab; g4.slab_bytes = w.slab_bytes;
+        if (fuse && !last) {                            // ... and the next layer's norm1
+            const OutfitLayer& Nx = h->ol[l + 1];
+            g4.ln_gamma = Nx.g1; g4.ln_beta = Nx.be1; g4.ln_out = w.H; g4.ln_ld = km * D; g4.ln_kind = okind; g4.ln_eps = d.ln_eps; g4.ln_done = &ln1_done;
+        }
         TRY(ofx_launch_gemm(g4, dt, s));
     }
     return OFX_OK;
@@ -1286,6 +1305,7 @@ extern "C" int ofx_tune(int knob, int value) {
         case 7: g_train_mfma_attn = value; return OFX_OK;
         case 8: g_prune_q = value; return OFX_OK;
         case 9: g_fuse_qkv = value; return OFX_OK;
+        case 10: g_set_fuse = value; return OFX_OK;
         default: ofx_set_error("ofx_tune: unknown knob %d", knob); return OFX_EINVAL;
     }
 }

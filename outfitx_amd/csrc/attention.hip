@@ -216,6 +216,8 @@ struct SetK {
     // causal AND key-padding mask (key_mask [nseq, mask_ld] int64, 0 = ignored)
     int fixed_S, causal, mask_ld;
     const int64_t* key_mask;
+    // fp32 q | k | v still in split-K slabs: element = sum_s qkv[s * plane + ...] + bias[col] (the GEMM's second pass, done here)
+    int splits; size_t plane; const float* bias;
 };
 
 template <typename T, int SMAX, typename TI = float>      // TI: element type of qkv (float: scoring path; T: training tape)
@@ -232,14 +234,43 @@ __global__ __launch_bounds__(64) void set_attention_kernel(SetK a) {
     const int nq = a.only_row0 ? 1 : S;
     const int D = a.D;
     float vreg[SMAX];
+    if (a.splits > 1) {
+        // q | k | v still in the QKV GEMM's split-K slabs: sum them here in the reduce kernel's order (slab 0 + 1 + ... + bias), 16 lanes x
+        // float4 per 64-column row slice, four rows per pass; v goes through LDS to reach its lane = column layout
+        constexpr int VS = SMAX <= 32 ? SMAX : 1;        // the launcher keeps the slab path to sets of <= 32 rows
+        __shared__ __attribute__((aligned(16))) float vs[VS * STR];
+        const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+        const float* bp = a.bias + h * 64 + c4;
+        const f32x4 bq = *(const f32x4*)bp, bk = *(const f32x4*)(bp + D), bv = *(const f32x4*)(bp + 2 * D);
+        for (int j0 = 0; j0 < S; j0 += 4) {
+            const int j = j0 + rsub;
+            if (j < S) {
+                const float* rp = (const float*)a.qkv + (size_t)(r0 + j) * 3 * D + h * 64 + c4;
+                f32x4 q = {0.f, 0.f, 0.f, 0.f}, kk = *(const f32x4*)(rp + D), vv = *(const f32x4*)(rp + 2 * D);
+                if (j < nq) q = *(const f32x4*)rp;
+                for (int sl = 1; sl < a.splits; ++sl) {
+                    const float* sp = rp + sl * a.plane;
+                    if (j < nq) q += *(const f32x4*)sp;
+                    kk += *(const f32x4*)(sp + D); vv += *(const f32x4*)(sp + 2 * D);
+                }
+                if (j < nq) *(f32x4*)(qs + j * STR + c4) = q + bq;
+                *(f32x4*)(ks + j * STR + c4) = kk + bk;
+                *(f32x4*)(vs + (j % VS) * STR + c4) = vv + bv;
+            }
+        }
+        __syncthreads();
 #pragma unroll
-    for (int j = 0; j < SMAX; ++j) {
-        vreg[j] = 0.f;
-        if (j < S) {
-            const TI* rp = (const TI*)a.qkv + (size_t)(r0 + j) * 3 * D + h * 64 + lane;
-            if (j < nq) qs[j * STR + lane] = (float)rp[0];
-            ks[j * STR + lane] = (float)rp[D];
-            vreg[j] = (float)rp[2 * D];
+        for (int j = 0; j < SMAX; ++j) vreg[j] = j < S ? vs[(j % VS) * STR + lane] : 0.f;
+    } else {
+#pragma unroll
+        for (int j = 0; j < SMAX; ++j) {
+            vreg[j] = 0.f;
+            if (j < S) {
+                const TI* rp = (const TI*)a.qkv + (size_t)(r0 + j) * 3 * D + h * 64 + lane;
+                if (j < nq) qs[j * STR + lane] = (float)rp[0];
+                ks[j * STR + lane] = (float)rp[D];
+                vreg[j] = (float)rp[2 * D];
+            }
         }
     }
     __syncthreads();
@@ -543,6 +574,8 @@ int ofx_launch_set_attention(const SetAttnArgs& g, int op_dtype, hipStream_t s) 
     k.qkv = g.qkv; k.out = (char*)g.out; k.cu = g.cu_seqlens; k.nseq = g.nseq; k.n_head = g.n_head; k.D = g.D; k.ldo = g.ldo;
     k.out_kind = g.out_kind; k.only_row0 = g.only_row0; k.scale = g.scale; k.drop = g.drop;
     k.fixed_S = g.fixed_len; k.causal = g.causal; k.mask_ld = g.mask_ld; k.key_mask = g.key_mask;
+    OFX_REQUIRE(g.splits <= 1 || (!g.qkv_op && g.bias && g.plane > 0 && g.max_len <= 32), OFX_EINVAL, "set_attention: slab input needs fp32 q|k|v, the bias, the slab stride and sets of <= 32 rows");
+    k.splits = g.splits > 1 ? g.splits : 1; k.plane = g.plane; k.bias = g.bias;
     const int grid = g.nseq * g.n_head;
     ProfScope prof(PROF_ATTN, s);
 #define SA(T, N) do { if (g.qkv_op) hipLaunchKernelGGL((set_attention_kernel<T, N, T>), dim3(grid), dim3(64), 0, s, k); \

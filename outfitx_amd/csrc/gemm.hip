@@ -225,6 +225,8 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
 #ifndef OFX_DIAG
     OFX_REQUIRE(g_gemm_ablate == 0, OFX_ESTATE, "gemm: the ablation kernels are only built with `make DIAG=1`");
 #endif
+    if (g.defer_splits) *g.defer_splits = 1;
+    if (g.ln_done) *g.ln_done = false;
     KArgs k;
     k.A = (const char*)g.A; k.W = (const char*)g.W; k.C = (char*)g.C; k.bias = g.bias; k.resid = g.resid; k.aux_out = g.aux_out; k.m_dev = g.m_dev; k.dbg = g_gemm_dbg; k.skew = g_gemm_skew; k.splits = 1; k.slab = nullptr; k.m_slab = g.M; k.kt_per_split = 0;
     k.ka_tiles = ka / BK;
@@ -289,23 +291,34 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
         k.splits = splits; k.slab = (float*)g.slab; k.m_slab = g.M;
         k.kt_per_split = splits > 1 ? (g.K / BK + splits - 1) / splits : 0;
         if (splits > 1) OFX_REQUIRE(g.slab_bytes >= (size_t)splits * g.M * g.N * 4, OFX_EWORKSPACE, "gemm: split-K slab too small");
+        // second pass of a split-K plan: left to the consumer (defer_splits), fused with the following LayerNorm (ln_gamma), or the plain reduce
+        auto second_pass = [&]() -> int {
+            if (g.defer_splits) { *g.defer_splits = splits; return OFX_OK; }
+            if (g.ln_gamma && g.out_kind == 0 && g.act == OFX_ACT_NONE && !g.aux_out && !g.drop.thresh && (g.N == 512 || g.N == 768 || g.N == 1024)) {
+                SplitKLnArgs a{(const float*)g.slab, (size_t)g.M * g.N, splits, g.bias, g.resid, g.ldr, (float*)g.C, g.ldc,
+                               g.ln_gamma, g.ln_beta, g.ln_out, g.ln_ld, g.ln_kind, g.ln_eps, g.M, g.N, g.m_dev};
+                TRY(ofx_launch_splitk_reduce_ln(a, op_dtype, s, true));
+                if (g.ln_done) *g.ln_done = true;
+                return OFX_OK;
+            }
+            size_t tot = (size_t)g.M * (g.N / 4);
+            int rg = (int)((tot + 255) / 256); if (rg > 2048) rg = 2048;
+            if (op_dtype == OFX_F16) OFX_PLAUNCH(true, splitk_reduce_kernel<f16_t>, dim3(rg), dim3(256), 0, s, k);
+            else OFX_PLAUNCH(true, splitk_reduce_kernel<bf16_t>, dim3(rg), dim3(256), 0, s, k);
+            return OFX_OK;
+        };
         if (pl.tile64) {        // 64-row tiles, three blocks per CU: grids that would leave CUs idle with 128-row tiles (with or without split-K)
             k.tiles_m = (g.M + 63) / 64; k.nwg = k.tiles_m * k.tiles_n; k.group_m = 2 * gm;
             const dim3 grid64(k.nwg, splits);
-            const bool one64 = splits <= 1;
+            const bool one64 = splits <= 1 || g.defer_splits;      // the launch that carries the profile record's stop event
             if (op_dtype == OFX_F16) OFX_PLAUNCH(one64, (gemm_128x128_kernel<f16_t, 0, 2>), grid64, dim3(256), GEMM64_LDS_BYTES, s, k);
             else OFX_PLAUNCH(one64, (gemm_128x128_kernel<bf16_t, 0, 2>), grid64, dim3(256), GEMM64_LDS_BYTES, s, k);
-            if (splits > 1) {
-                size_t tot = (size_t)g.M * (g.N / 4);
-                int rg = (int)((tot + 255) / 256); if (rg > 2048) rg = 2048;
-                if (op_dtype == OFX_F16) OFX_PLAUNCH(true, splitk_reduce_kernel<f16_t>, dim3(rg), dim3(256), 0, s, k);
-                else OFX_PLAUNCH(true, splitk_reduce_kernel<bf16_t>, dim3(rg), dim3(256), 0, s, k);
-            }
+            if (splits > 1) TRY(second_pass());
             OFX_LAUNCH_CHECK();
             return OFX_OK;
         }
         const dim3 grid(k.nwg, splits > 1 ? splits : 1);
-        const bool one = splits <= 1;
+        const bool one = splits <= 1 || g.defer_splits;
         if (op_dtype == OFX_F16) OFX_PLAUNCH(one, (gemm_128x128_kernel<f16_t, 0>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
 #ifdef OFX_DIAG
         else if (g_gemm_ablate == 1) OFX_PLAUNCH(one, (gemm_128x128_kernel<bf16_t, 1>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
@@ -313,12 +326,7 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
         else if (g_gemm_ablate == 3) OFX_PLAUNCH(one, (gemm_128x128_kernel<bf16_t, 3>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
 #endif
         else OFX_PLAUNCH(one, (gemm_128x128_kernel<bf16_t, 0>), grid, dim3(256), GEMM_LDS_BYTES, s, k);
-        if (splits > 1) {
-            size_t tot = (size_t)g.M * (g.N / 4);
-            int rg = (int)((tot + 255) / 256); if (rg > 2048) rg = 2048;
-            if (op_dtype == OFX_F16) OFX_PLAUNCH(true, splitk_reduce_kernel<f16_t>, dim3(rg), dim3(256), 0, s, k);
-            else OFX_PLAUNCH(true, splitk_reduce_kernel<bf16_t>, dim3(rg), dim3(256), 0, s, k);
-        }
+        if (splits > 1) TRY(second_pass());
     }
     OFX_LAUNCH_CHECK();
     return OFX_OK;

@@ -84,6 +84,59 @@ int ofx_launch_layernorm_dev(const LnArgs& a, const int* rows_dev, int op_dtype,
 int ofx_launch_layernorm(const LnArgs& a, int op_dtype, hipStream_t s) { return ofx_launch_layernorm_dev(a, nullptr, op_dtype, s); }
 
 // ------------------------------------------------------------------------------------------------
+// Split-K second pass fused with the LayerNorm that follows it (small batches of the outfit transformer: one launch instead of
+// two): x[r] = sum_s slab[s][r] (fixed order) + bias + resid[r] -> fp32 x (may alias resid), then y[r] = LN(x[r]) (the block-wide sums
+// take another order than layernorm_kernel's single-wave ones: the two paths agree to fp32 rounding, not bit for bit).
+namespace {
+// One block per row, one float4 per thread (D = 4 * blockDim.x): the slab loads of a row are spread over D / 4 lanes, so even
+// 16 slabs are one short load burst; the two LayerNorm reductions go wave_sum -> LDS -> every thread re-adds the per-wave partials
+// in the same order (any wave count gives every thread the same value).
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(SplitKLnArgs a) {
+    __shared__ float part[2][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int rows = a.m_dev ? min(*a.m_dev, a.rows) : a.rows;
+    const int D = a.D, col = threadIdx.x * 4;
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float* sp = a.slab + (size_t)r * D + col;
+        f32x4 t = *(const f32x4*)sp;
+        for (int k = 1; k < a.splits; ++k) t += *(const f32x4*)(sp + k * a.plane);
+        if (a.bias) t += *(const f32x4*)(a.bias + col);
+        if (a.resid) t += *(const f32x4*)(a.resid + (size_t)r * a.ldr + col);
+        *(f32x4*)(a.x + (size_t)r * a.ldx + col) = t;
+        const float s = wave_sum(t[0] + t[1] + t[2] + t[3]);
+        if (lane == 0) part[0][w] = s;
+        __syncthreads();
+        float tot = 0.f;
+        for (int i = 0; i < nw; ++i) tot += part[0][i];
+        const float mu = tot * (1.0f / D);
+        t -= mu;
+        const float q = wave_sum(t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3]);
+        if (lane == 0) part[1][w] = q;
+        __syncthreads();
+        float tq = 0.f;
+        for (int i = 0; i < nw; ++i) tq += part[1][i];
+        const float rstd = rsqrtf(tq * (1.0f / D) + a.eps);
+        const f32x4 g = *(const f32x4*)(a.gamma + col), b = *(const f32x4*)(a.beta + col);
+        store4<T>(a.y, (size_t)r * a.ldy + col, t * rstd * g + b, a.out_kind, D);
+        __syncthreads();                    // part[] is reused by the block's next row
+    }
+}
+}  // namespace
+
+int ofx_launch_splitk_reduce_ln(const SplitKLnArgs& a, int op_dtype, hipStream_t s, bool in_gemm_scope) {
+    OFX_REQUIRE(a.D == 512 || a.D == 768 || a.D == 1024, OFX_ESHAPE, "splitk_reduce_ln: D=%d not in {512,768,1024}", a.D);
+    OFX_REQUIRE(a.rows > 0 && a.splits >= 1 && a.ldx % 4 == 0 && a.ldx >= a.D && (!a.resid || (a.ldr % 4 == 0 && a.ldr >= a.D)), OFX_ESHAPE, "splitk_reduce_ln: bad shape");
+    OFX_REQUIRE(a.ldy % 4 == 0 && a.ldy >= (a.out_kind == 2 ? 3 * a.D : a.D), OFX_ESHAPE, "splitk_reduce_ln: bad ldy=%d", a.ldy);
+    const int grid = a.rows > 8192 ? 8192 : a.rows;
+    ProfScope prof(PROF_NORM, s, 0.0, false, !in_gemm_scope);
+    if (op_dtype == OFX_F16) OFX_PLAUNCH(in_gemm_scope, splitk_reduce_ln_kernel<f16_t>, dim3(grid), dim3(a.D / 4), 0, s, a);
+    else OFX_PLAUNCH(in_gemm_scope, splitk_reduce_ln_kernel<bf16_t>, dim3(grid), dim3(a.D / 4), 0, s, a);
+    OFX_LAUNCH_CHECK();
+    return OFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // fp32 -> operand type (optionally hi|lo|hi or hi|hi|lo split along the row): weight packing and
 // activation casts.  mode 0: plain, 1: [hi|lo|hi] (activations), 2: [hi|hi|lo] (weights).
 // src [rows, K] fp32 with K_src valid columns (zero-padded to K_dst); dst [rows_dst, ld].

@@ -139,7 +139,7 @@ void ofx_prof_ext_end();
 extern hipEvent_t g_ofx_launch_e0, g_ofx_launch_e1;
 struct ProfScope {
     hipStream_t s; bool on, ext;
-    ProfScope(int cat, hipStream_t st, double flops = 0.0, bool ext_ = false) : s(st), on(g_ofx_prof_on && ((g_ofx_prof_mask >> cat) & 1)), ext(ext_) {
+    ProfScope(int cat, hipStream_t st, double flops = 0.0, bool ext_ = false, bool enable = true) : s(st), on(enable && g_ofx_prof_on && ((g_ofx_prof_mask >> cat) & 1)), ext(ext_) {
         if (on && ext) on = ofx_prof_ext_begin(cat, flops);
         else if (on) ofx_prof_begin(cat, s, flops);
     }
@@ -243,6 +243,14 @@ struct GemmArgs {
     // [M, a_wrap] and its k index wraps, so C = A . (hi + lo)^T: ~22 significant weight bits for two MFMA products
     int a_wrap = 0;
     int k_mult = 1;     // informational (profile records): K = k_mult x the logical depth (3: three-product K-concatenation; a_wrap implies 2)
+    // ---- small batches (split-K plans): let the NEXT kernel do the second pass, one launch less per linear layer.
+    // defer_splits: when the plan splits K, the reduce pass is skipped and *defer_splits = number of slabs (fp32 [splits, M, N] at
+    // `slab`, bias / activation / residual NOT applied: the consumer sums them); left at 1 when the output was written normally.
+    int* defer_splits = nullptr;
+    // ln_gamma: when the plan splits K (fp32 output, no activation), the reduce pass also emits LayerNorm(C) * gamma + beta to
+    // ln_out (ln_kind: 1 operand type | 2 split3, row stride ln_ld) and sets *ln_done; otherwise the caller runs its LayerNorm.
+    const float* ln_gamma = nullptr; const float* ln_beta = nullptr; void* ln_out = nullptr; int ln_ld = 0, ln_kind = 0; float ln_eps = 0.f;
+    bool* ln_done = nullptr;
 };
 int ofx_launch_gemm(const GemmArgs& g, int op_dtype /*OFX_BF16|OFX_F16*/, hipStream_t s);
 int ofx_gemm_splitk_plan(int M, int N, int K);
@@ -264,6 +272,14 @@ size_t ofx_gemm_tn_slab_bytes(int M, int N, int K);
 int ofx_launch_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K, const int* k_dev,
                        void* slab, size_t slab_bytes, int op_dtype, hipStream_t s, int m_valid = 0, int n_valid = 0, int accumulate = 0);
 int ofx_launch_layernorm(const LnArgs& a, int op_dtype, hipStream_t s);
+struct SplitKLnArgs {       // split-K second pass + LayerNorm in one launch (norm_act.hip)
+    const float* slab; size_t plane; int splits;       // fp32 [splits][rows, D]
+    const float* bias; const float* resid; int ldr;    // optional [D]; optional fp32 [rows, ldr] (may alias x)
+    float* x; int ldx;                                 // fp32 [rows, ldx]: the reduced rows
+    const float* gamma; const float* beta; void* y; int ldy, out_kind; float eps;
+    int rows, D; const int* m_dev;
+};
+int ofx_launch_splitk_reduce_ln(const SplitKLnArgs& a, int op_dtype, hipStream_t s, bool in_gemm_scope = false);   // in_gemm_scope: the launch closes the GEMM dispatcher's profile record
 int ofx_launch_layernorm_dev(const LnArgs& a, const int* rows_dev, int op_dtype, hipStream_t s);
 int ofx_launch_pack_rows(const float* src, void* dst, int rows_src, int rows_dst, int K_src, int K_dst, int ld_src,
                          int mode, int op_dtype, hipStream_t s);
@@ -320,5 +336,7 @@ struct SetAttnArgs {
     // fixed-length mode (cu_seqlens == nullptr): every sequence has fixed_len <= 32 rows; optional causal AND key-padding mask
     int fixed_len = 0, causal = 0, mask_ld = 0;
     const int64_t* key_mask = nullptr;
+    // fp32 qkv still in split-K slabs (GemmArgs::defer_splits): qkv = slab 0, element = sum_s qkv[s * plane + ...] + bias[col]
+    int splits = 1; size_t plane = 0; const float* bias = nullptr;
 };
 int ofx_launch_set_attention(const SetAttnArgs& a, int op_dtype, hipStream_t s);

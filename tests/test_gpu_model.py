@@ -222,6 +222,32 @@ def test_errors_are_python_exceptions(model):
     model.cuda()
 
 
+def test_small_batch_split_k_consumers_match_the_separate_passes(model):
+    """Small batches run their GEMMs as split-K plans; by default (ofx_tune(10, 3)) the second pass rides on the consumer - bit 0:
+    the set attention sums the q | k | v slabs (same operation order as the reduce kernel: bit-identical logits), bit 1: the
+    out-proj / linear2 reduce also emits the next LayerNorm (block-wide instead of wave-wide sums: equal to fp32 rounding).
+    CP and CIR, ragged outfits, the last layer's prefix-rows-only path, B = 1 .. 32."""
+    from outfitx_amd import _lib as L
+    lib = L.load()
+    CP, CIR = tasks()[0], tasks()[1]
+    for B, lens in ((32, None), (5, [16, 0, 3, 9, 1]), (1, [7])):
+        n = synth.ragged_lengths(55 + B, B, 1, 16) if lens is None else np.asarray(lens)
+        emb, mask = synth.outfit_batch(55 + B, B, 16, n)
+        txt = synth.unit_rows(55, "t", B, 512)
+        out = {}
+        try:
+            for v in (3, 1, 0):
+                lib.ofx_tune(10, v)
+                with torch.no_grad():
+                    out[v] = (model(task=CP, outfit_embedding=cu(emb), outfit_mask=cu(mask)).cpu().numpy(),
+                              model(task=CIR, outfit_embedding=cu(emb), outfit_mask=cu(mask), target_item_text_embedding=cu(txt)).cpu().numpy())
+        finally:
+            lib.ofx_tune(10, 3)
+        assert np.array_equal(out[1][0], out[0][0]) and np.array_equal(out[1][1], out[0][1]), B
+        assert rel_err(out[3][0], out[0][0]) < 2e-5 and rel_err(out[3][1], out[0][1]) < 2e-5, B      # bf16x3 floor 2^-16: a re-ordered fp32 sum moves a few operand roundings
+        assert rel_err(out[3][0], O.cp_forward(emb, mask, synth.outfit_transformer_weights(W_SEED))) < 1e-3
+
+
 def test_edge_cases_empty_full_and_long_outfits(model):
     """Edge cases the collate can produce: outfits with 0 items (all slots masked), exactly full outfits, B = 1,
     L = 31 (the kernel limit) and L = 0 (prefix token only)."""
