@@ -11,7 +11,7 @@ namespace {
 // k-tile j >= 2 is issued by both groups in slot 2j-1 (after both groups read k-tile j-2, slots 2j-3 / 2j-2: WAR),
 // waited for (vmcnt(0)) at the end of slot 2j and read in slots 2j+1 / 2j+2 (RAW: every wave's wait precedes the
 // barrier that opens slot 2j+1).  Two 64 KiB stages + 32 KiB private epilogue staging.
-template <typename T>
+template <typename T, int ABL = 0>      // ABL (make DIAG=1, wrong results): 1 no W pieces in the loop's LDS-DMA, 2 no A pieces, 3 neither
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(KArgs p) {
     typedef typename OpT<T>::v8 v8;
     constexpr int TM = 256, TN = 256, STAGE = (TM + TN) * BK * 2;
@@ -59,9 +59,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(KArgs p) {
         const char* ak = a_base + (size_t)kt * BK * 2;
         const char* wk = w_base + (size_t)kt * BK * 2;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(ak + a_off[i], base + a_dst + i * 1024);
+        for (int i = 0; i < 4; ++i) if (!(ABL & 2) || kt < 2) glds16(ak + a_off[i], base + a_dst + i * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(wk + w_off[i], base + w_dst + i * 1024);
+        for (int i = 0; i < 4; ++i) if (!(ABL & 1) || kt < 2) glds16(wk + w_off[i], base + w_dst + i * 1024);
     };
 
     const int fr = lane & 15, fq = lane >> 4, fsw = fr >> 1;
@@ -128,8 +128,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(KArgs p) {
             for (int m = 0; m < 64; ++m) {
                 if (m % 5 == 0 && m / 5 < 8) {
                     const int q = m / 5;
-                    if (q < 4) glds16(ak + a_off[q], nbase + a_dst + q * 1024);
-                    else glds16(wk + w_off[q - 4], nbase + w_dst + (q - 4) * 1024);
+                    if (q < 4) { if (!(ABL & 2)) glds16(ak + a_off[q], nbase + a_dst + q * 1024); }
+                    else if (!(ABL & 1)) glds16(wk + w_off[q - 4], nbase + w_dst + (q - 4) * 1024);
                 }
                 const int ks = m >> 5, i = (m >> 2) & 7, j = m & 3;
                 acc[i][j] = OpT<T>::mfma16(wf[ks][j], af[ks][i], acc[i][j]);
@@ -150,22 +150,28 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(KArgs p) {
 }
 
 
-template <typename T>
+template <typename T, int ABL = 0>
 static int launch_pp(KArgs& k, int M, int N, hipStream_t s) {
     constexpr int LDSB = 2 * (256 + 256) * BK * 2 + 8 * EPI2_BYTES_PER_WAVE;
     static DeviceOnce attr;
     TRY(attr.run([]() -> int {
-        OFX_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+        OFX_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<T, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
         return OFX_OK;
     }));
     k.tiles_n = N / 256; k.tiles_m = (M + 255) / 256; k.nwg = k.tiles_m * k.tiles_n;
-    OFX_PLAUNCH(true, gemm_pp_kernel<T>, dim3(k.nwg), dim3(512), LDSB, s, k);
+    OFX_PLAUNCH(true, (gemm_pp_kernel<T, ABL>), dim3(k.nwg), dim3(512), LDSB, s, k);
     return OFX_OK;
 }
 
 }  // namespace
 
+extern int g_gemm_ablate;
 int ofx_gemm_launch_pp(void* kargs, int op_dtype, int M, int N, hipStream_t s) {
     KArgs& k = *(KArgs*)kargs;
+#ifdef OFX_DIAG
+    if (g_gemm_ablate == 1) return launch_pp<f16_t, 1>(k, M, N, s);
+    if (g_gemm_ablate == 2) return launch_pp<f16_t, 2>(k, M, N, s);
+    if (g_gemm_ablate == 3) return launch_pp<f16_t, 3>(k, M, N, s);
+#endif
     return op_dtype == OFX_F16 ? launch_pp<f16_t>(k, M, N, s) : launch_pp<bf16_t>(k, M, N, s);
 }

@@ -42,6 +42,16 @@ def main():
                 "w2": lambda: lib.ofx_gemm_w2(A.data_ptr(), W2.data_ptr(), C.data_ptr(), bias.data_ptr(), resid, M, N, K, K, N, N, act, okind, 2, s)}
         for a_ in abl:
             runs[f"abl{a_}"] = ablated(a_)
+        def x1_ablated(a):
+            def f():
+                lib.ofx_tune(1, a)
+                try:
+                    return runs["x1"]()
+                finally:
+                    lib.ofx_tune(1, 0)
+            return f
+        for a_ in [int(v) for v in os.environ.get("OFX_X1_ABLATE", "").split(",") if v]:        # single-product kernel's ablations (DIAG build)
+            runs[f"x1 abl{a_}"] = x1_ablated(a_)
         res = {k: [] for k in runs}
         for rnd in range(6):
             for k, fn in runs.items():
@@ -55,7 +65,7 @@ def main():
         t1, t2 = np.median(res["x1"]), np.median(res["w2"])
         print(f"{name:8s} M={M} N={N} K={K} ep={ep} | x1 {t1*1e3:7.1f} us {2*M*N*K/t1/1e9:6.0f} TF | w2 {t2*1e3:7.1f} us "
               f"{2*M*N*K/t2/1e9:6.0f} TF useful, {4*M*N*K/t2/1e9:6.0f} TF executed | w2/x1 {t2/t1:.2f}"
-              + "".join(f" | abl{a_} {np.median(res[f'abl{a_}'])*1e3:7.1f} us" for a_ in abl), flush=True)
+              + "".join(f" | {k} {np.median(v)*1e3:7.1f} us" for k, v in res.items() if k not in ("x1", "w2")), flush=True)
 
 
 if __name__ == "__main__":
