@@ -5,7 +5,8 @@ size-independent properties at BASELINE.json's full sizes.
 Tolerances (metric: max|Δ| / max|ref| over the batch, as DESIGN.md states):
   outfit transformer, precision 'bf16x3' (default)  : 1e-3   (north-star bound; measured ~1e-5)
   outfit transformer, 'f16' / 'bf16' single product : 3e-3 / 3e-2  (operand-rounding floor; secondary modes)
-  CLIP towers, scheme 'f16w2' (DEFAULT, what bench.py runs): 1e-3 at the tower outputs AND end to end on the CP logit (five weight seeds)
+  CLIP towers, scheme 'f16w2x' (DEFAULT, what bench.py runs): 1e-3 at the tower outputs AND end to end on the CP logit (11 weight draws here,
+  100 in profiles/r02_seed_sweep_gpu.json); 'f16w2' (the faster rung): 1e-3 on 98 of those 100, tested on its worst passing seeds
   CLIP towers 'f16' / 'bf16' single product          : 4e-3 / 3e-2  (secondary, faster modes: they do not meet the north star's 1e-3)
   argmin / top-k indices                             : bit-exact
 """
@@ -105,8 +106,8 @@ def test_vit_tower_vs_reference_golden(model):
     g = golden("vit_n4")
     px = synth.pixel_values(int(g["seed"]), 4)
     enc = model.item_encoder.image_enc
-    assert enc.tower_precision == DEFAULT_TOWERS == "f16w2"
-    for prec, tol in ((DEFAULT_TOWERS, 1e-3), ("f16w2x", 1e-3), ("f16x3", 3e-4), ("bf16", 3e-2), ("f16", 4e-3)):      # the default scheme holds the north star's bound;
+    assert enc.tower_precision == DEFAULT_TOWERS == "f16w2x"
+    for prec, tol in ((DEFAULT_TOWERS, 1e-3), ("f16w2", 1e-3), ("f16x3", 3e-4), ("bf16", 3e-2), ("f16", 4e-3)):      # the default scheme holds the north star's bound;
         enc.tower_precision = prec                      # f16x3: what is left is the MFMA attention core's f16 q, k, v, P (1.2e-4 measured)
         out = enc(cu(px).view(4, 1, 3, 224, 224), normalize=False).view(4, 512)
         e = rel_err(out.cpu().numpy(), g["image_embeds"])
@@ -137,7 +138,7 @@ def test_item_encoder_cp_with_encoder_and_precompute(model):
     px = synth.pixel_values(1239, B * L).reshape(B, L, 3, 224, 224)
     ids, att = synth.token_batch(1239, B * L, 64, np.array([4, 8, 6, 3, 9, 12]))
     texts = {"input_ids": torch.from_numpy(ids).view(B, L, 64), "attention_mask": torch.from_numpy(att).view(B, L, 64)}
-    with torch.no_grad():                                       # default tower scheme (f16w2): the north star's 1e-3 throughout
+    with torch.no_grad():                                       # default tower scheme (f16w2x): the north star's 1e-3 throughout
         items = model.item_encoder(cu(px), texts)
         cp = model(task=CP, outfit_embedding=None, outfit_mask=cu(g["mask"]), encoder_input_dict={"images": cu(px), "texts": texts})
         pe = model(task=PE, images=cu(px[:, :1]), texts={k: v[:, :1] for k, v in texts.items()})
@@ -574,7 +575,7 @@ def test_set_transformer_precision_follows_the_embedding_source(model):
     ids, att = synth.token_batch(77, B * L, 64, 8)
     texts = {"input_ids": torch.from_numpy(ids).view(B, L, 64), "attention_mask": torch.from_numpy(att).view(B, L, 64)}
     mask = np.zeros((B, L), bool)
-    assert model._tower_fed() is None                      # default towers (f16w2): the set transformer stays bf16x3
+    assert model._tower_fed() is None                      # default towers (f16w2x): the set transformer stays bf16x3
     model.item_encoder.set_precision("bf16")
     assert model.tower_fed_precision == "f16" and model._tower_fed() == "f16"
     with torch.no_grad():
@@ -651,22 +652,25 @@ def _cfg2_end_to_end(wseed, towers, bound):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("wseed", [1, 2, 3, 4, 5, 6, 14, 20, -3])
+@pytest.mark.parametrize("wseed", [1, 2, 3, 4, 5, 6, 14, 20, 44, 99, -3])
 def test_cfg2_end_to_end_within_1e3_on_every_weight_seed(wseed):
-    """Seeds 1-6 plus two of the worst of the forty measured on the GPU (profiles/r02_seed_sweep_gpu.json: 14 reads 9.7e-4 - the
-    scheme's measured edge) and seed 3 with massive residual-stream channels."""
+    """Default scheme ('f16w2x').  Seeds 1-6, the worst seeds of the hundred measured on the GPU for either split-weight scheme
+    (profiles/r02_seed_sweep_gpu.json: 14, 20, 44, 99 - on 44 and 99 the cheaper 'f16w2' reads 1.3e-3 / 1.9e-3, this scheme 4.0e-4 /
+    8.9e-4, its worst of the hundred: all eight logits of that draw are small, max|ref| = 0.27) and seed 3 with massive
+    residual-stream channels."""
     _cfg2_end_to_end(wseed, None, 1e-3)
 
 
 @pytest.mark.parametrize("wseed", [6, 14])
-def test_cfg2_end_to_end_all_vit_weights_split(wseed):
-    """tower_precision='f16w2x': every ViT GEMM against split weights (qkv as dual-weight GEMM + attention kernel)."""
-    _cfg2_end_to_end(wseed, "f16w2x", 1e-3)
+def test_cfg2_end_to_end_split_weights_on_three_gemms_only(wseed):
+    """tower_precision='f16w2' (split weights on patch embedding / out-proj / fc2 only, qkv through the fused kernel: 15 % faster):
+    inside 1e-3 on 98 of the 100 seeds measured; 14 is its worst passing one (9.7e-4)."""
+    _cfg2_end_to_end(wseed, "f16w2", 1e-3)
 
 
 @pytest.mark.parametrize("wseed", [4, 6])
 def test_cfg2_end_to_end_three_product_towers(wseed):
     """tower_precision='f16x3' (every tower GEMM in three products, the ViT's attention core still on f16 q, k, v, P): the weight
-    seeds on which the default scheme sits closest to the bound (4: 7.9e-4, 6: 4.3e-4) measure 1.3e-4 / 1.8e-4 - the slower mode
-    (60.5 vs 32 ms per cfg2 step) for callers who want a 5x margin on any weight draw."""
+    seeds 4 and 6 measure 1.3e-4 / 1.8e-4 - the slower mode (60.5 vs 37.5 ms per cfg2 step) for callers who want a 5x margin on any
+    weight draw."""
     _cfg2_end_to_end(wseed, "f16x3", 4e-4)
