@@ -241,7 +241,8 @@ int ofx_profile_records(ofx_prof_record* out, int cap);
  * knob 6: 2 (default) folds the CLIP towers' LayerNorms into the neighbouring GEMM epilogues AND keeps their residual stream as an
  * operand-type (hi, lo) pair updated in place (no fp32 stream between the layers), 1 folds with an fp32 stream, 0 materialises them;
  * knob 8: 1 (default) the ViT's last layer computes queries for the CLS rows only, 0 runs the full QKV GEMM;
- * knob 9: 1 (default) the ViT's layers run the fused QKV-projection + attention kernel, 0 the GEMM -> HBM -> attention-kernel pair;
+ * knob 9: bit 0 (default on) / bit 1 (default off): ViT layers with single-product / split (hi, lo) q | k | v weights run the fused
+ *         QKV-projection + attention kernel; cleared: the GEMM -> HBM -> attention-kernel pair;
  * knob 10: 1 (default) small-batch outfit-transformer GEMMs (split-K plans) leave their second pass to the consumer kernel (set
  *          attention sums the q | k | v slabs; reduce + LayerNorm in one launch), 0 the separate reduce and LayerNorm launches. */
 int ofx_tune(int knob, int value);
@@ -279,6 +280,10 @@ int ofx_set_attention(const float* qkv, void* out, const int* cu_seqlens, int ns
  * out [nseq * seq_len, ldo] operand type (heads concatenated).  seq_len in [33, 64], width = n_head * 64, no mask.  X and out must not alias. */
 int ofx_fused_qkv_attention(const void* X, const void* Wqkv, const float* bias, const float* row_stat, const float* col_sum, void* out,
                             int nseq, int seq_len, int width, int n_head, int ldx, int ldo, float scale, int op_dtype, ofx_stream stream);
+/* The same against split weights: Wqkv2 [3 width, 2 width], row n = [hi(width) | lo(width)] (ofx_convert mode 3): q | k | v = X . (hi + lo)^T,
+ * two MFMA products per weight on one copy of the activations (the default tower scheme 'f16w2x'). */
+int ofx_fused_qkv_attention_w2(const void* X, const void* Wqkv2, const float* bias, const float* row_stat, const float* col_sum, void* out,
+                               int nseq, int seq_len, int width, int n_head, int ldx, int ldo, float scale, int op_dtype, ofx_stream stream);
 /* fp32-arithmetic attention over fixed-length sequences of <= 64 rows (the three-product CLIP text tower): qkv fp32 [nseq * seq_len, 3 D]
  * (q | k | v), HF's causal AND key-padding mask (key_mask [nseq, mask_ld] int64, 0 = ignored, may be NULL); out as ofx_set_attention. */
 int ofx_attention_f32(const float* qkv, void* out, const int64_t* key_mask, int nseq, int seq_len, int n_head, int D, int ldo, int out_kind,

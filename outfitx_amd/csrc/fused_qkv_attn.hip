@@ -34,8 +34,15 @@ constexpr int FQ_TM = 256, FQ_TN = 192, FQ_STAGE = (FQ_TM + FQ_TN) * BK * 2;    
 constexpr int FQ_QK_ROW = 144, FQ_V_ROW = 160;
 constexpr int FQ_Q_OFF = 0, FQ_K_OFF = FQ_TM * FQ_QK_ROW, FQ_V_OFF = 2 * FQ_TM * FQ_QK_ROW;      // 0, 36864, 73728; V ends at 114688 = 2 stages
 constexpr int FQ_LDS = 2 * FQ_STAGE + 16 * FQ_V_ROW;                               // + 16 zeroed V rows behind the last image (keys S .. 63 of image G-1)
+// Dual-weight variant (W2 = true: Wqkv rows are [hi(Wm) | lo(Wm)], the split weights of DESIGN.md section 2): the main loop of
+// gemm_w2.hip - BK = 32, three stages [A 256 rows | W_hi 192 rows | W_lo 192 rows] x 64 B, the two wave groups offset by one barrier
+// slot, 48 MFMAs (8 A fragments x 3 column tiles x {hi, lo}) per wave and step against 14 fragment reads - then the same epilogue
+// and attention.  The q | k | v image (117,248 B incl. the V pad rows) lies inside the three stages (122,880 B).
+constexpr int FQ2_BK = 32, FQ2_A = FQ_TM * FQ2_BK * 2, FQ2_W = FQ_TN * FQ2_BK * 2, FQ2_STAGE = FQ2_A + 2 * FQ2_W, FQ2_NST = 3;   // 16384, 12288, 40960
+constexpr int FQ2_LDS = FQ2_NST * FQ2_STAGE;
+static_assert(FQ2_LDS >= FQ_LDS, "q | k | v image must fit the dual-weight stages");
 
-template <typename T>
+template <typename T, bool W2 = false>
 __global__ __launch_bounds__(512, 2) void fused_qkv_attn_kernel(FusedK p) {
     typedef typename OpT<T>::v8 v8;
     typedef typename OpT<T>::v4 v4;
@@ -62,6 +69,102 @@ __global__ __launch_bounds__(512, 2) void fused_qkv_attn_kernel(FusedK p) {
     const int m0 = grp * p.G * p.S;
     const int n_live_img = min(p.G, p.n_img - grp * p.G);
 
+    f32x4 acc[8][3];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+
+    if constexpr (W2) {
+    // ------------------------------------------------------------------ dual-weight main loop (see gemm_w2.hip for the slot schedule)
+    const int prow = lane >> 2, pchk = (lane & 3) ^ ((4 - (lane >> 4)) & 3);
+    const char* a_base = p.X + (size_t)m0 * p.ldx * 2;
+    const char* w_base = p.Wqkv + (size_t)head * 64 * (2 * p.Wm) * 2;          // row stride 2 Wm elements: [hi | lo]
+    unsigned a_off[2], w_off[3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 16 + prow;
+        const int rr = m0 + row < M ? row : M - 1 - m0;
+        a_off[i] = ((unsigned)rr * p.ldx + pchk * 8) * 2;
+    }
+    int w_dst[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int q = wave * 3 + i;                                            // 24 weight pieces: 0..11 hi, 12..23 lo (16 tile rows each)
+        const int row = (q % 12) * 16 + prow;                                  // tile row 0..191 = which * 64 + r
+        const unsigned grow = (unsigned)(row >> 6) * p.Wm + (row & 63);
+        w_off[i] = (grow * (2 * p.Wm) + (q >= 12 ? p.Wm : 0) + pchk * 8) * 2;
+        w_dst[i] = FQ2_A + (q >= 12 ? FQ2_W : 0) + (q % 12) * 1024;
+    }
+    const int a_dst = wave * 2 * 1024;
+    const int nk = p.Wm / FQ2_BK;
+    auto issue_all = [&](int step) {
+        const int sc = step < nk ? step : nk - 1;
+        OFX_LDS char* base = lds + (step % FQ2_NST) * FQ2_STAGE;
+        const char* ak = a_base + (size_t)sc * FQ2_BK * 2;
+        const char* wk = w_base + (size_t)sc * FQ2_BK * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(ak + a_off[i], base + a_dst + i * 1024);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) glds16(wk + w_off[i], base + w_dst[i]);
+    };
+    const int fchk = (fq ^ ((4 - (fr >> 2)) & 3)) * 16;
+    const int a_frag = (wr * 128 + fr) * 64 + fchk;
+    const int w_frag = FQ2_A + (wc * 48 + fr) * 64 + fchk;
+    v8 af[8], wh[3], wl[3];
+#define FQ2_READ(STG)                                                                                            \
+    {                                                                                                            \
+        OFX_LDS char* base_ = lds + (STG) * FQ2_STAGE;                                                           \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) wh[j] = *(OFX_LDS v8*)(base_ + w_frag + j * 16 * 64);       \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) af[i] = *(OFX_LDS v8*)(base_ + a_frag + i * 16 * 64);       \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) wl[j] = *(OFX_LDS v8*)(base_ + FQ2_W + w_frag + j * 16 * 64); \
+    }
+#define FQ2_MFMA()                                                                                               \
+    {                                                                                                            \
+        __builtin_amdgcn_s_setprio(1);                                                                           \
+        _Pragma("unroll") for (int m = 0; m < 48; ++m) {                                                         \
+            const int i = m / 6, j = m % 3;                                                                      \
+            acc[i][j] = OpT<T>::mfma16((m % 6) >= 3 ? wl[j] : wh[j], af[i], acc[i][j]);                          \
+        }                                                                                                        \
+        __builtin_amdgcn_s_setprio(0);                                                                           \
+    }
+    issue_all(0); issue_all(1);
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");            // step 0 landed (my pieces)
+    __builtin_amdgcn_s_barrier();
+    if (wr == 0) {
+        for (int t = 0; t < nk; ++t) {
+            issue_all(t + 2);
+            FQ2_READ(t % FQ2_NST)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            FQ2_MFMA()
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    // my pieces of step t+1 landed (step t+2 stays in flight)
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_s_barrier();
+    } else {
+        __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < nk; ++t) {
+            issue_all(t + 2);
+            FQ2_READ(t % FQ2_NST)
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            FQ2_MFMA()
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+#undef FQ2_READ
+#undef FQ2_MFMA
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                           // every stage read and every (clamped) fill is done: the stages become q | k | v
+    // the V pad rows lie inside stage 2 here: zero them now (the barrier before the attention publishes them)
+    if (tid < 16 * FQ_V_ROW / 16) *(OFX_LDS f32x4*)(lds + 2 * FQ_STAGE + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+    // ------------------------------------------------------------------ single-product main loop (ping-pong, BK = 64, two stages)
     // zero the V pad rows once (never touched by the stages)
     if (tid < 16 * FQ_V_ROW / 16) *(OFX_LDS f32x4*)(lds + 2 * FQ_STAGE + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -92,15 +195,9 @@ __global__ __launch_bounds__(512, 2) void fused_qkv_attn_kernel(FusedK p) {
         for (int i = 0; i < 3; ++i) glds16(wk + w_off[i], base + w_dst + i * 1024);
     };
 
-    const int fr = lane & 15, fq = lane >> 4, fsw = fr >> 1;
+    const int fsw = fr >> 1;
     const int a_frag = (wr * 128 + fr) * 128;
     const int w_frag = FQ_TM * BK * 2 + (wc * 48 + fr) * 128;
-
-    f32x4 acc[8][3];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     v8 af[2][8], wf[2][3];
 
 #define FQ_READ_FRAGS(STG)                                                                                    \
@@ -164,6 +261,7 @@ __global__ __launch_bounds__(512, 2) void fused_qkv_attn_kernel(FusedK p) {
 #undef FQ_READ_FRAGS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                           // every stage read and every (clamped) fill is done: the stages become q | k | v
+    }
 
     // ---- epilogue into LDS: acc[i][j][r] = C[row wr*128 + i*16 + fr][col wc*48 + j*16 + fq*4 + r]
     {
@@ -304,9 +402,9 @@ __global__ __launch_bounds__(512, 2) void fused_qkv_attn_kernel(FusedK p) {
 
 }  // namespace
 
-// X [n_img * S, ldx], Wqkv [3 Wm, Wm] (q | k | v rows), out [n_img * S, ldo]; non-causal, no key mask (the ViT's attention)
+// X [n_img * S, ldx], Wqkv [3 Wm, Wm] (q | k | v rows; w2: [3 Wm, 2 Wm], row = [hi | lo]), out [n_img * S, ldo]; non-causal, no key mask (the ViT's attention)
 int ofx_launch_fused_qkv_attn(const void* X, const void* Wqkv, const float* bias, const float* row_stat, const float* col_sum, void* out,
-                              int n_img, int S, int Wm, int heads, int ldx, int ldo, float scale, int op_dtype, hipStream_t s) {
+                              int n_img, int S, int Wm, int heads, int ldx, int ldo, float scale, int op_dtype, hipStream_t s, bool w2) {
     OFX_REQUIRE(X && Wqkv && bias && out && n_img > 0, OFX_EINVAL, "fused_qkv_attn: NULL argument");
     OFX_REQUIRE(S >= 33 && S <= 64 && Wm == heads * 64 && Wm % BK == 0 && Wm / BK >= 2, OFX_ESHAPE, "fused_qkv_attn: S=%d must be in [33,64], width %d = heads * 64", S, Wm);
     OFX_REQUIRE(ldx >= Wm && ldx % 8 == 0 && ldo >= Wm && ldo % 8 == 0, OFX_ESHAPE, "fused_qkv_attn: bad strides");
@@ -318,14 +416,21 @@ int ofx_launch_fused_qkv_attn(const void* X, const void* Wqkv, const float* bias
     k.nwg = ((groups + 5) / 6) * 6 * heads;            // whole units of 6 groups (blocks of the ragged tail exit at once)
     static DeviceOnce attr;
     TRY(attr.run([]() -> int {
-        OFX_HIP(hipFuncSetAttribute((const void*)fused_qkv_attn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, FQ_LDS));
-        OFX_HIP(hipFuncSetAttribute((const void*)fused_qkv_attn_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, FQ_LDS));
+        OFX_HIP(hipFuncSetAttribute((const void*)fused_qkv_attn_kernel<bf16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FQ_LDS));
+        OFX_HIP(hipFuncSetAttribute((const void*)fused_qkv_attn_kernel<f16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FQ_LDS));
+        OFX_HIP(hipFuncSetAttribute((const void*)fused_qkv_attn_kernel<bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FQ2_LDS));
+        OFX_HIP(hipFuncSetAttribute((const void*)fused_qkv_attn_kernel<f16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FQ2_LDS));
         return OFX_OK;
     }));
-    if (g_ofx_prof_on) ofx_prof_set_tag(n_img * S, 3 * Wm, Wm, 7, 1);
-    ProfScope prof(PROF_GEMM, s, 2.0 * n_img * S * 3.0 * Wm * Wm + 4.0 * n_img * S * S * Wm, true);
-    if (op_dtype == OFX_F16) OFX_PLAUNCH(true, fused_qkv_attn_kernel<f16_t>, dim3(k.nwg), dim3(512), FQ_LDS, s, k);
-    else OFX_PLAUNCH(true, fused_qkv_attn_kernel<bf16_t>, dim3(k.nwg), dim3(512), FQ_LDS, s, k);
+    if (g_ofx_prof_on) ofx_prof_set_tag(n_img * S, 3 * Wm, Wm, 7, w2 ? 2 : 1);
+    ProfScope prof(PROF_GEMM, s, (w2 ? 2.0 : 1.0) * 2.0 * n_img * S * 3.0 * Wm * Wm + 4.0 * n_img * S * S * Wm, true);
+    if (w2) {
+        if (op_dtype == OFX_F16) OFX_PLAUNCH(true, (fused_qkv_attn_kernel<f16_t, true>), dim3(k.nwg), dim3(512), FQ2_LDS, s, k);
+        else OFX_PLAUNCH(true, (fused_qkv_attn_kernel<bf16_t, true>), dim3(k.nwg), dim3(512), FQ2_LDS, s, k);
+    } else {
+        if (op_dtype == OFX_F16) OFX_PLAUNCH(true, (fused_qkv_attn_kernel<f16_t, false>), dim3(k.nwg), dim3(512), FQ_LDS, s, k);
+        else OFX_PLAUNCH(true, (fused_qkv_attn_kernel<bf16_t, false>), dim3(k.nwg), dim3(512), FQ_LDS, s, k);
+    }
     OFX_LAUNCH_CHECK();
     return OFX_OK;
 }

@@ -462,6 +462,27 @@ def test_vit_last_layer_query_pruning_changes_nothing(model):
             assert rel_err(outs[0], outs[1]) < 2e-3, (n_img, fold, rel_err(outs[0], outs[1]))
 
 
+def test_fused_attention_kernel_matches_the_gemm_attention_pair_in_the_default_scheme(model):
+    """Default scheme ('f16w2x'): ViT layers 0-10 run ofx_gemm (split weights) -> q | k | v in HBM -> attention kernel; with
+    ofx_tune(9, 3) they run the dual-weight variant of the fused QKV-projection + attention kernel instead (built, 0.9 % faster, off by
+    default: DESIGN.md section 2).  Same arithmetic: the image embeddings agree to the operand type's rounding, and both hold 1e-3
+    against the reference's golden."""
+    from outfitx_amd import _lib as L
+    lib = L.load()
+    g = golden("vit_n4")
+    px = synth.pixel_values(int(g["seed"]), 4)
+    enc = model.item_encoder.image_enc
+    out = {}
+    try:
+        for v in (1, 3):
+            lib.ofx_tune(9, v)
+            out[v] = enc(cu(px).view(4, 1, 3, 224, 224), normalize=False).view(4, 512).cpu().numpy()
+    finally:
+        lib.ofx_tune(9, 1)
+    assert rel_err(out[3], g["image_embeds"]) < 1e-3 and rel_err(out[1], g["image_embeds"]) < 1e-3
+    assert rel_err(out[3], out[1]) < 5e-4 and not np.array_equal(out[3], out[1])       # two different kernels ran
+
+
 def test_hi_lo_residual_stream_matches_the_fp32_one(model):
     """ofx_tune(6, 2): the towers keep their residual stream as an operand-type (hi, lo) pair that the out-proj / fc2 epilogues
     read and rewrite in place (no fp32 stream between the layers; the hi half is the next GEMM's operand).  2^-17 (bf16) per

@@ -363,6 +363,45 @@ def test_fused_qkv_projection_attention(fold, dt, n, S, H):
         assert rel_err(got, o2.double().cpu().numpy()) < (4e-3 if dt == "bf16" else 5e-4)
 
 
+@pytest.mark.parametrize("fold", [0, 1])
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("n,S,H", [(1, 50, 12), (5, 50, 12), (13, 50, 12), (7, 64, 4), (9, 33, 2)])
+def test_fused_qkv_projection_attention_split_weights(fold, dt, n, S, H):
+    """Dual-weight variant of the fused kernel (the default tower scheme's ViT layers): q | k | v = X . (hi + lo)^T on the
+    gemm_w2 main loop, then the same LDS-staged attention.  Against float64 arithmetic on the operand-rounded X and the exact
+    hi + lo weights, and against the unfused pair ofx_gemm_w2 -> ofx_attention on the same operands."""
+    g = np.random.default_rng(n * 11 + S + H + fold)
+    W = H * 64
+    rows = n * S
+    X = to_op(g.standard_normal((rows, W), dtype=np.float32), dt)
+    W2, Wv = _split_w((g.standard_normal((3 * W, W), dtype=np.float32) / np.float32(np.sqrt(W))).astype(np.float32), dt)
+    bias = dev((0.1 * g.standard_normal(3 * W)).astype(np.float32))
+    stat = dev(np.stack([0.05 * g.standard_normal(rows), 1.0 + 0.1 * g.standard_normal(rows)], 1).astype(np.float32)) if fold else None
+    cs = dev((0.2 * g.standard_normal(3 * W)).astype(np.float32)) if fold else None
+    lib = L.load()
+    out = torch.full((rows, W), float("nan"), dtype=X.dtype, device="cuda")
+    L.check(lib.ofx_fused_qkv_attention_w2(X.data_ptr(), W2.data_ptr(), bias.data_ptr(), stat.data_ptr() if fold else None, cs.data_ptr() if fold else None,
+                                           out.data_ptr(), n, S, W, H, W, W, 0.125, DT[dt], stream()))
+    qkv = X.double().cpu().numpy() @ Wv.T
+    if fold:
+        st = stat.double().cpu().numpy()
+        qkv = (qkv - cs.double().cpu().numpy()[None] * st[:, :1]) * st[:, 1:2]
+    qkv = qkv + bias.double().cpu().numpy()[None]
+    qkv_r = torch.from_numpy(qkv).to(X.dtype).double().numpy()
+    x = qkv_r.reshape(n, S, 3, H, 64).transpose(2, 0, 3, 1, 4)
+    want = _attn_ref(x[0], x[1], x[2], 0.125, np.zeros((n, 1, S, S), bool)).transpose(0, 2, 1, 3).reshape(rows, W)
+    got = out.double().cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel_err(got, want) < (8e-3 if dt == "bf16" else 1e-3)
+    if not fold:        # the unfused pair on the same operands
+        q2 = torch.empty(rows, 3 * W, dtype=X.dtype, device="cuda")
+        L.check(lib.ofx_gemm_w2(X.data_ptr(), W2.data_ptr(), q2.data_ptr(), bias.data_ptr(), None, rows, 3 * W, W, W, 3 * W, 0, 0, 1, DT[dt], stream()))
+        o2 = torch.zeros(rows, W, dtype=X.dtype, device="cuda")
+        L.check(lib.ofx_attention(q2.data_ptr(), o2.data_ptr(), None, n, S, H, 3 * W, W, W, 2 * W, 0, 0, 0.125, DT[dt], stream()))
+        # at these sizes ofx_gemm_w2 runs the 128x128 kernel (another fp32 summation order): single operand-type roundings of q | k | v / the output may differ
+        assert rel_err(got, o2.double().cpu().numpy()) < (8e-3 if dt == "bf16" else 1e-3)
+
+
 @pytest.mark.parametrize("kind,row0", [(0, 0), (2, 0), (0, 1), (1, 0)])
 def test_set_attention(kind, row0):
     g = np.random.default_rng(kind * 2 + row0)
