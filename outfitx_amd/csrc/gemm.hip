@@ -207,6 +207,7 @@ int g_gemm_group_m = 0;   // 0 = adaptive
 int g_gemm_ablate = 0;    // diagnostics only (tools/gemm_bench.py)
 unsigned long long* g_gemm_dbg = nullptr;   // diagnostics only
 int g_gemm_pref = 2;      // short-K big GEMMs: 0 -> 256x128 kernel, 1 -> 256x256, 2 -> 256x256 ping-pong
+int g_w2_persist = 256;   // dual-weight kernel: persistent grid size (blocks walk tiles b, b + grid, ...; 0 = one block per tile), ofx_tune(11, v)
 int g_gemm_skew = 0;      // start skew of the second co-resident block (x 8128 cycles), 256x128 kernel only
 int g_gemm_kernel = 0;    // 0 auto, 1 force 128x128, 2 force 256x256 (8 waves, 2 stages), 3 force 256x128 (4 waves, register-resident k-tile), 4 force 256x256 ping-pong, 6 force the dual-weight 256x256 kernel for split weights
 
@@ -257,7 +258,7 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
     int kind = g_gemm_kernel;
     if (g.a_wrap) {        // split weights: the dual-weight 256x256 kernel when its grid fills the chip, else the 128x128 kernel with a wrapping A index
         const long t2 = (long)((g.M + 255) / 256) * (g.N / 256);
-        kind = (g.K == 2 * g.a_wrap && g.a_wrap % 32 == 0 && g.N % 256 == 0 && (t2 >= 256 || g_gemm_kernel == 6) && g_gemm_kernel != 1) ? 6 : 1;
+        kind = (g.K == 2 * g.a_wrap && g.a_wrap % 32 == 0 && g.a_wrap >= 64 && g.N % 256 == 0 && (t2 >= 256 || g_gemm_kernel == 6) && g_gemm_kernel != 1) ? 6 : 1;
     } else if (kind == 0) {   // measured crossover points (tools/gemm_bench.py, profiles/r01_gemm_variants.txt)
         const long t2 = (long)((g.M + 255) / 256) * (g.N / 256), t3 = (long)((g.M + 255) / 256) * (g.N / 128);
         if (g.N % 256 == 0 && t2 >= 1024 && (g.K > 1024 || g_gemm_pref >= 1)) kind = g_gemm_pref == 2 && g.K <= 1024 ? 4 : 2;   // 256x256, one block per CU

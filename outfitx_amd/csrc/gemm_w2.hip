@@ -15,14 +15,17 @@
 //   Step s is read in slots 2s+1 (group 0) and 2s+2 (group 1); its stage is refilled with step s+3 in slots 2s+3 / 2s+4 (WAR: both
 //   groups' reads ended before the barrier that closes slot 2s+2).  Every wave waits for its own pieces of step s (counted
 //   vmcnt(6): the youngest step stays in flight) before the barrier that closes slot 2s; step s is first read in slot 2s+1 (RAW).
+// Persistent over tiles (one block per CU; ofx_tune(11, 0) = one block per tile): steps are numbered across the block's tiles, the
+// fills of steps nk and nk + 1 fetch the next tile's first two steps under the current epilogue (see the kernel body).
 // LDS image of a stage: [A 256 rows | W_hi 256 rows | W_lo 256 rows] x 64 B; a wave-instruction moves 16 rows x 64 B; the 16-B
 // chunk c of row r sits at slot c ^ f(r >> 2), f(g) = (-g) & 3, applied on the DMA source address and on the ds_read_b128 side:
 // conflict-free for the hardware's lane groups of ds_read_b128 (MI355X_MICROARCH.md, LDS table).
 #include "gemm_common.h"
 
+extern int g_w2_persist;
 namespace {
 
-template <typename T, int ABL = 0>      // ABL (make DIAG=1; 1-3 give wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads after step 0, 3 both, 5 DMA issued AFTER the fragment reads (the first shipped order)
+template <typename T, int ABL = 0>      // ABL (make DIAG=1; wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads after step 0, 3 both
 __global__ __launch_bounds__(512, 2) void gemm_w2_kernel(KArgs p) {
     typedef typename OpT<T>::v8 v8;
     constexpr int TM = 256, TN = 256, BK2 = 32, PART = TM * BK2 * 2, STAGE = 3 * PART, NST = 3;      // 16 KiB per operand, 48 KiB per stage
@@ -31,74 +34,107 @@ __global__ __launch_bounds__(512, 2) void gemm_w2_kernel(KArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const int Kh = p.K >> 1;                           // logical K; p.K = 2 Kh is the row stride of W = [hi | lo]
-
-    int bid = blockIdx.x;
-    {
-        const int nx = 8, q = p.nwg / nx, r = p.nwg % nx, x = bid % nx, i = bid / nx;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    const int Kh = p.K >> 1;                           // logical K; 2 Kh is the row stride of W = [hi | lo]
+    p.K = Kh;                                          // the epilogues never read K; keep the logical value anyway
+    if (p.m_dev) {                                     // device-side live row count: the launcher runs one block per tile then
+        const int m_live = *p.m_dev;
+        p.M = m_live < p.M ? m_live : p.M;
     }
-    int tm, tn;
-    {
+
+    // Persistent over tiles: block b runs tiles b, b + gridDim.x, ... (the launcher sizes the grid to one block per CU, or one block
+    // per tile on small problems).  The k-steps are numbered across the block's tiles - step g lives in stage g % 3 - so the two fills
+    // that used to be redundant at the end of a tile (steps nk, nk + 1) fetch the NEXT tile's first two steps instead: they land
+    // under the epilogue, whose staging sits in the stage of the tile's last step (the one stage no fill targets), and the next main
+    // loop starts without a load-latency bubble.
+    auto map_tile = [&](int vb, int& m0, int& n0) {
+        int bid = vb;
+        {
+            const int nx = 8, q = p.nwg / nx, r = p.nwg % nx, x = bid % nx, i = bid / nx;
+            bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+        }
         const int per_group = p.group_m * p.tiles_n;
         const int gidx = bid / per_group, first = gidx * p.group_m;
         const int gm = min(p.group_m, p.tiles_m - first);
         const int r = bid - gidx * per_group;
-        tm = first + r % gm;
-        tn = r / gm;
-    }
-    const int m0 = tm * TM, n0 = tn * TN;
-    if (p.m_dev) {
-        const int m_live = *p.m_dev;
-        p.M = m_live < p.M ? m_live : p.M;
-        if (m0 >= p.M) return;
-    }
-
-    // LDS-DMA pieces: 16 rows x 64 B; lane l -> row l >> 2, physical slot l & 3 <- logical chunk (l & 3) ^ f(row >> 2)
-    const int prow = lane >> 2, pchk = (lane & 3) ^ ((4 - (lane >> 4)) & 3);
-    const char* a_base = p.A + (size_t)m0 * p.lda * 2;
-    const char* w_base = p.W + (size_t)n0 * p.K * 2;
-    unsigned a_off[2], w_off[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave * 2 + i) * 16 + prow;
-        const int rr = m0 + row < p.M ? row : p.M - 1 - m0;          // rows past M re-read the last live row
-        a_off[i] = ((unsigned)rr * p.lda + pchk * 8) * 2;
-        w_off[i] = ((unsigned)row * p.K + pchk * 8) * 2;
-    }
-    const int dst0 = wave * 2 * 1024;
+        m0 = (first + r % gm) * TM;
+        n0 = (r / gm) * TN;
+    };
     const unsigned lo_bytes = (unsigned)Kh * 2;
     const int nk = Kh / BK2;
-#define OFX_W2_PIECE(Q, AK, WK, BASE)                                                              \
-    {                                                                                              \
-        if ((Q) < 2) glds16((AK) + a_off[(Q)], (BASE) + dst0 + (Q) * 1024);                        \
-        else if ((Q) < 4) glds16((WK) + w_off[(Q) - 2], (BASE) + PART + dst0 + ((Q) - 2) * 1024);  \
-        else glds16((WK) + lo_bytes + w_off[(Q) - 4], (BASE) + 2 * PART + dst0 + ((Q) - 4) * 1024); \
+    const int dst0 = wave * 2 * 1024;
+
+    int vb = blockIdx.x, m0, n0;
+    map_tile(vb, m0, n0);
+    if (m0 >= p.M) return;                              // only with m_dev (one block per tile)
+    int base = 0;                                       // (global index of the current tile's step 0) mod 3
+    bool first = true;
+    for (;;) {
+        const bool has_next = vb + (int)gridDim.x < p.nwg;     // its first two steps are fetched by this tile's last two fills
+        // Lane constants are re-derived per tile from an opaque copy of the lane id: kept live across the epilogue they cost more
+        // registers than the kernel has (spills), recomputing them costs a few dozen VALU operations per ~50 us tile.
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        // LDS-DMA pieces: 16 rows x 64 B; lane l -> row l >> 2, physical slot l & 3 <- logical chunk (l & 3) ^ f(row >> 2)
+        const int prow = ln >> 2, pchk = (ln & 3) ^ ((4 - (ln >> 4)) & 3);
+        unsigned w_off[2];                                  // tile-independent
+#pragma unroll
+        for (int i = 0; i < 2; ++i) w_off[i] = ((unsigned)((wave * 2 + i) * 16 + prow) * (2 * Kh) + pchk * 8) * 2;
+        auto a_offset = [&](int mt, int i) {                // rows past M re-read the last live row
+            const int row = (wave * 2 + i) * 16 + prow;
+            const int rr = mt + row < p.M ? row : p.M - 1 - mt;
+            return ((unsigned)rr * p.lda + pchk * 8) * 2;
+        };
+        const int fr = ln & 15, fq = ln >> 4;
+        const int fchk = (fq ^ ((4 - (fr >> 2)) & 3)) * 16;
+        const int a_frag = (wr * 128 + fr) * 64 + fchk;
+        const int w_frag = PART + (wc * 64 + fr) * 64 + fchk;
+        const char* a_base = p.A + (size_t)m0 * p.lda * 2;
+        const char* w_base = p.W + (size_t)n0 * (2 * Kh) * 2;
+        unsigned a_off[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a_off[i] = a_offset(m0, i);
+
+#define OFX_W2_PIECE(Q, AK, A0, A1, WK, BASE)                                                          \
+    {                                                                                                  \
+        if ((Q) < 2) glds16((AK) + ((Q) ? (A1) : (A0)), (BASE) + dst0 + (Q) * 1024);                    \
+        else if ((Q) < 4) glds16((WK) + w_off[(Q) - 2], (BASE) + PART + dst0 + ((Q) - 2) * 1024);       \
+        else glds16((WK) + lo_bytes + w_off[(Q) - 4], (BASE) + 2 * PART + dst0 + ((Q) - 4) * 1024);     \
     }
-    auto issue_all = [&](int step) {
-        const int sc = step < nk ? step : nk - 1;
-        OFX_LDS char* base = lds + (step % NST) * STAGE;
-        const char* ak = a_base + (size_t)sc * BK2 * 2;
-        const char* wk = w_base + (size_t)sc * BK2 * 2;
+        auto issue_cur = [&](int step) {                // a step of the current tile (step < nk)
+            OFX_LDS char* sbase = lds + ((base + step) % NST) * STAGE;
+            const char* ak = a_base + (size_t)step * BK2 * 2;
+            const char* wk = w_base + (size_t)step * BK2 * 2;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) OFX_W2_PIECE(q, ak, wk, base)
-    };
-
-    const int fr = lane & 15, fq = lane >> 4;
-    const int fchk = (fq ^ ((4 - (fr >> 2)) & 3)) * 16;
-    const int a_frag = (wr * 128 + fr) * 64 + fchk;
-    const int w_frag = PART + (wc * 64 + fr) * 64 + fchk;
-
-    f32x4 acc[8][4];
+            for (int q = 0; q < 6; ++q) OFX_W2_PIECE(q, ak, a_off[0], a_off[1], wk, sbase)
+        };
+        auto issue_next = [&](int j) {                  // step nk + j: the next tile's step j, in the stage of this tile's step nk + j - 3
+            OFX_LDS char* sbase = lds + ((base + nk + j) % NST) * STAGE;
+            if (has_next) {
+                int m1, n1;
+                map_tile(vb + (int)gridDim.x, m1, n1);
+                const char* ak = p.A + (size_t)m1 * p.lda * 2 + (size_t)j * BK2 * 2;
+                const char* wk = p.W + (size_t)n1 * (2 * Kh) * 2 + (size_t)j * BK2 * 2;
+                const unsigned n0_ = a_offset(m1, 0), n1_ = a_offset(m1, 1);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+                for (int q = 0; q < 6; ++q) OFX_W2_PIECE(q, ak, n0_, n1_, wk, sbase)
+            } else {                                    // the block's last tile: a redundant re-fill with the last step (keeps the counted waits uniform; nobody reads it)
+                const char* ak = a_base + (size_t)(nk - 1) * BK2 * 2;
+                const char* wk = w_base + (size_t)(nk - 1) * BK2 * 2;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    v8 af[8], wh[4], wl[4];
+                for (int q = 0; q < 6; ++q) OFX_W2_PIECE(q, ak, a_off[0], a_off[1], wk, sbase)
+            }
+        };
 
-#define OFX_W2_READ(STG)                                                                                     \
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        v8 af[8], wh[4], wl[4];
+
+#define OFX_W2_READ(STEP)                                                                                    \
     {                                                                                                        \
-        OFX_LDS char* base_ = lds + (STG) * STAGE;                                                           \
+        OFX_LDS char* base_ = lds + ((base + (STEP)) % NST) * STAGE;                                         \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) wh[j] = *(OFX_LDS v8*)(base_ + w_frag + j * 16 * 64);   \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) af[i] = *(OFX_LDS v8*)(base_ + a_frag + i * 16 * 64);   \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) wl[j] = *(OFX_LDS v8*)(base_ + PART + w_frag + j * 16 * 64); \
@@ -116,52 +152,66 @@ __global__ __launch_bounds__(512, 2) void gemm_w2_kernel(KArgs p) {
         __builtin_amdgcn_s_setprio(0);                                                                       \
     }
 
-    issue_all(0); issue_all(1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            // step 0 landed (my pieces)
-    __builtin_amdgcn_s_barrier();                               // ---- end of slot 0
-    if (wr == 0) {
-        for (int t = 0; t < nk; ++t) {
-            // slot 2t+1: read step t; refill the stage of step t-1 (group 1 read it in slot 2t) with step t+2
-            if (ABL == 0 || ABL == 2) issue_all(t + 2);         // before the reads: 760 vs 775 us on the fc2 shape (tools/gemm_w2_bench.py, DIAG build)
-            if (ABL < 2 || ABL == 5 || t == 0) OFX_W2_READ(t % NST)
-            if (ABL == 5) issue_all(t + 2);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            // slot 2t+2: multiply step t
-            OFX_W2_MFMA()
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // my pieces of step t+1 landed (step t+2 stays in flight)
-            __builtin_amdgcn_s_barrier();
+        if (first) {
+            issue_cur(0); issue_cur(1);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");        // step 0 landed (my pieces)
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // steps 0 and 1 (fetched under the previous epilogue) and that epilogue's stores
         }
-        __builtin_amdgcn_s_barrier();                           // group 1's last MFMA slot
-    } else {
-        __builtin_amdgcn_s_barrier();                           // slot 1: group 0 reads step 0
-        for (int t = 0; t < nk; ++t) {
-            // slot 2t+2: read step t; refill the stage of step t-1 (read by group 0 in slot 2t-1, by this group in slot 2t)
-            if (ABL == 0 || ABL == 2) issue_all(t + 2);         // before the reads: 760 vs 775 us on the fc2 shape (tools/gemm_w2_bench.py, DIAG build)
-            if (ABL < 2 || ABL == 5 || t == 0) OFX_W2_READ(t % NST)
-            if (ABL == 5) issue_all(t + 2);
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // my pieces of step t+1 landed: group 0 reads them in slot 2t+3
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            // slot 2t+3: multiply step t
-            OFX_W2_MFMA()
-            __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();                               // ---- end of slot 0
+        // One iteration of group 0 (slots 2t+1, 2t+2) / group 1 (slots 2t+2, 2t+3): ISSUE refills the stage of step t-1 (both groups
+        // have read it) with step t+2, before the reads (760 vs 775 us on the fc2 shape with the DMA after them); the last two
+        // iterations of a tile are peeled so that the steady-state body carries no next-tile logic.
+#define OFX_W2_ITER_G0(T_, ISSUE)                                                                                \
+        {                                                                                                        \
+            if (ABL == 0 || ABL == 2) { ISSUE; }                                                                 \
+            if (ABL < 2 || (T_) == 0) OFX_W2_READ(T_)                                                            \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            __builtin_amdgcn_s_barrier();                                                                        \
+            OFX_W2_MFMA()                                                                                        \
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    /* my pieces of step t+1 landed (step t+2 stays in flight) */ \
+            __builtin_amdgcn_s_barrier();                                                                        \
         }
-    }
+#define OFX_W2_ITER_G1(T_, ISSUE)                                                                                \
+        {                                                                                                        \
+            if (ABL == 0 || ABL == 2) { ISSUE; }                                                                 \
+            if (ABL < 2 || (T_) == 0) OFX_W2_READ(T_)                                                            \
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    /* my pieces of step t+1 landed: group 0 reads them in slot 2t+3 */ \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            __builtin_amdgcn_s_barrier();                                                                        \
+            OFX_W2_MFMA()                                                                                        \
+            __builtin_amdgcn_s_barrier();                                                                        \
+        }
+        if (wr == 0) {
+            for (int t = 0; t < nk - 2; ++t) OFX_W2_ITER_G0(t, issue_cur(t + 2))
+            OFX_W2_ITER_G0(nk - 2, issue_next(0))
+            OFX_W2_ITER_G0(nk - 1, issue_next(1))
+            __builtin_amdgcn_s_barrier();                           // group 1's last MFMA slot begins: every read of this tile is done
+        } else {
+            __builtin_amdgcn_s_barrier();                           // slot 1: group 0 reads step 0
+            for (int t = 0; t < nk - 2; ++t) OFX_W2_ITER_G1(t, issue_cur(t + 2))
+            OFX_W2_ITER_G1(nk - 2, issue_next(0))
+            OFX_W2_ITER_G1(nk - 1, issue_next(1))
+        }
+#undef OFX_W2_ITER_G0
+#undef OFX_W2_ITER_G1
 #undef OFX_W2_READ
 #undef OFX_W2_MFMA
 #undef OFX_W2_PIECE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the clamped tail fills have landed ...
-    __builtin_amdgcn_s_barrier();                               // ... everybody's: the stages are dead, the epilogue staging aliases them
-
-    OFX_LDS char* ep = lds + wave * EPI2_BYTES_PER_WAVE;
-    const int gm0 = m0 + wr * 128, gn0 = n0 + wc * 64;
-    OFX_LDS float* st = nullptr;
-    if (p.row_stat && p.out_kind != 0) st = (OFX_LDS float*)(lds + 8 * EPI2_BYTES_PER_WAVE + wave * 1024);
-    p.K = Kh;                                                   // the epilogues never read K; keep the logical value anyway
-    epilogue2_dispatch<T>(p, ep, acc, gm0, gn0, lane, st);
+        // Epilogue staging: the stage of this tile's LAST step - read by everybody before the barriers above, and the one stage
+        // the fills of steps nk, nk + 1 (the next tile's first steps, still landing) do not target.
+        OFX_LDS char* estage = lds + ((base + nk - 1) % NST) * STAGE;
+        OFX_LDS char* ep = estage + wave * EPI2_BYTES_PER_WAVE;
+        const int gm0 = m0 + wr * 128, gn0 = n0 + wc * 64;
+        OFX_LDS float* st = nullptr;
+        if (p.row_stat && p.out_kind != 0) st = (OFX_LDS float*)(estage + 8 * EPI2_BYTES_PER_WAVE + wave * 1024);
+        epilogue2_dispatch<T>(p, ep, acc, gm0, gn0, ln, st);
+        if (!has_next) break;
+        vb += gridDim.x; map_tile(vb, m0, n0); base = (base + nk) % NST; first = false;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the last tile's redundant fills have landed before the wave ends
 }
 
 template <typename T, int ABL = 0>
@@ -173,7 +223,9 @@ static int launch_w2(KArgs& k, int M, int N, hipStream_t s) {
         return OFX_OK;
     }));
     k.tiles_n = N / 256; k.tiles_m = (M + 255) / 256; k.nwg = k.tiles_m * k.tiles_n;
-    OFX_PLAUNCH(true, (gemm_w2_kernel<T, ABL>), dim3(k.nwg), dim3(512), LDSB, s, k);
+    // one block per CU, each walking tiles b, b + grid, ... (g_w2_persist == 0: one block per tile, as before)
+    const int grid = (g_w2_persist && !k.m_dev && k.nwg > g_w2_persist) ? g_w2_persist : k.nwg;
+    OFX_PLAUNCH(true, (gemm_w2_kernel<T, ABL>), dim3(grid), dim3(512), LDSB, s, k);
     return OFX_OK;
 }
 
@@ -186,7 +238,6 @@ int ofx_gemm_launch_w2(void* kargs, int op_dtype, int M, int N, hipStream_t s) {
     if (g_gemm_ablate == 1) return launch_w2<f16_t, 1>(k, M, N, s);
     if (g_gemm_ablate == 2) return launch_w2<f16_t, 2>(k, M, N, s);
     if (g_gemm_ablate == 3) return launch_w2<f16_t, 3>(k, M, N, s);
-    if (g_gemm_ablate == 5) return launch_w2<f16_t, 5>(k, M, N, s);
 #endif
     return op_dtype == OFX_F16 ? launch_w2<f16_t>(k, M, N, s) : launch_w2<bf16_t>(k, M, N, s);
 }

@@ -42,6 +42,15 @@ def main():
                 "w2": lambda: lib.ofx_gemm_w2(A.data_ptr(), W2.data_ptr(), C.data_ptr(), bias.data_ptr(), resid, M, N, K, K, N, N, act, okind, 2, s)}
         for a_ in abl:
             runs[f"abl{a_}"] = ablated(a_)
+        if os.environ.get("OFX_KNOB"):                  # A/B of an ofx_tune knob on the dual-weight kernel: OFX_KNOB=11:0:256 (knob:value:restore)
+            kn, kv, kr = [int(v) for v in os.environ["OFX_KNOB"].split(":")]
+            def knobbed():
+                lib.ofx_tune(kn, kv)
+                try:
+                    return runs["w2"]()
+                finally:
+                    lib.ofx_tune(kn, kr)
+            runs[f"w2 knob{kn}={kv}"] = knobbed
         def x1_ablated(a):
             def f():
                 lib.ofx_tune(1, a)
