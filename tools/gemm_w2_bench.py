@@ -7,7 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from outfitx_amd import _lib as L
 
 SHAPES = [("vit out", 102400, 768, 768, "r"), ("vit fc2", 102400, 768, 3072, "r"), ("patch", 100352, 768, 3072, "f"),
-          ("vit qkv", 102400, 2304, 768, "b"), ("vit fc1", 102400, 3072, 768, "g")]
+          ("vit qkv", 102400, 2304, 768, "b"), ("vit fc1", 102400, 3072, 768, "g"),
+          # the text tower's three-product GEMMs as dual-weight calls on K' = 2 K (A' = [hi | lo], W rows [hi | hi] / [lo | 0]): name them to run them
+          ("txt qkv", 16384, 1536, 1024, "f"), ("txt out", 16384, 512, 1024, "r"), ("txt fc1", 16384, 2048, 1024, "g"), ("txt fc2", 16384, 512, 4096, "r")]
 
 
 def main():
@@ -16,8 +18,9 @@ def main():
     s = torch.cuda.current_stream().cuda_stream
     g = torch.Generator(device="cuda"); g.manual_seed(0)
     for name, M, N, K, ep in SHAPES:
-        if only and not any(o in name for o in only):
+        if (only and not any(o in name for o in only)) or (not only and name.startswith("txt")):
             continue
+        lib.ofx_tune(2, 6 if name.startswith("txt") else 0)          # small grids: force the dual-weight 256x256 kernel
         A = torch.randn(M, K, device="cuda", generator=g).half()
         Wf = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
         W = Wf.half()
