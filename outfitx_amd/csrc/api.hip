@@ -647,8 +647,8 @@ extern "C" int ofx_cir_prefix(ofx_handle* h, const float* txt, int B, float* out
 // One CLIP encoder layer on `rows` rows.  When `pool_idx` is given (last layer) everything after the attention
 // runs only on the n pooled rows (CLS / EOS): they are the only ones the tower's output depends on.
 int g_fuse_qkv = 1;     // ofx_tune(9, v): bit 0 (default on) = ViT layers with single-product q | k | v weights run the fused QKV-projection + attention kernel
-                        // (q | k | v stay in LDS); bit 1 (default OFF) = so do layers with split (hi, lo) weights, through its dual-weight variant: 0.9 % faster
-                        // per step, same error distribution, but on the 100-seed sweep it re-rolls two borderline small-logit weight draws from 8.0e-4 /
+                        // (q | k | v stay in LDS); bit 1 (default OFF) = so do layers with split (hi, lo) weights, through its dual-weight variant: level with the
+                        // persistent GEMM + attention-kernel pair in time, same error distribution, but on the 100-seed sweep it re-rolls two borderline small-logit weight draws from 8.0e-4 /
                         // 8.9e-4 to 1.05e-3 / 1.12e-3, so the default scheme keeps the dual-weight GEMM + attention-kernel pair
 int ofx_launch_fused_qkv_attn(const void* X, const void* Wqkv, const float* bias, const float* row_stat, const float* col_sum, void* out,
                               int n_img, int S, int Wm, int heads, int ldx, int ldo, float scale, int op_dtype, hipStream_t s, bool w2 = false);
