@@ -245,8 +245,8 @@ int ofx_profile_records(ofx_prof_record* out, int cap);
  *         QKV-projection + attention kernel; cleared: the GEMM -> HBM -> attention-kernel pair;
  * knob 10: 1 (default) small-batch outfit-transformer GEMMs (split-K plans) leave their second pass to the consumer kernel (set
  *          attention sums the q | k | v slabs; reduce + LayerNorm in one launch), 0 the separate reduce and LayerNorm launches;
- * knob 11: grid size of the persistent dual-weight GEMM (default 256 = one block per CU, each walking its tiles and fetching the next
- *          tile's first k-steps under the current epilogue), 0 = one block per tile. */
+ * knob 11: grid size of the persistent dual-weight GEMM (default -1 = one block per CU of the device, each walking its tiles and
+ *          fetching the next tile's first k-steps under the current epilogue), 0 = one block per tile. */
 int ofx_tune(int knob, int value);
 /* Diagnostics: when buf != NULL the big-tile GEMM writes {shader cycles, 100 MHz ticks} of its main loop per block (16 B each). */
 void ofx_debug_gemm_clock(void* buf);

@@ -207,7 +207,7 @@ int g_gemm_group_m = 0;   // 0 = adaptive
 int g_gemm_ablate = 0;    // diagnostics only (tools/gemm_bench.py)
 unsigned long long* g_gemm_dbg = nullptr;   // diagnostics only
 int g_gemm_pref = 2;      // short-K big GEMMs: 0 -> 256x128 kernel, 1 -> 256x256, 2 -> 256x256 ping-pong
-int g_w2_persist = 256;   // dual-weight kernel: persistent grid size (blocks walk tiles b, b + grid, ...; 0 = one block per tile), ofx_tune(11, v)
+int g_w2_persist = -1;    // dual-weight kernel: persistent grid size (blocks walk tiles b, b + grid, ...): -1 = one block per CU of the device, 0 = one block per tile, ofx_tune(11, v)
 int g_gemm_skew = 0;      // start skew of the second co-resident block (x 8128 cycles), 256x128 kernel only
 int g_gemm_kernel = 0;    // 0 auto, 1 force 128x128, 2 force 256x256 (8 waves, 2 stages), 3 force 256x128 (4 waves, register-resident k-tile), 4 force 256x256 ping-pong, 6 force the dual-weight 256x256 kernel for split weights
 

@@ -223,8 +223,17 @@ static int launch_w2(KArgs& k, int M, int N, hipStream_t s) {
         return OFX_OK;
     }));
     k.tiles_n = N / 256; k.tiles_m = (M + 255) / 256; k.nwg = k.tiles_m * k.tiles_n;
-    // one block per CU, each walking tiles b, b + grid, ... (g_w2_persist == 0: one block per tile, as before)
-    const int grid = (g_w2_persist && !k.m_dev && k.nwg > g_w2_persist) ? g_w2_persist : k.nwg;
+    // one block per CU, each walking tiles b, b + grid, ... (g_w2_persist: -1 = the device's CU count, 0 = one block per tile, n = n blocks)
+    int persist = g_w2_persist;
+    if (persist < 0) {
+        static int cus[64] = {0};                      // per device ordinal; a benign race writes the same value
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        int& c = cus[dev & 63];
+        if (c == 0) { int v = 0; c = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256; }
+        persist = c;
+    }
+    const int grid = (persist && !k.m_dev && k.nwg > persist) ? persist : k.nwg;
     OFX_PLAUNCH(true, (gemm_w2_kernel<T, ABL>), dim3(grid), dim3(512), LDSB, s, k);
     return OFX_OK;
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of an ofx_tune knob on the headline step (BASELINE configs[1]: 256 outfits x 8 items, default schemes, text tower on the side
-stream), interleaved rounds in one process:   python tools/step_ab.py KNOB V1 V2 ...   e.g.  python tools/step_ab.py 11 256 0"""
+stream), interleaved rounds in one process:   python tools/step_ab.py KNOB V1 V2 ...   e.g.  python tools/step_ab.py 11 -1 0"""
 import os, sys, time, warnings
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); warnings.simplefilter("ignore")
