@@ -53,6 +53,20 @@ def oracle_logits(px, ids, att, mask, n_outfits):
     return O.cp_forward(emb, mask[:n_outfits], synth.outfit_transformer_weights(W_SEED))
 
 
+def bench_reference_logits(w_seed, B, n, in_crc):
+    """The reference's own CP logits of this batch (tests/golden/cfg2_bench_logits.npz: src.models.OutfitX run on the CPU in fp32 in the
+    build container by oracle/gen_bench_golden.py) - or None when the run is not the fixture's configuration."""
+    path = os.path.join(ROOT, "tests", "golden", "cfg2_bench_logits.npz")
+    if not os.path.exists(path):
+        return None
+    z = np.load(path)
+    if f"w{w_seed}" not in z or int(z["outfits"]) != B or int(z["items"]) != n:
+        return None
+    if (str(z["px_crc"]), str(z["ids_crc"])) != in_crc:
+        raise RuntimeError("bench batch differs from the fixture's inputs (checksum mismatch)")
+    return z[f"w{w_seed}"].astype(np.float32)
+
+
 def host_cores():
     """CPU cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands one job a 16-core
     share of a 256-thread host; 256 torch threads on that share run several times slower than 16)."""
@@ -164,6 +178,9 @@ def main():
     rehearsal = os.environ.get("OFX_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local = 0
+    if world > 1:            # N ranks share one host: each takes its share of the cores (token staging, pinned copies, the input generator)
+        torch.set_num_threads(max(1, host_cores() // world))
+        os.environ.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // world)))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -188,13 +205,13 @@ def main():
     model.item_encoder.overlap_towers = bool(a.overlap_towers)
 
     B, n = a.outfits, a.items
-    seed = 1236 + rank
-    g = torch.Generator(device=dev); g.manual_seed(seed)
-    u8 = torch.randint(0, 256, (B, n, 3, 224, 224), generator=g, device=dev, dtype=torch.uint8)
-    mean = torch.tensor(synth.CLIP_MEAN, device=dev).view(1, 1, 3, 1, 1); std = torch.tensor(synth.CLIP_STD, device=dev).view(1, 1, 3, 1, 1)
-    px = ((u8.float() * (1 / 255.0) - mean) / std).contiguous()          # [B,n,3,224,224] fp32, host preprocessing excluded
-    del u8
-    ids_np, att_np = synth.token_batch(seed, B * n, 64, 8)              # BOS + 6 words + EOS, padded to 64
+    seed = 1236 + rank                                                    # rank-local batch (weak scaling)
+    # host-generated (numpy PCG64) so that the build container - where the reference itself can be imported,
+    # oracle/gen_bench_golden.py - and this box see the same batch; preprocessing excluded from the timing
+    px_np, ids_np, att_np = synth.bench_batch(seed, B, n)                 # [B,n,3,224,224] fp32; BOS + 6 words + EOS, padded to 64
+    in_crc = (synth.checksum(px_np[:2]), synth.checksum(ids_np))
+    px = torch.from_numpy(px_np).to(dev)
+    del px_np
     texts = {"input_ids": torch.from_numpy(ids_np).view(B, n, 64).pin_memory(), "attention_mask": torch.from_numpy(att_np).view(B, n, 64).pin_memory()}
     mask = torch.zeros(B, n, dtype=torch.bool, device=dev)
 
@@ -251,81 +268,91 @@ def main():
         alg_all_outfit = alg_gemm_outfit + n * (VIT_ATTN + txt_attn(T_real)) + ot_attn(n)
         padded_outfit = n * (VIT_GEMM + VIT_ATTN + txt_gemm(64) + txt_attn(64)) + ot_gemm(16) + ot_attn(16)
         gemm_ms, gemm_launches = ms[0], int(cnt[0])
-        achieved = alg_gemm_outfit * B / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0   # one sampled step
+        achieved_fixed = alg_gemm_outfit * B / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0   # SURVEY 8(d)'s per-outfit count x outfits, one sampled step
         executed = fl[0] / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         # per-shape table of the sampled step: shape -> kernel -> launches, us per launch, useful TF/s (2 M N K_logical) and its
-        # fraction of the dense peak, executed TF/s (x kmul: split weights run 2, three-product GEMMs 3 MFMA products per term)
+        # fraction of the dense peak, executed TF/s (x kmul: split weights run 2, three-product GEMMs 3 MFMA products per term),
+        # algorithmic HBM bytes per launch as the launch's own epilogue configuration implies (ofx_prof_record.bytes)
         KIND = {1: "gemm_128x128_kernel", 2: "gemm_big_kernel<2,4,2>", 3: "gemm_big_kernel<2,2,1>", 4: "gemm_pp_kernel", 6: "gemm_w2_kernel",
-                7: "fused_qkv_attn_kernel (N = q|k|v columns; its attention FLOPs are not in useful_tflops)"}
+                7: "fused_qkv_attn_kernel (N = q|k|v columns; its attention FLOPs are not in useful_tflops)", 8: "gemm_w2f8_kernel"}
         shapes = {}
         for i in range(nrec):
             r = recs[i]
             if r.cat != 0:
                 continue
-            e = shapes.setdefault((r.M, r.N, r.K, r.kmul, r.kind), [0, 0.0])
-            e[0] += 1; e[1] += r.ms
-        table = []
-        for (M_, N_, K_, km_, kind_), (c_, t_) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+            e = shapes.setdefault((r.M, r.N, r.K, r.kmul, r.kind), [0, 0.0, 0.0])
+            e[0] += 1; e[1] += r.ms; e[2] += r.bytes
+        table, by_kernel = [], {}
+        launched_flop = 0.0          # useful FLOPs of the shapes actually launched (the pruned last ViT layer runs fewer rows than 8(d) counts)
+        for (M_, N_, K_, km_, kind_), (c_, t_, b_) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
             useful = 2.0 * M_ * N_ * K_ * c_ / (t_ * 1e-3) / 1e12
+            launched_flop += 2.0 * M_ * N_ * K_ * c_
             table.append({"M": M_, "N": N_, "K": K_, "products_per_term": km_, "kernel": KIND.get(kind_, str(kind_)), "launches": c_,
                           "us_per_launch": round(t_ * 1e3 / c_, 1), "ms_per_step": round(t_, 3), "useful_tflops": round(useful, 1),
-                          "frac_useful": round(useful / PEAK_BF16_TFLOPS, 4), "executed_tflops": round(useful * km_, 1)})
-        traffic, traffic_src = None, None   # PMC counters cannot be read inside a timed run: the committed rocprofv3 --pmc passes of this same command
-        try:
-            with open(os.path.join(ROOT, "profiles", "r02_mfma_util.json")) as f:
-                traffic = round(json.load(f)["gemm_kernels"]["gemm_hbm_bytes_per_launch"]); traffic_src = "r02_mfma_util.json"
-        except Exception:
-            pass
-
-        def alg_bytes(M_, N_, K_, km_, kind_):
-            """Algorithmic HBM bytes of one GEMM launch: every operand read once, every output written once.  A = M x K operand rows
-            (x3 wide in the three-product form), W = N x K x products, output by what the launch produces."""
-            a_b = M_ * K_ * 2 * (3 if km_ == 3 else 1)
-            w_b = N_ * K_ * 2 * km_
-            if kind_ == 7:                       # fused QKV + attention: writes the attention output [M, N / 3] in the operand type
-                o_b = M_ * (N_ // 3) * 2
-            elif km_ == 2 and N_ == 768 and K_ == 3072 and M_ > 100000 and M_ % 49 == 0:
-                o_b = M_ * N_ * 4                # patch embedding: fp32 output
-            elif km_ == 2:
-                o_b = M_ * N_ * 8                # out-proj / fc2 on the (hi, lo) residual stream: 4 B read + 4 B written per element
-            elif km_ == 3:
-                o_b = M_ * N_ * (8 if N_ in (512, 1024) else 6)      # fp32 residual read + write; else [hi | lo | hi] or fp32 q|k|v
-            else:
-                o_b = M_ * N_ * 2
-            return a_b + w_b + o_b
-        alg_total = sum(alg_bytes(M_, N_, K_, km_, kind_) * c_ for (M_, N_, K_, km_, kind_), (c_, t_) in shapes.items())
+                          "frac_useful": round(useful / PEAK_BF16_TFLOPS, 4), "executed_tflops": round(useful * km_, 1),
+                          "algorithmic_mb_per_launch": round(b_ / c_ / 1e6, 1), "algorithmic_tb_per_s": round(b_ / (t_ * 1e-3) / 1e12, 2)})
+            k_ = by_kernel.setdefault(KIND.get(kind_, str(kind_)).split(" ")[0], [0, 0.0, 0.0, 0.0])
+            k_[0] += c_; k_[1] += t_; k_[2] += b_; k_[3] += 2.0 * M_ * N_ * K_ * c_
+        achieved = launched_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0      # useful FLOPs of the launched shapes: the graded figure
+        alg_total = sum(v[2] for v in shapes.values())
+        assert abs(alg_total - sum(v[2] for v in by_kernel.values())) <= 1e-6 * max(alg_total, 1.0)
         alg_per_launch = alg_total / max(gemm_launches, 1)
+        # PMC counters cannot be read inside a timed run: `traffic` refers to the committed rocprofv3 --pmc passes of this same
+        # command (tools/profile_r03.sh -> tools/pmc_mfma_util.py), per launch over every GEMM kernel, FETCH_SIZE x2 + WRITE_SIZE
+        traffic, traffic_src, traffic_by_kernel = None, None, None
+        for name in ("r03_mfma_util.json", "r02_mfma_util.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    pm = json.load(f)
+                traffic = round(pm["gemm_kernels"]["gemm_hbm_bytes_per_launch"]); traffic_src = name
+                traffic_by_kernel = pm.get("per_kernel_traffic")
+                break
+            except Exception:
+                continue
+        kernels = {kn: {"launches": v[0], "us_per_launch": round(v[1] * 1e3 / v[0], 1), "ms_per_step": round(v[1], 3),
+                        "useful_tflops": round(v[3] / (v[1] * 1e-3) / 1e12, 1), "algorithmic_mb_per_launch": round(v[2] / v[0] / 1e6, 1)}
+                   for kn, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][1])}
+        dom = max(by_kernel.items(), key=lambda kv: kv[1][1])[0] if by_kernel else None
         scheme = {"f16w2x": "f16w2x = f16 MFMA operands; split (hi, lo) weights (2 products per weight) on every ViT GEMM (patch embedding, qkv, out-proj, fc1, fc2); text tower, "
                             "ViT projection tail and the outfit transformer in three-product arithmetic",
                   "f16w2": "f16w2 = f16 MFMA operands; split (hi, lo) weights (2 products per weight) on the ViT patch-embedding / out-proj / fc2 GEMMs; text tower, "
                            "ViT projection tail and the outfit transformer in three-product arithmetic",
                   "f16": "f16, one MFMA product per term", "bf16": "bf16, one MFMA product per term"}.get(a.tower_precision, a.tower_precision)
+        op = "bf16" if a.tower_precision.startswith("bf16") else "f16"
         res = {
-            "metric": "outfits/sec CP forward (8-item sets, 224^2, bf16)",
+            "metric": "outfits/sec CP forward (8-item sets, 224^2, bf16)",      # BASELINE.json's metric name, verbatim; the arithmetic type is `dtype`
             "value": round(world * B * a.steps / elapsed, 2),
             "unit": "outfits/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if a.tower_precision.startswith("bf16") else "f16",
+            "dtype": op,
             "data": "synthetic (seeded uniform-uint8 images after CLIP normalise, 8-token ids, random-init weights of the reference architecture)",
             "config": {"workload": "BASELINE configs[1]: CP forward with CLIP ViT-B/32 image+text encode, 256 outfits x 8 items per GPU, 224^2",
                        "outfits_per_gpu": B, "items": n, "parallelism": f"dp{world} (batch sharded, no data-path collective)",
                        "tower_precision": scheme,
-                       "outfit_precision": (model._tower_fed() or a.precision) + (" (set transformer fed by the in-call bf16 towers)" if model._tower_fed() else ""),
-                       "parity_bound": "north star: <= 1e-3 max|d| / max|ref| on the CP logit vs the fp32 reference path; held by the default scheme (tests/test_gpu_model.py::test_cfg2_end_to_end_within_1e3_on_every_weight_seed)"},
+                       "outfit_precision": (model._tower_fed() or a.precision) + (f" (set transformer fed by the in-call {op} towers)" if model._tower_fed() else ""),
+                       "parity_bound": "north star: <= 1e-3 max|d| / max|ref| over the batch on the CP logit vs the fp32 reference path; measured on THIS batch below "
+                                       "(parity_rel_err_vs_reference, all logits) and at this batch size on weight seeds 7/44/89/97/99 by "
+                                       "tests/test_gpu_model.py::test_cfg2_bench_batch_within_1e3_of_the_reference; sweep over 100 weight seeds: profiles/r03_seed_sweep_bench_scale.json"},
             "roofline": {"bound": "mfma", "kernel": "every dense contraction of the step: " + " / ".join(sorted({t_["kernel"] for t_ in table})),
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                         "traffic_note": f"bytes/launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/{traffic_src} (separate rocprofv3 --pmc passes of this command, tools/profile_r02.sh)" if traffic else "no PMC pass committed for this build yet",
+                         "traffic_note": (f"bytes per GEMM launch, FETCH_SIZE x2 + WRITE_SIZE, read from the committed profiles/{traffic_src} (separate rocprofv3 --pmc passes of this "
+                                          "command, tools/profile_r03.sh) - a reference to that file, not a measurement of this run") if traffic else "no PMC pass committed for this build yet",
                          "algorithmic_bytes_per_launch": round(alg_per_launch),
                          "traffic_over_algorithmic": round(traffic / alg_per_launch, 3) if traffic else None,
-                         "note": "achieved = ALGORITHMIC (useful, pad-free, one product per term) GEMM FLOPs of the step / summed GEMM launch time of one sampled step; "
-                                 "executed_tflops counts the extra MFMA products the 1e-3-compliant scheme spends (split weights x2, three-product x3)",
+                         "note": "achieved = useful (pad-free, one product per term) FLOPs of the GEMM shapes actually LAUNCHED / summed GEMM launch time of one sampled step "
+                                 "(HIP events on the launches); achieved_fixed_count uses SURVEY 8(d)'s per-outfit count instead (the pruned last ViT layer launches fewer rows "
+                                 "than that count assumes: no pruning credit is taken in `achieved`); executed_tflops counts the extra MFMA products the 1e-3-compliant scheme "
+                                 "spends (split weights x2, three-product x3)",
+                         "achieved_fixed_count": round(achieved_fixed, 2), "frac_fixed_count": round(achieved_fixed / PEAK_BF16_TFLOPS, 4),
                          "executed_tflops": round(executed, 2), "executed_frac": round(executed / PEAK_BF16_TFLOPS, 4),
                          "launches_per_step": gemm_launches, "sampled_steps": 1,
                          "avg_launch_us": round(gemm_ms * 1e3 / max(gemm_launches, 1), 2),
                          "algorithmic_gflop_per_outfit": round(alg_gemm_outfit / 1e9, 3),
+                         "launched_gflop_per_outfit": round(launched_flop / B / 1e9, 3),
+                         "dominant_kernel": dom, "per_kernel": kernels, "per_kernel_traffic_pmc": traffic_by_kernel,
                          "per_shape": table},
             "step_breakdown_ms": {"gemm": round(bms[0], 3), "norm_embed": round(bms[1], 3), "attention": round(bms[2], 3),
                                   "other": round(bms[3], 3), "note": "one extra untimed step with all launches bracketed"},
@@ -337,15 +364,24 @@ def main():
                 "tflops_equiv_per_gpu": round(padded_outfit * B * a.steps / elapsed / 1e12, 2),
                 "frac_of_peak": round(padded_outfit * B * a.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS, 4)},
         }
-        if a.cpu_outfits > 0 and world == 1:      # oracle check + CPU baseline: single-GPU-run data (rank 0, N = 1 only), outside the timed region
+        if a.cpu_outfits > 0 and world == 1:      # parity + CPU baseline: single-GPU-run data (rank 0, N = 1 only), outside the timed region
             try:
+                got_all = out.float().cpu().numpy().reshape(-1)
+                ref_all = bench_reference_logits(W_SEED, B, n, in_crc)
+                if ref_all is not None:         # ALL logits of the batch against the reference's own fp32 CPU output (committed fixture)
+                    res["parity_rel_err_vs_reference"] = float(np.abs(got_all - ref_all).max() / np.abs(ref_all).max())
+                    res["parity_abs_err_vs_reference"] = float(np.abs(got_all - ref_all).max())
+                    res["parity_note"] = (f"max|d| / max|ref| over ALL {B} CP logits of the timed batch vs the reference itself (src.models.OutfitX on the CPU in fp32, "
+                                          f"tests/golden/cfg2_bench_logits.npz from oracle/gen_bench_golden.py; input checksums verified), weight seed {W_SEED}")
                 k = min(a.cpu_outfits, B)
-                _log(f"timed region done: {elapsed / a.steps * 1e3:.2f} ms/step; oracle check on {k} outfits")
+                _log(f"timed region done: {elapsed / a.steps * 1e3:.2f} ms/step; live oracle check on {k} outfits")
                 torch.set_num_threads(min(host_cores(), 32))
                 ref = oracle_logits(px[:k].cpu().numpy(), texts["input_ids"][:k].numpy(), texts["attention_mask"][:k].numpy(), mask[:k].cpu().numpy(), k)
                 got = out[:k].float().cpu().numpy()
                 res["parity_rel_err_vs_oracle"] = float(np.abs(got - ref).max() / np.abs(ref).max())
-                res["parity_note"] = f"max|d| / max|ref| of the first {k} outfits' CP logits vs the fp32 numpy oracle (oracle/np_oracle.py), weight seed {W_SEED}"
+                res["parity_oracle_note"] = f"the first {k} outfits recomputed live on this box by the fp32 numpy oracle (oracle/np_oracle.py): max|d| / max|ref| over those {k}"
+                if ref_all is not None:
+                    res["oracle_vs_reference_fixture"] = float(np.abs(ref.reshape(-1) - ref_all[:k]).max() / np.abs(ref_all[:k]).max())
                 res["cpu_baseline"] = cpu_baseline(px, texts["input_ids"], texts["attention_mask"], n, min(a.cpu_cfg2_outfits, B))
                 if a.secondary and a.secondary != a.tower_precision:
                     # secondary, NON-compliant mode for context (never `value`): single-product towers, same batch, 5 steps after 2 warm-up
@@ -359,10 +395,12 @@ def main():
                         o2 = step()
                     fence()
                     dt2 = (time.perf_counter() - t1) / 5
-                    g2 = o2[:k].float().cpu().numpy()
+                    g2 = o2.float().cpu().numpy().reshape(-1)
+                    r2 = ref_all if ref_all is not None else ref.reshape(-1)
+                    g2 = g2[:len(r2)]
                     res["secondary_single_product"] = {"tower_precision": a.secondary + ", one MFMA product per term (the round-1 headline mode)",
                                                        "outfits_per_s": round(B / dt2, 1), "ms_per_step": round(dt2 * 1e3, 3),
-                                                       "parity_rel_err_vs_oracle": float(np.abs(g2 - ref).max() / np.abs(ref).max()),
+                                                       "parity_rel_err": float(np.abs(g2 - r2).max() / np.abs(r2).max()),
                                                        "note": "faster but outside the 1e-3 bound: reported for context only"}
                     model.item_encoder.set_precision(a.tower_precision)
             except Exception as exc:      # the throughput line must survive a failure of the (host-side) checker / baseline legs

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define OFX_ABI_VERSION 3
+#define OFX_ABI_VERSION 4
 
 enum { OFX_OK = 0, OFX_EINVAL = -1, OFX_ESHAPE = -2, OFX_EHIP = -3, OFX_EWORKSPACE = -4, OFX_ESTATE = -5 };
 enum ofx_dtype { OFX_F32 = 0, OFX_BF16 = 1, OFX_F16 = 2 };
@@ -233,8 +233,10 @@ int ofx_profile_read(double* ms, double* flops, long long* launches);
 /* Per-launch records of the last recording, in launch order (call BEFORE ofx_profile_read, which clears them).  GEMM records carry
  * their shape and kernel: M, N, K (logical depth), kmul (executed K = kmul x K: 2 split weights [hi | lo], 3 three-product
  * K-concatenation) and kind (1 128x128 tile kernel incl. its split-K / 64-row variants, 2 256x256, 3 256x128, 4 256x256 ping-pong,
- * 6 dual-weight 256x256); flops = executed FLOPs.  Returns the count. */
-typedef struct ofx_prof_record { int cat, M, N, K, kind, kmul; float ms; double flops; } ofx_prof_record;
+ * 6 dual-weight 256x256, 7 fused QKV projection + attention); flops = executed FLOPs; bytes = ALGORITHMIC HBM bytes of the launch (every operand
+ * read once - A [M, K], the weight rows as stored - and every output / in-place stream element read and written once, as the
+ * launch's epilogue is configured).  Returns the count. */
+typedef struct ofx_prof_record { int cat, M, N, K, kind, kmul; float ms; double flops; double bytes; } ofx_prof_record;
 int ofx_profile_records(ofx_prof_record* out, int cap);
 
 /* Process-wide tuning knobs (benchmarks / tests only).  knob 0: GEMM rasterisation group (row panels per L2 group, default 8);

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OFX_LIB") or os.path.join(_HERE, "libofx_hip.so")
 
 OFX_OK = 0
+ABI_VERSION = 4          # include/ofx.h OFX_ABI_VERSION
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU, ACT_MISH = 0, 1, 2, 3
 PREC_BF16, PREC_F16, PREC_BF16X3 = 0, 1, 2
@@ -53,7 +54,7 @@ class ModelDesc(C.Structure):
 
 
 class ProfRecord(C.Structure):
-    _fields_ = [("cat", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("kind", C.c_int), ("kmul", C.c_int), ("ms", C.c_float), ("flops", C.c_double)]
+    _fields_ = [("cat", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("kind", C.c_int), ("kmul", C.c_int), ("ms", C.c_float), ("flops", C.c_double), ("bytes", C.c_double)]
 
 
 _vp, _i, _f, _sz, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
@@ -132,7 +133,7 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)        # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.ofx_abi_version() != 3:
+    if lib.ofx_abi_version() != ABI_VERSION:
         raise OfxError("libofx_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -25,9 +25,10 @@ extern "C" int ofx_abi_version(void) { return OFX_ABI_VERSION; }
 bool g_ofx_prof_on = false;
 int g_ofx_prof_mask = 0xf;
 namespace {
-struct ProfRec { hipEvent_t a, b; int cat; double flops; int tag[5]; };      // tag: {M, N, logical K, kernel kind, K multiplier} of a GEMM launch
+struct ProfRec { hipEvent_t a, b; int cat; double flops; int tag[5]; double bytes; };      // tag: {M, N, logical K, kernel kind, K multiplier} of a GEMM launch; bytes: its algorithmic HBM bytes
 std::vector<ProfRec> g_prof;
 int g_prof_next_tag[5] = {0, 0, 0, 0, 0};
+double g_prof_next_bytes = 0.0;
 size_t g_prof_used = 0;
 bool g_prof_over = false;
 }
@@ -40,9 +41,10 @@ void ofx_prof_begin(int cat, hipStream_t s, double flops) {
     ProfRec& r = g_prof[g_prof_used];
     r.cat = cat; r.flops = flops;
     for (int i = 0; i < 5; ++i) { r.tag[i] = g_prof_next_tag[i]; g_prof_next_tag[i] = 0; }
+    r.bytes = g_prof_next_bytes; g_prof_next_bytes = 0.0;
     (void)hipEventRecord(r.a, s);
 }
-void ofx_prof_set_tag(int M, int N, int K, int kind, int kmul) { g_prof_next_tag[0] = M; g_prof_next_tag[1] = N; g_prof_next_tag[2] = K; g_prof_next_tag[3] = kind; g_prof_next_tag[4] = kmul; }
+void ofx_prof_set_tag(int M, int N, int K, int kind, int kmul, double bytes) { g_prof_next_tag[0] = M; g_prof_next_tag[1] = N; g_prof_next_tag[2] = K; g_prof_next_tag[3] = kind; g_prof_next_tag[4] = kmul; g_prof_next_bytes = bytes; }
 void ofx_prof_end(hipStream_t s) {
     if (!g_prof_over && g_prof_used < g_prof.size()) { (void)hipEventRecord(g_prof[g_prof_used].b, s); ++g_prof_used; }
 }
@@ -52,6 +54,7 @@ bool ofx_prof_ext_begin(int cat, double flops) {
     ProfRec& r = g_prof[g_prof_used];
     r.cat = cat; r.flops = flops;
     for (int i = 0; i < 5; ++i) { r.tag[i] = g_prof_next_tag[i]; g_prof_next_tag[i] = 0; }
+    r.bytes = g_prof_next_bytes; g_prof_next_bytes = 0.0;
     g_ofx_launch_e0 = r.a; g_ofx_launch_e1 = r.b;
     return true;
 }
@@ -64,7 +67,7 @@ void ofx_prof_ext_end() {
 extern "C" void ofx_profile_enable(int on) {
     // create the event pool up front (never inside a timed region): room for 4096 bracketed launches
     while (on && g_prof.size() < 4096) {
-        ProfRec r; r.cat = 0; r.flops = 0; r.tag[0] = r.tag[1] = r.tag[2] = r.tag[3] = r.tag[4] = 0;
+        ProfRec r; r.cat = 0; r.flops = 0; r.bytes = 0; r.tag[0] = r.tag[1] = r.tag[2] = r.tag[3] = r.tag[4] = 0;
         if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) break;
         g_prof.push_back(r);
     }
@@ -80,7 +83,7 @@ extern "C" int ofx_profile_records(ofx_prof_record* out, int cap) {
         OFX_HIP(hipEventSynchronize(r.b));
         float t = 0;
         OFX_HIP(hipEventElapsedTime(&t, r.a, r.b));
-        out[n].cat = r.cat; out[n].M = r.tag[0]; out[n].N = r.tag[1]; out[n].K = r.tag[2]; out[n].kind = r.tag[3]; out[n].kmul = r.tag[4]; out[n].ms = t; out[n].flops = r.flops;
+        out[n].cat = r.cat; out[n].M = r.tag[0]; out[n].N = r.tag[1]; out[n].K = r.tag[2]; out[n].kind = r.tag[3]; out[n].kmul = r.tag[4]; out[n].ms = t; out[n].flops = r.flops; out[n].bytes = r.bytes;
     }
     return n;
 }

@@ -422,7 +422,8 @@ int ofx_launch_fused_qkv_attn(const void* X, const void* Wqkv, const float* bias
         OFX_HIP(hipFuncSetAttribute((const void*)fused_qkv_attn_kernel<f16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FQ2_LDS));
         return OFX_OK;
     }));
-    if (g_ofx_prof_on) ofx_prof_set_tag(n_img * S, 3 * Wm, Wm, 7, w2 ? 2 : 1);
+    // algorithmic bytes: X read once, the (split) weight rows once, the attention output [rows, Wm] written once in the operand type
+    if (g_ofx_prof_on) ofx_prof_set_tag(n_img * S, 3 * Wm, Wm, 7, w2 ? 2 : 1, 2.0 * n_img * S * Wm + 2.0 * (w2 ? 2 : 1) * 3.0 * Wm * Wm + 2.0 * n_img * S * Wm);
     ProfScope prof(PROF_GEMM, s, (w2 ? 2.0 : 1.0) * 2.0 * n_img * S * 3.0 * Wm * Wm + 4.0 * n_img * S * S * Wm, true);
     if (w2) {
         if (op_dtype == OFX_F16) OFX_PLAUNCH(true, (fused_qkv_attn_kernel<f16_t, true>), dim3(k.nwg), dim3(512), FQ2_LDS, s, k);

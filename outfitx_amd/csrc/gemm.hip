@@ -269,7 +269,18 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
     if (kind == 5 && g.N % 128) kind = 1;
     // record label: logical shape (K without the split-weight / three-product concatenation), the K multiplier and
     // kernel kind (1 128x128 [+ split-K / 64-row variants], 2 256x256, 3 256x128, 4 256x256 ping-pong, 6 dual-weight 256x256)
-    if (g_ofx_prof_on) { const int km = g.a_wrap ? g.K / g.a_wrap : (g.k_mult > 0 ? g.k_mult : 1); ofx_prof_set_tag(g.M, g.N, g.K / km, kind, km); }
+    if (g_ofx_prof_on) {
+        const int km = g.a_wrap ? g.K / g.a_wrap : (g.k_mult > 0 ? g.k_mult : 1);
+        // algorithmic HBM bytes of this launch: A once (its k index wraps over a_wrap columns for split weights), the weight rows as
+        // stored, and per output element what the configured epilogue moves: fp32 4 (+4 residual read, +2 operand copy), operand
+        // type 2 (in-place (hi, lo) stream: 4 read + 4 written), [hi | lo | hi] 6, +4 pre-activation tape copy
+        const double ab = 2.0 * g.M * (g.a_wrap ? g.a_wrap : g.K), wb = 2.0 * g.N * g.K;
+        double ob = g.out_kind == 0 ? 4.0 : (g.out_kind == 2 ? 6.0 : 2.0);
+        if (g.xlo) ob = 8.0;
+        else { if (g.resid) ob += 4.0; if (g.xb_out) ob += 2.0; }
+        if (g.aux_out) ob += 4.0;
+        ofx_prof_set_tag(g.M, g.N, g.K / km, kind, km, ab + wb + ob * g.M * g.N);
+    }
     ProfScope prof(PROF_GEMM, s, 2.0 * g.M * g.N * g.K, true);      // events ride on the launches (OFX_PLAUNCH)
     if (kind == 2 || kind == 3 || kind == 4 || kind == 6) {
         k.group_m = g_gemm_group_m > 0 ? g_gemm_group_m : (kind == 3 ? 4 : 8);

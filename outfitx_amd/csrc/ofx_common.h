@@ -129,7 +129,7 @@ extern bool g_ofx_prof_on;
 extern int g_ofx_prof_mask;   // bit per category
 void ofx_prof_begin(int cat, hipStream_t s, double flops);
 void ofx_prof_end(hipStream_t s);
-void ofx_prof_set_tag(int M, int N, int K, int kind, int kmul);      // labels the NEXT record (GEMM dispatcher: shape and kernel kind)
+void ofx_prof_set_tag(int M, int N, int K, int kind, int kmul, double bytes);      // labels the NEXT record (GEMM dispatcher: shape, kernel kind, algorithmic HBM bytes)
 // ext = true: nothing is recorded on the stream; the scope's launches carry the two events themselves (OFX_PLAUNCH ->
 // hipExtLaunchKernelGGL start / stop events: the timestamps come from the dispatch packet's completion signal, so no marker
 // packets are put between the kernels).  The first launch of the scope takes the start event, the one flagged `last` the stop.

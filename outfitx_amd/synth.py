@@ -229,5 +229,14 @@ def token_batch(seed: int, N: int, T: int = 64, n_real=8, name: str = "tokens"):
     return ids, att
 
 
+def bench_batch(seed: int, B: int = 256, n_items: int = 8, T: int = 64, n_real: int = 8):
+    """bench.py's batch (BASELINE configs[1]), generated on the HOST so that the build container (where the reference can be
+    imported: oracle/gen_bench_golden.py) and the GPU box see the same inputs: pixel_values [B, n, 3, 224, 224] fp32 (uniform
+    uint8 after CLIP rescale + normalise), input_ids / attention_mask [B * n, T] (BOS + words + EOS, padded)."""
+    px = pixel_values(seed, B * n_items).reshape(B, n_items, 3, VIT_IMG, VIT_IMG)
+    ids, att = token_batch(seed, B * n_items, T, n_real)
+    return px, ids, att
+
+
 def checksum(a: np.ndarray) -> str:
     return f"{zlib.crc32(np.ascontiguousarray(a).tobytes()):08x}"

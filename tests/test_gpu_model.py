@@ -695,3 +695,47 @@ def test_cfg2_end_to_end_three_product_towers(wseed):
     seeds 4 and 6 measure 1.3e-4 / 1.8e-4 - the slower mode (60.5 vs 37.5 ms per cfg2 step) for callers who want a 5x margin on any
     weight draw."""
     _cfg2_end_to_end(wseed, "f16x3", 4e-4)
+
+
+_BENCH_BATCH = {}
+
+
+def _bench_batch():
+    """bench.py's batch (256 outfits x 8 items, input seed 1236), generated once per session on the host and kept on the device."""
+    if not _BENCH_BATCH:
+        z = golden("cfg2_bench_logits")
+        B, n = int(z["outfits"]), int(z["items"])
+        px, ids, att = synth.bench_batch(int(z["in_seed"]), B, n)
+        assert synth.checksum(px[:2]) == str(z["px_crc"]) and synth.checksum(ids) == str(z["ids_crc"])
+        _BENCH_BATCH.update(z=z, B=B, n=n, px=torch.from_numpy(px).cuda(),
+                            texts={"input_ids": torch.from_numpy(ids).view(B, n, 64), "attention_mask": torch.from_numpy(att).view(B, n, 64)})
+    return _BENCH_BATCH
+
+
+@pytest.mark.parametrize("wseed", [7, 44, 89, 97, 99])
+def test_cfg2_bench_batch_within_1e3_of_the_reference(wseed):
+    """The configuration bench.py times - 256 outfits x 8 items, so every ViT GEMM runs through the persistent 256x256 kernels and
+    not the 128x128 split-K paths of the 8-outfit tests - in the default scheme, ALL 256 CP logits against the reference ITSELF
+    (src.models.OutfitX._cp_forward with encoder_input_dict, outfit_x.py:120-144, on the CPU in fp32: tests/golden/
+    cfg2_bench_logits.npz from oracle/gen_bench_golden.py).  Weight seeds: the bench's (7) and the four worst of the round-2
+    sweeps (44, 89, 97, 99: draws whose logits are all small).  Metric and bound: the north star's max|d| / max|ref| over the
+    batch <= 1e-3."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    from src.models import OutfitX
+    from src.models.configs import ItemEncoderConfig, OutfitXConfig
+    CP = tasks()[0]
+    bb = _bench_batch()
+    ref = bb["z"][f"w{wseed}"].astype(np.float32)
+    m = OutfitX(OutfitXConfig(item_encoder=ItemEncoderConfig(type="clip")))
+    assert m.item_encoder.image_enc.tower_precision == DEFAULT_TOWERS
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.full_state_dict(wseed).items()}, strict=True)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        got = m(task=CP, outfit_embedding=None, outfit_mask=torch.zeros(bb["B"], bb["n"], dtype=torch.bool, device="cuda"),
+                encoder_input_dict={"images": bb["px"], "texts": bb["texts"]}).float().cpu().numpy().reshape(-1)
+    e = rel_err(got, ref)
+    print(f"cfg2 bench batch ({DEFAULT_TOWERS}), weight seed {wseed}: {e:.2e} (abs {np.abs(got - ref).max():.2e}, max|ref| {np.abs(ref).max():.3f})")
+    assert e < 1e-3, e
+    del m
+    torch.cuda.empty_cache()

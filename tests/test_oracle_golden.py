@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from conftest import golden, rel_err
+from conftest import W_SEED, golden, rel_err
 from oracle import np_oracle as O
 from outfitx_amd import synth
 
@@ -151,3 +151,28 @@ def test_pil_bicubic_restatement_is_bit_exact():
     assert np.array_equal(O.pil_resize_bicubic(grey, 323, 224), np.asarray(Image.fromarray(grey).resize((323, 224), resample=Image.BICUBIC)))
     ims = [g.integers(0, 256, s, dtype=np.uint8) for s in [(300, 300, 3), (260, 400, 3), (500, 231, 3), (60, 45, 3), (224, 224, 3), (90, 130)]]
     assert np.array_equal(O.clip_preprocess(ims), host_preprocess(ims).numpy())
+
+
+def test_both_restatements_reproduce_the_bench_batch_fixture():
+    """tests/golden/cfg2_bench_logits.npz (the reference's own CP logits of bench.py's 256-outfit batch, oracle/gen_bench_golden.py):
+    the first two outfits recomputed by both restatements - the fixture is what the GPU parity test and bench.py's parity leg compare
+    ALL logits with, so it is itself held to the oracles here (the generators' streams are prefix-stable: the first 16 images /
+    token rows of the 2,048 are those of a 16-row draw)."""
+    import torch
+    from oracle import torch_ref as T
+    g = golden("cfg2_bench_logits")
+    k, n = 2, int(g["items"])
+    px = synth.pixel_values(int(g["in_seed"]), k * n).reshape(k, n, 3, 224, 224)
+    ids, att = synth.token_batch(int(g["in_seed"]), k * n, 64, 8)
+    assert synth.checksum(px) == str(g["px_crc"])
+    k = 1                                                        # one outfit (8 images, 8 texts of 64 tokens) keeps the CPU suite short
+    px, ids, att = px[:k], ids[:k * n], att[:k * n]
+    mask = np.zeros((k, n), bool)
+    ref = g[f"w{W_SEED}"][:k]
+    emb = O.item_encoder(px, ids.reshape(k, n, 64), att.reshape(k, n, 64), synth.vision_weights(W_SEED), synth.text_weights(W_SEED))
+    assert rel_err(O.cp_forward(emb, mask, synth.outfit_transformer_weights(W_SEED)).reshape(-1), ref) < 2e-5
+    with torch.no_grad():
+        tv, tt, ts = T.TorchRef(synth.vision_weights(W_SEED)), T.TorchRef(synth.text_weights(W_SEED)), T.TorchRef(synth.outfit_transformer_weights(W_SEED))
+        e = T.item_encoder(tv, tt, torch.from_numpy(px), torch.from_numpy(ids).view(k, n, 64), torch.from_numpy(att).view(k, n, 64))
+        got = ts.cp(e, torch.zeros(k, n, dtype=torch.bool)).numpy().reshape(-1)
+    assert rel_err(got, ref) < 2e-5
