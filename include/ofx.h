@@ -247,6 +247,8 @@ int ofx_profile_records(ofx_prof_record* out, int cap);
  *         QKV-projection + attention kernel; cleared: the GEMM -> HBM -> attention-kernel pair;
  * knob 10: 1 (default) small-batch outfit-transformer GEMMs (split-K plans) leave their second pass to the consumer kernel (set
  *          attention sums the q | k | v slabs; reduce + LayerNorm in one launch), 0 the separate reduce and LayerNorm launches;
+ * knob 12: 1 (default) split-weight GEMMs with an fp8 copy of their lo halves run the fp8 correction product, 0 = the f16 one;
+ * knob 13: log2 of the activation scale of that product (default 2).
  * knob 11: grid size of the persistent dual-weight GEMM (default -1 = one block per CU of the device, each walking its tiles and
  *          fetching the next tile's first k-steps under the current epilogue), 0 = one block per tile. */
 int ofx_tune(int knob, int value);
@@ -260,6 +262,14 @@ int ofx_gemm(const void* A, const void* W, void* C, const float* bias, const flo
  * copy of A - two MFMA products per weight, ~22 significant weight bits.  K multiple of 64. */
 int ofx_gemm_w2(const void* A, const void* W2, void* C, const float* bias, const float* resid, int M, int N, int K,
                 int lda, int ldc, int ldr, int act, int out_kind, int op_dtype, ofx_stream stream);
+/* The same with the correction product A . lo^T on the block-scaled fp8 matrix instruction (2x the f16 rate; f16 operands only):
+ * ofx_pack_lo8 turns the lo halves of W2 [N, 2K] into W8 [N, K] e4m3 bytes (per row scaled to max |lo| 2^sw in [128, 256), the
+ * 128-blocks k-permuted as the kernel's in-register fp8 activation image is) + scale8 [N] E8M0 bytes; N and K multiples of 128.
+ * ofx_gemm_w2f8 = A hi^T + fp8(A 2^shift) fp8(lo 2^sw)^T 2^-(shift + sw): the weight error drops from 2^-12 to ~2^-15 relative, the
+ * activation operand stays the one f16 copy.  Small problems (fewer than 256 tiles of 256 x 256) run ofx_gemm_w2's path on W2. */
+int ofx_pack_lo8(const void* W2, void* W8, void* scale8, int N, int K, ofx_stream stream);
+int ofx_gemm_w2f8(const void* A, const void* W2, const void* W8, const void* scale8, void* C, const float* bias, const float* resid, int M, int N, int K,
+                  int lda, int ldc, int ldr, int act, int out_kind, ofx_stream stream);
 /* Weight-gradient GEMM of the training step: C[M,N] fp32 = sum_k A[k, m] * B[k, n]; A [K, lda] and B [K, ldb] row-major
  * operand-type matrices whose ROW index is contracted (dW = dY^T X without transposed copies).  M, N multiples of 256.
  * k_dev: optional device-side live row count (<= K).  Both operands must be readable up to round_up(K, 64) rows.

@@ -105,6 +105,8 @@ SIGNATURES = {
     "ofx_debug_gemm_clock": (None, [_vp]),
     "ofx_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ofx_gemm_w2": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ofx_pack_lo8": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "ofx_gemm_w2f8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ofx_gemm_tn_ws": (_sz, [_i, _i, _i]),
     "ofx_gemm_tn": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp]),
     "ofx_gemm_splitk_ws": (_sz, [_i, _i, _i]),

@@ -33,6 +33,10 @@ struct KArgs {
     char* xb_out; float* stat_part; const float* row_stat; const float* col_sum; int stat_ld; char* xlo;   // LayerNorm folding (GemmArgs)
     int n_valid;                // columns >= n_valid are computed but not stored (fp32 outputs of the TN kernel; = N elsewhere)
     int ka_tiles;               // A's k-tile index wraps modulo ka_tiles (K-concatenated weights against ONE copy of A: GemmArgs::a_wrap); = K / BK otherwise
+    // fp8 weight-correction product (gemm_w2f8.hip): e4m3 copy of the weights' lo half, [N, K] bytes, k-permuted inside 128-blocks,
+    // and its per-row E8M0 scale bytes laid out 8 per (128-column block, lane & 15); a8_scale / a8_e8m0: activations are converted as
+    // fp8(a / a8_scale) in registers and enter the product with the scale byte a8_e8m0 (= 127 + log2 a8_scale)
+    const char* W8 = nullptr; const char* w8_scale = nullptr; float a8_scale = 0.25f; int a8_e8m0 = 125;
 };
 
 __device__ __forceinline__ void glds16(const char* g, OFX_LDS char* l) {
@@ -142,8 +146,10 @@ __device__ __forceinline__ float act_apply(float v) {
 // FOLD (LayerNorm folding, compile-time so the common path keeps its registers): 0 none, 1 producer (fp32 output + operand copy
 // + per-segment statistics), 2 consumer (row statistics + column sums applied to the accumulator), 3 producer whose residual
 // stream is the operand-type pair (xb_out = hi, xlo = lo = x - hi), read and rewritten in place - no fp32 copy of the stream.
-template <typename T, int ACT, int FOLD = 0, int RAMP = 0>
-__device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x4 (&acc)[8][4], int gm0, int gn0, int lane,
+// NP x 16 rows by 64 columns of the wave's accumulators: acc[i][J0 + j], i < NP passes, j < 4 column fragments (the 128x64 wave tile
+// is NP = 8, JW = 4, J0 = 0; a 64x128 wave tile drains as two halves NP = 4, JW = 8, J0 = 0 / 4).
+template <typename T, int ACT, int FOLD = 0, int RAMP = 0, int NP = 8, int JW = 4, int J0 = 0>
+__device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x4 (&acc)[NP][JW], int gm0, int gn0, int lane,
                                           OFX_LDS float* st = nullptr) {
     typedef typename OpT<T>::v8 v8;
     const int fr = lane & 15, fq = lane >> 4;
@@ -165,7 +171,7 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
         };
         // RAMP: the residual prefetch deepens as accumulator registers retire (16 per pass): passes fetched before pass i is
         // processed = min(8, 3 + 2 i), so by pass 3 every residual row of the tile is in flight; else a fixed DEPTH ahead
-        f32x4 resr[RAMP ? 8 : 1][4];
+        f32x4 resr[RAMP ? NP : 1][4];
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             if (RAMP) fetch(d, resr[RAMP ? d : 0]);
@@ -173,13 +179,13 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
         }
         if (RAMP) fetch(2, resr[RAMP ? 2 : 0]);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NP; ++i) {
             if (RAMP) {
-                if (i >= 1 && 2 * i + 1 < 8) fetch(2 * i + 1, resr[RAMP ? (2 * i + 1) % 8 : 0]);
-                if (i >= 1 && 2 * i + 2 < 8) fetch(2 * i + 2, resr[RAMP ? (2 * i + 2) % 8 : 0]);
-            } else if (i + DEPTH < 8) fetch(i + DEPTH, res[(i + DEPTH) % (DEPTH + 1)]);
+                if (i >= 1 && 2 * i + 1 < NP) fetch(2 * i + 1, resr[RAMP ? (2 * i + 1) % NP : 0]);
+                if (i >= 1 && 2 * i + 2 < NP) fetch(2 * i + 2, resr[RAMP ? (2 * i + 2) % NP : 0]);
+            } else if (i + DEPTH < NP) fetch(i + DEPTH, res[(i + DEPTH) % (DEPTH + 1)]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *(OFX_LDS f32x4*)(ep + fr * 256 + (((j * 4 + fq) ^ (fr & 7)) << 4)) = acc[i][j];
+            for (int j = 0; j < 4; ++j) *(OFX_LDS f32x4*)(ep + fr * 256 + (((j * 4 + fq) ^ (fr & 7)) << 4)) = acc[i][J0 + j];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int row = it * 4 + rsub;
@@ -251,10 +257,10 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
         };
         if (FOLD == 3) { fetch_hl(0, rh[0], rl[0]); fetch_hl(1, rh[FOLD == 3 ? 1 : 0], rl[FOLD == 3 ? 1 : 0]); }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (FOLD == 3 && i + 2 < 8) fetch_hl(i + 2, rh[FOLD == 3 ? (i + 2) % 3 : 0], rl[FOLD == 3 ? (i + 2) % 3 : 0]);
+        for (int i = 0; i < NP; ++i) {
+            if (FOLD == 3 && i + 2 < NP) fetch_hl(i + 2, rh[FOLD == 3 ? (i + 2) % 3 : 0], rl[FOLD == 3 ? (i + 2) % 3 : 0]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *(OFX_LDS f32x4*)(ep + fr * 256 + (((j * 4 + fq) ^ (fr & 7)) << 4)) = acc[i][j];
+            for (int j = 0; j < 4; ++j) *(OFX_LDS f32x4*)(ep + fr * 256 + (((j * 4 + fq) ^ (fr & 7)) << 4)) = acc[i][J0 + j];
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const int row = it * 8 + rsub;
@@ -316,30 +322,30 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
     }
 }
 
-template <typename T>
-__device__ __forceinline__ void epilogue2_dispatch(const KArgs& p, OFX_LDS char* ep, f32x4 (&acc)[8][4], int gm0, int gn0, int lane,
+template <typename T, int NP = 8, int JW = 4, int J0 = 0>
+__device__ __forceinline__ void epilogue2_dispatch(const KArgs& p, OFX_LDS char* ep, f32x4 (&acc)[NP][JW], int gm0, int gn0, int lane,
                                                    OFX_LDS float* st = nullptr) {
     if (p.row_stat) {                                  // LayerNorm-fold consumer: towers only (no residual, no dropout, no tape)
         switch (p.act) {
-            case OFX_ACT_QUICK_GELU: epilogue2<T, OFX_ACT_QUICK_GELU, 2>(p, ep, acc, gm0, gn0, lane, st); break;
-            case OFX_ACT_GELU: epilogue2<T, OFX_ACT_GELU, 2>(p, ep, acc, gm0, gn0, lane, st); break;
-            default: epilogue2<T, OFX_ACT_NONE, 2>(p, ep, acc, gm0, gn0, lane, st); break;
+            case OFX_ACT_QUICK_GELU: epilogue2<T, OFX_ACT_QUICK_GELU, 2, 0, NP, JW, J0>(p, ep, acc, gm0, gn0, lane, st); break;
+            case OFX_ACT_GELU: epilogue2<T, OFX_ACT_GELU, 2, 0, NP, JW, J0>(p, ep, acc, gm0, gn0, lane, st); break;
+            default: epilogue2<T, OFX_ACT_NONE, 2, 0, NP, JW, J0>(p, ep, acc, gm0, gn0, lane, st); break;
         }
         return;
     }
     if (p.xb_out || p.stat_part) {
-        if (p.xlo) epilogue2<T, OFX_ACT_NONE, 3, 1>(p, ep, acc, gm0, gn0, lane);
-        else epilogue2<T, OFX_ACT_NONE, 1, 1>(p, ep, acc, gm0, gn0, lane);
+        if (p.xlo) epilogue2<T, OFX_ACT_NONE, 3, 1, NP, JW, J0>(p, ep, acc, gm0, gn0, lane);
+        else epilogue2<T, OFX_ACT_NONE, 1, 1, NP, JW, J0>(p, ep, acc, gm0, gn0, lane);
         return;
     }
     switch (p.act) {
-        case OFX_ACT_QUICK_GELU: epilogue2<T, OFX_ACT_QUICK_GELU>(p, ep, acc, gm0, gn0, lane); break;
-        case OFX_ACT_GELU: epilogue2<T, OFX_ACT_GELU>(p, ep, acc, gm0, gn0, lane); break;
-        case OFX_ACT_MISH: epilogue2<T, OFX_ACT_MISH>(p, ep, acc, gm0, gn0, lane); break;
-        case OFX_ACT_MISH_GRAD: epilogue2<T, OFX_ACT_MISH_GRAD>(p, ep, acc, gm0, gn0, lane); break;
+        case OFX_ACT_QUICK_GELU: epilogue2<T, OFX_ACT_QUICK_GELU, 0, 0, NP, JW, J0>(p, ep, acc, gm0, gn0, lane); break;
+        case OFX_ACT_GELU: epilogue2<T, OFX_ACT_GELU, 0, 0, NP, JW, J0>(p, ep, acc, gm0, gn0, lane); break;
+        case OFX_ACT_MISH: epilogue2<T, OFX_ACT_MISH, 0, 0, NP, JW, J0>(p, ep, acc, gm0, gn0, lane); break;
+        case OFX_ACT_MISH_GRAD: epilogue2<T, OFX_ACT_MISH_GRAD, 0, 0, NP, JW, J0>(p, ep, acc, gm0, gn0, lane); break;
         default:      // fp32 residual outputs (out-proj / fc2): ramped residual prefetch, +1.2 % on those GEMMs (tools/gemm_bench.py)
-            if (p.resid && p.out_kind == 0) epilogue2<T, OFX_ACT_NONE, 0, 1>(p, ep, acc, gm0, gn0, lane);
-            else epilogue2<T, OFX_ACT_NONE>(p, ep, acc, gm0, gn0, lane);
+            if (p.resid && p.out_kind == 0) epilogue2<T, OFX_ACT_NONE, 0, 1, NP, JW, J0>(p, ep, acc, gm0, gn0, lane);
+            else epilogue2<T, OFX_ACT_NONE, 0, 0, NP, JW, J0>(p, ep, acc, gm0, gn0, lane);
             break;
     }
 }
@@ -397,3 +403,4 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(KArgs p) {
 int ofx_gemm_launch_big(void* kargs, int kind, int ablate, int op_dtype, int M, int N, hipStream_t s);
 int ofx_gemm_launch_pp(void* kargs, int op_dtype, int M, int N, hipStream_t s);
 int ofx_gemm_launch_w2(void* kargs, int op_dtype, int M, int N, hipStream_t s);
+int ofx_gemm_launch_w2f8(void* kargs, int M, int N, hipStream_t s);

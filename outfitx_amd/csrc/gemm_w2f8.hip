@@ -1,0 +1,382 @@
+// Split-weight 256x256 tile kernel with the weight-correction product on the block-scaled fp8 matrix instruction:
+//
+//     C = A . W_hi^T  (f16 x f16, v_mfma_f32_16x16x32_f16)  +  fp8(A) . fp8(W_lo)^T  (v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 x e4m3)
+//
+// W = W_hi + W_lo with W_hi = f16(W) as in gemm_w2.hip.  The correction term A . W_lo^T is 2^-11 of the product, so 4 significant
+// bits of each of its operands keep the result at ~2^-15 - below the activation rounding the scheme leaves anyway (DESIGN.md section 2,
+// tests/studies/fp8_correction_cpu.py) - and the fp8 instruction runs at twice the f16 rate: per 128-deep super-step and wave
+// 4 x 32 f16 MFMAs (16 cycles each) + 32 fp8 MFMAs (32 cycles each) = 3,072 matrix-pipe cycles against gemm_w2's 4,096.
+//
+// What makes it fit (tools/mx_probe.hip pins the instruction semantics used here):
+//   * the fp8 copy of the ACTIVATIONS never exists in memory: each wave converts the f16 A fragments it has just read for the f16
+//     product (v_cvt_scalef32_pk_fp8_f16, 2 elements per instruction, MODE.FP16_OVFL = 1 so that overflow saturates) and keeps them
+//     for the four k-steps of a super-step: fragment i's 8 VGPRs collect bytes 8 s + j <- k = 32 s + 8 g + j (s = k-step, g = lane
+//     >> 4) - a k-permutation inside the 128-block, harmless because the packed fp8 weights carry the same one (ofx_launch_pack_lo8);
+//   * the wave tile is 64 x 128 (8 waves as 4 x 2), so only 4 activation fragments = 32 VGPRs are held; the 8 weight fragments of the
+//     fp8 step stream through the registers the f16 fragments have just left (128 accumulators + 32 + 64 = 224);
+//   * per-row weight scales (E8M0, max |lo| 2^sw in [128, 256)) ride in as the instruction's per-lane scale operand, the activation
+//     scale (x4: values below 2^-8 would otherwise fall under the e4m3 subnormal step) as the other one.
+//
+// Structure: gemm_w2.hip's ping-pong (two wave groups one barrier slot apart, three 32 KiB stages [A | W_hi] at BK = 32, counted
+// vmcnt(5), persistent over tiles) plus two 32 KiB buffers for the fp8 weights of the current / next super-step (160 KiB in all).
+// Per k-step a wave issues 5 LDS-DMA pieces: 2 A, 2 W_hi and the quarter q = step & 3 of its 4 KiB of the super-step's fp8 rows.
+//   LDS image of the fp8 buffer: row n (256) x 128 B; 16-byte chunk c of row r at slot c ^ x(r & 15),
+//   x(c) = (((c >> 1) & 3) << 1) | (c >> 3): conflict-free for ds_read_b128's lane groups with 128-byte rows (each lane reads the two
+//   chunks 2 g, 2 g + 1 of row lane & 15).
+// Epilogue staging: the stage of the tile's last k-step (8 x 4 KiB); the LayerNorm-fold statistics slot of a wave sits in the part of
+// the NEXT super-step's fp8 buffer that only this wave's own later pieces (q = 2, 3) write.
+#include "gemm_common.h"
+
+extern int g_w2_persist;
+namespace {
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+template <int ABL = 0>      // ABL (make DIAG=1; wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads after step 0, 3 both, 4 no fp8 product
+__global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
+    typedef f16_t T;
+    typedef OpT<T>::v8 v8;
+    constexpr int TM = 256, TN = 256, BK2 = 32, PART = TM * BK2 * 2, STAGE = 2 * PART, NST = 3;      // 16 KiB per operand, 32 KiB per stage
+    constexpr int W8BUF = TN * 128, W8BASE = NST * STAGE;                                              // 2 x 32 KiB behind the stages
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    OFX_LDS char* lds = (OFX_LDS char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;           // 4 x 2 waves of 64 x 128; waves 0-3 (rows 0-127) are ping-pong group 0
+    const int grp = wave >> 2;
+    const int Kh = p.K >> 1;                           // logical K; 2 Kh is the row stride (elements) of W = [hi | lo]
+    p.K = Kh;
+    if (p.m_dev) {
+        const int m_live = *p.m_dev;
+        p.M = m_live < p.M ? m_live : p.M;
+    }
+    auto map_tile = [&](int vb, int& m0, int& n0) {
+        int bid = vb;
+        {
+            const int nx = 8, q = p.nwg / nx, r = p.nwg % nx, x = bid % nx, i = bid / nx;
+            bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+        }
+        const int per_group = p.group_m * p.tiles_n;
+        const int gidx = bid / per_group, first = gidx * p.group_m;
+        const int gm = min(p.group_m, p.tiles_m - first);
+        const int r = bid - gidx * per_group;
+        m0 = (first + r % gm) * TM;
+        n0 = (r / gm) * TN;
+    };
+    const int nk = Kh / BK2, nsup = nk >> 2;
+    const int dst0 = wave * 2 * 1024;
+    const float a_scale = p.a8_scale;
+    const int a_e8 = p.a8_e8m0;
+
+    int vb = blockIdx.x, m0, n0;
+    map_tile(vb, m0, n0);
+    if (m0 >= p.M) return;
+    int base = 0;                                       // (global index of the current tile's step 0) mod 3
+    int sbase = 0;                                      // (global index of the current tile's super-step 0) mod 2
+    bool first = true;
+    for (;;) {
+        const bool has_next = vb + (int)gridDim.x < p.nwg;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        // f16 pieces: 16 rows x 64 B; lane l -> row l >> 2, physical slot l & 3 <- logical chunk (l & 3) ^ f(row >> 2)
+        const int prow = ln >> 2, pchk = (ln & 3) ^ ((4 - (ln >> 4)) & 3);
+        unsigned w_off[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) w_off[i] = ((unsigned)((wave * 2 + i) * 16 + prow) * (2 * Kh) + pchk * 8) * 2;
+        auto a_offset = [&](int mt, int i) {
+            const int row = (wave * 2 + i) * 16 + prow;
+            const int rr = mt + row < p.M ? row : p.M - 1 - mt;
+            return ((unsigned)rr * p.lda + pchk * 8) * 2;
+        };
+        // fp8 piece q: 8 rows x 128 B, rows (wave * 4 + q) * 8 + (l >> 3); physical chunk l & 7 <- logical (l & 7) ^ x(row & 15),
+        // row & 15 = (q & 1) * 8 + (l >> 3)  =>  x = (((l >> 4) & 3) << 1) | (q & 1)
+        const unsigned w8_off = (unsigned)(wave * 32 + (ln >> 3)) * Kh + (((ln & 7) ^ (((ln >> 4) & 3) << 1)) << 4);
+        const int fr = ln & 15, fq = ln >> 4;
+        const int fchk = (fq ^ ((4 - (fr >> 2)) & 3)) * 16;
+        const int a_frag = (wr * 64 + fr) * 64 + fchk;
+        const int w_frag = PART + (wc * 128 + fr) * 64 + fchk;
+        // fp8 weight fragment j: row wc * 128 + j * 16 + fr, logical chunks 2 fq, 2 fq + 1
+        const int x8 = (((fr >> 1) & 3) << 1) | (fr >> 3);
+        const int w8_frag0 = (wc * 128 + fr) * 128 + (((2 * fq) ^ x8) << 4), w8_frag1 = (wc * 128 + fr) * 128 + (((2 * fq + 1) ^ x8) << 4);
+        const char* a_base = p.A + (size_t)m0 * p.lda * 2;
+        const char* w_base = p.W + (size_t)n0 * (2 * Kh) * 2;
+        const char* w8_base = p.W8 + (size_t)n0 * Kh;
+        unsigned a_off[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a_off[i] = a_offset(m0, i);
+        // per-row E8M0 scale bytes of this wave's 128 columns: 8 bytes per lane (fragment j -> byte j), one 8-byte load per tile
+        const unsigned long long sc8 = *(const unsigned long long*)(p.w8_scale + ((size_t)((n0 >> 7) + wc) * 16 + fr) * 8);
+        int sc_lo = (int)(unsigned)sc8, sc_hi = (int)(unsigned)(sc8 >> 32);
+
+        // one k-step's five pieces: A rows (2), W_hi rows (2), fp8 quarter q = step & 3 of super-step (step >> 2)
+#define OFX_F8_ISSUE(AK, A0, A1, WK, W8K, STG, W8B, Q)                                                                     \
+    {                                                                                                                      \
+        glds16((AK) + (A0), (STG) + dst0);                                                                                 \
+        glds16((AK) + (A1), (STG) + dst0 + 1024);                                                                          \
+        glds16((WK) + w_off[0], (STG) + PART + dst0);                                                                      \
+        glds16((WK) + w_off[1], (STG) + PART + dst0 + 1024);                                                               \
+        glds16((W8K) + ((w8_off + (unsigned)(Q) * 8u * (unsigned)Kh) ^ (((Q) & 1) << 4)), (W8B) + (wave * 4 + (Q)) * 1024); \
+    }
+        auto issue_cur = [&](int step) {                // a step of the current tile (step < nk)
+            OFX_LDS char* stg = lds + ((base + step) % NST) * STAGE;
+            OFX_LDS char* w8b = lds + W8BASE + ((sbase + (step >> 2)) & 1) * W8BUF;
+            const char* ak = a_base + (size_t)step * BK2 * 2;
+            const char* wk = w_base + (size_t)step * BK2 * 2;
+            const char* w8k = w8_base + (size_t)(step >> 2) * 128;
+            OFX_F8_ISSUE(ak, a_off[0], a_off[1], wk, w8k, stg, w8b, step & 3)
+        };
+        auto issue_next = [&](int j) {                  // step nk + j: the next tile's step j (j = 0, 1)
+            OFX_LDS char* stg = lds + ((base + nk + j) % NST) * STAGE;
+            OFX_LDS char* w8b = lds + W8BASE + ((sbase + nsup) & 1) * W8BUF;
+            if (has_next) {
+                int m1, n1;
+                map_tile(vb + (int)gridDim.x, m1, n1);
+                const char* ak = p.A + (size_t)m1 * p.lda * 2 + (size_t)j * BK2 * 2;
+                const char* wk = p.W + (size_t)n1 * (2 * Kh) * 2 + (size_t)j * BK2 * 2;
+                const char* w8k = p.W8 + (size_t)n1 * Kh;
+                const unsigned n0_ = a_offset(m1, 0), n1_ = a_offset(m1, 1);
+                OFX_F8_ISSUE(ak, n0_, n1_, wk, w8k, stg, w8b, j)
+            } else {                                    // the block's last tile: redundant fills (uniform counted waits; nobody reads them)
+                const char* ak = a_base + (size_t)(nk - 1) * BK2 * 2;
+                const char* wk = w_base + (size_t)(nk - 1) * BK2 * 2;
+                const char* w8k = w8_base + (size_t)(nsup - 1) * 128;
+                OFX_F8_ISSUE(ak, a_off[0], a_off[1], wk, w8k, stg, w8b, j)
+            }
+        };
+
+        f32x4 acc[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        v8 af[4], wh[8];
+        i32x8 a8[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a8[i] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+
+#define OFX_F8_READ(STEP)                                                                                     \
+    {                                                                                                         \
+        OFX_LDS char* base_ = lds + ((base + (STEP)) % NST) * STAGE;                                          \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) wh[j] = *(OFX_LDS v8*)(base_ + w_frag + j * 16 * 64);    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) af[i] = *(OFX_LDS v8*)(base_ + a_frag + i * 16 * 64);    \
+    }
+        // 32 f16 MFMAs + the conversion of the four A fragments into bytes 8 S .. 8 S + 7 of their fp8 images (S = step & 3, static)
+#define OFX_F8_CVT1(I, S)                                                                                      \
+    {                                                                                                         \
+        i16x2 lo_ = __builtin_bit_cast(i16x2, a8[I][2 * (S)]), hi_ = __builtin_bit_cast(i16x2, a8[I][2 * (S) + 1]); \
+        lo_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(lo_, f16x2{af[I][0], af[I][1]}, a_scale, false);       \
+        lo_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(lo_, f16x2{af[I][2], af[I][3]}, a_scale, true);        \
+        hi_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(hi_, f16x2{af[I][4], af[I][5]}, a_scale, false);       \
+        hi_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(hi_, f16x2{af[I][6], af[I][7]}, a_scale, true);        \
+        a8[I][2 * (S)] = __builtin_bit_cast(int, lo_); a8[I][2 * (S) + 1] = __builtin_bit_cast(int, hi_);      \
+    }
+#define OFX_F8_MFMA16(S)                                                                                      \
+    {                                                                                                         \
+        __builtin_amdgcn_s_setprio(1);                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[i][j] = OpT<T>::mfma16(wh[j], af[i], acc[i][j]); \
+            if (ABL != 4) OFX_F8_CVT1(i, S)                                                                   \
+        }                                                                                                     \
+        __builtin_amdgcn_s_setprio(0);                                                                        \
+    }
+        // the super-step's 32 fp8 MFMAs: weight fragment j (two 16-byte reads per lane) against the four activation images; the
+        // fragments go through a 3-deep register ring (24 VGPRs: two in flight beside the one being multiplied); the scale-byte
+        // selector of the instruction is an immediate, hence one expansion per fragment
+#define OFX_F8_LD(J)                                                                                           \
+    {                                                                                                         \
+        const i32x4 c0_ = *(OFX_LDS i32x4*)(b8_ + w8_frag0 + (J) * 16 * 128), c1_ = *(OFX_LDS i32x4*)(b8_ + w8_frag1 + (J) * 16 * 128); \
+        w8_[(J) % 3] = i32x8{c0_[0], c0_[1], c0_[2], c0_[3], c1_[0], c1_[1], c1_[2], c1_[3]};                 \
+    }
+#define OFX_F8_MF(J, SEL, SC)                                                                                 \
+    if ((J) + 2 < 8) OFX_F8_LD((J) + 2)                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
+        acc[i][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8_[(J) % 3], a8[i], acc[i][J], 0, 0, SEL, SC, 0, a_e8);
+#define OFX_F8_MFMA8(SUP)                                                                                      \
+    if (ABL != 4) {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);      /* the fp8 fragments take the registers the f16 fragments leave: no hoisting above */ \
+        OFX_LDS char* b8_ = lds + W8BASE + ((sbase + (SUP)) & 1) * W8BUF;                                      \
+        i32x8 w8_[3];                                                                                         \
+        OFX_F8_LD(0) OFX_F8_LD(1)                                                                             \
+        __builtin_amdgcn_s_setprio(1);                                                                        \
+        OFX_F8_MF(0, 0, sc_lo) OFX_F8_MF(1, 1, sc_lo) OFX_F8_MF(2, 2, sc_lo) OFX_F8_MF(3, 3, sc_lo)           \
+        OFX_F8_MF(4, 0, sc_hi) OFX_F8_MF(5, 1, sc_hi) OFX_F8_MF(6, 2, sc_hi) OFX_F8_MF(7, 3, sc_hi)           \
+        __builtin_amdgcn_s_setprio(0);                                                                        \
+    }
+
+        if (first) {
+            issue_cur(0); issue_cur(1);
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");        // step 0 landed (my pieces)
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // steps 0 and 1 (fetched under the previous epilogue) and that epilogue's stores
+        }
+        asm volatile("" : "+v"(sc_lo), "+v"(sc_hi));                  // the scale load is waited for HERE, not inside the counted-vmcnt loop
+        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");     // MODE.FP16_OVFL: f16 -> fp8 saturates at +-448 instead of NaN
+        __builtin_amdgcn_s_barrier();                               // ---- end of slot 0
+        // One iteration of group 0 (slots 2t+1, 2t+2) / group 1 (slots 2t+2, 2t+3), as in gemm_w2.hip; the fp8 product of a super-step
+        // runs at the end of the MFMA slot of its fourth k-step.
+#define OFX_F8_ITER_G0(T_, S_, ISSUE, TAIL)                                                                        \
+        {                                                                                                        \
+            if (ABL == 0 || ABL == 2 || ABL == 4) { ISSUE; }                                                     \
+            if (ABL == 0 || ABL == 1 || ABL == 4 || (T_) == 0) OFX_F8_READ(T_)                                   \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            __builtin_amdgcn_s_barrier();                                                                        \
+            OFX_F8_MFMA16(S_)                                                                                    \
+            TAIL                                                                                                 \
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    /* my pieces of step t+1 landed (step t+2 stays in flight) */ \
+            __builtin_amdgcn_s_barrier();                                                                        \
+        }
+#define OFX_F8_ITER_G1(T_, S_, ISSUE, TAIL)                                                                        \
+        {                                                                                                        \
+            if (ABL == 0 || ABL == 2 || ABL == 4) { ISSUE; }                                                     \
+            if (ABL == 0 || ABL == 1 || ABL == 4 || (T_) == 0) OFX_F8_READ(T_)                                   \
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    /* my pieces of step t+1 landed: group 0 reads them in slot 2t+3 */ \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            __builtin_amdgcn_s_barrier();                                                                        \
+            OFX_F8_MFMA16(S_)                                                                                    \
+            TAIL                                                                                                 \
+            __builtin_amdgcn_s_barrier();                                                                        \
+        }
+        if (grp == 0) {
+            for (int u = 0; u < nsup - 1; ++u) {
+                const int t = 4 * u;
+                OFX_F8_ITER_G0(t, 0, issue_cur(t + 2), )
+                OFX_F8_ITER_G0(t + 1, 1, issue_cur(t + 3), )
+                OFX_F8_ITER_G0(t + 2, 2, issue_cur(t + 4), )
+                OFX_F8_ITER_G0(t + 3, 3, issue_cur(t + 5), OFX_F8_MFMA8(u))
+            }
+            {
+                const int t = nk - 4;
+                OFX_F8_ITER_G0(t, 0, issue_cur(t + 2), )
+                OFX_F8_ITER_G0(t + 1, 1, issue_cur(t + 3), )
+                OFX_F8_ITER_G0(t + 2, 2, issue_next(0), )
+                OFX_F8_ITER_G0(t + 3, 3, issue_next(1), OFX_F8_MFMA8(nsup - 1))
+            }
+            __builtin_amdgcn_s_barrier();                           // group 1's last MFMA slot begins: every stage read of this tile is done
+        } else {
+            __builtin_amdgcn_s_barrier();                           // slot 1: group 0 reads step 0
+            for (int u = 0; u < nsup - 1; ++u) {
+                const int t = 4 * u;
+                OFX_F8_ITER_G1(t, 0, issue_cur(t + 2), )
+                OFX_F8_ITER_G1(t + 1, 1, issue_cur(t + 3), )
+                OFX_F8_ITER_G1(t + 2, 2, issue_cur(t + 4), )
+                OFX_F8_ITER_G1(t + 3, 3, issue_cur(t + 5), OFX_F8_MFMA8(u))
+            }
+            {
+                const int t = nk - 4;
+                OFX_F8_ITER_G1(t, 0, issue_cur(t + 2), )
+                OFX_F8_ITER_G1(t + 1, 1, issue_cur(t + 3), )
+                OFX_F8_ITER_G1(t + 2, 2, issue_next(0), )
+                OFX_F8_ITER_G1(t + 3, 3, issue_next(1), OFX_F8_MFMA8(nsup - 1))
+            }
+        }
+#undef OFX_F8_ITER_G0
+#undef OFX_F8_ITER_G1
+#undef OFX_F8_READ
+#undef OFX_F8_MFMA16
+#undef OFX_F8_MFMA8
+#undef OFX_F8_MF
+#undef OFX_F8_LD
+#undef OFX_F8_CVT1
+#undef OFX_F8_ISSUE
+        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 0");     // the epilogue's f32 -> f16 casts keep the default overflow behaviour
+        // Epilogue staging: the stage of this tile's LAST k-step (every read of it is over, no fill targets it); statistics slot of the
+        // LayerNorm-fold consumers: this wave's own not-yet-issued quarters (q = 2, 3) of the next super-step's fp8 buffer.
+        OFX_LDS char* estage = lds + ((base + nk - 1) % NST) * STAGE;
+        OFX_LDS char* ep = estage + wave * EPI2_BYTES_PER_WAVE;
+        const int gm0 = m0 + wr * 64, gn0 = n0 + wc * 128;
+        OFX_LDS float* st = nullptr;
+        if (p.row_stat && p.out_kind != 0) st = (OFX_LDS float*)(lds + W8BASE + ((sbase + nsup) & 1) * W8BUF + (wave * 4 + 2) * 1024);
+        epilogue2_dispatch<T, 4, 8, 0>(p, ep, acc, gm0, gn0, ln, st);
+        epilogue2_dispatch<T, 4, 8, 4>(p, ep, acc, gm0, gn0 + 64, ln, st);
+        if (!has_next) break;
+        vb += gridDim.x; map_tile(vb, m0, n0); base = (base + nk) % NST; sbase = (sbase + nsup) & 1; first = false;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the last tile's redundant fills have landed before the wave ends
+}
+
+template <int ABL = 0>
+static int launch_w2f8(KArgs& k, int M, int N, hipStream_t s) {
+    constexpr int LDSB = 3 * 2 * 256 * 32 * 2 + 2 * 256 * 128;          // 96 KiB of stages + 64 KiB of fp8 weight buffers = 160 KiB
+    static DeviceOnce attr;
+    TRY(attr.run([]() -> int {
+        OFX_HIP(hipFuncSetAttribute((const void*)gemm_w2f8_kernel<ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+        return OFX_OK;
+    }));
+    k.tiles_n = N / 256; k.tiles_m = (M + 255) / 256; k.nwg = k.tiles_m * k.tiles_n;
+    int persist = g_w2_persist;
+    if (persist < 0) {
+        static int cus[64] = {0};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        int& c = cus[dev & 63];
+        if (c == 0) { int v = 0; c = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256; }
+        persist = c;
+    }
+    const int grid = (persist && !k.m_dev && k.nwg > persist) ? persist : k.nwg;
+    OFX_PLAUNCH(true, (gemm_w2f8_kernel<ABL>), dim3(grid), dim3(512), LDSB, s, k);
+    return OFX_OK;
+}
+
+// fp8 copy of the lo half of split-weight rows: src row n = [hi(K) | lo(K)] in f16 (row stride 2 K); dst row n = K bytes, e4m3 of
+// lo 2^sw(n) with max |lo| 2^sw in [128, 256), the 128-blocks k-permuted (byte 32 g + 8 s + j <- k = 32 s + 8 g + j); scale byte
+// 127 - sw(n) at scale[((n >> 7) * 16 + (n & 15)) * 8 + ((n >> 4) & 7)].  One wave per row.
+__global__ __launch_bounds__(256) void pack_lo8_kernel(const f16_t* src, unsigned char* dst, unsigned char* scale, int N, int K) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    const f16_t* lo = src + (size_t)n * 2 * K + K;
+    float mx = 0.f;
+    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, fabsf((float)lo[k]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    int sw = 0;
+    if (mx > 0.f) { int e; (void)frexpf(mx, &e); sw = 8 - e; }          // mx = m 2^e, m in [0.5, 1): mx 2^(8 - e) in [128, 256)
+    sw = sw > 127 ? 127 : (sw < -127 ? -127 : sw);
+    const float mul = ldexpf(1.0f, sw);
+    for (int p = lane; p < K; p += 64) {
+        const int blk = p >> 7, q = p & 127, g = q >> 5, s_ = (q >> 3) & 3, j = q & 7;
+        const float v = (float)lo[blk * 128 + 32 * s_ + 8 * g + j] * mul;
+        // e4m3 (OCP, round to nearest even) of |v| <= 256 by hand: exact for the values above, no dependence on library conversions
+        const float a = fabsf(v);
+        unsigned char b = 0;
+        if (a > 0.f) {
+            int e; const float m = frexpf(a, &e);                      // a = m 2^e, m in [0.5, 1)
+            int E = e - 1 + 7;                                          // biased exponent of 1.xxx 2^(e - 1)
+            if (E >= 1) {
+                int q3 = (int)rintf((m * 2.0f - 1.0f) * 8.0f);         // 3 mantissa bits, ties to even
+                if (q3 == 8) { q3 = 0; ++E; }
+                b = (unsigned char)((E << 3) | q3);
+            } else {
+                const int q3 = (int)rintf(a * 512.0f);                 // subnormal step 2^-9
+                b = (unsigned char)(q3 > 7 ? 8 : q3);                  // 8 = the smallest normal
+            }
+        }
+        dst[(size_t)n * K + p] = (unsigned char)(b | (v < 0.f ? 0x80 : 0));
+    }
+    if (lane == 0) scale[((size_t)(n >> 7) * 16 + (n & 15)) * 8 + ((n >> 4) & 7)] = (unsigned char)(127 - sw);
+}
+
+}  // namespace
+
+extern int g_gemm_ablate;
+int ofx_gemm_launch_w2f8(void* kargs, int M, int N, hipStream_t s) {
+    KArgs& k = *(KArgs*)kargs;
+#ifdef OFX_DIAG
+    if (g_gemm_ablate == 1) return launch_w2f8<1>(k, M, N, s);
+    if (g_gemm_ablate == 2) return launch_w2f8<2>(k, M, N, s);
+    if (g_gemm_ablate == 3) return launch_w2f8<3>(k, M, N, s);
+    if (g_gemm_ablate == 4) return launch_w2f8<4>(k, M, N, s);
+#endif
+    return launch_w2f8<0>(k, M, N, s);
+}
+
+int ofx_launch_pack_lo8(const void* w2_rows, void* dst8, void* scale8, int N, int K, hipStream_t s) {
+    OFX_REQUIRE(N % 128 == 0 && K % 128 == 0, OFX_ESHAPE, "pack_lo8: N and K must be multiples of 128");
+    hipLaunchKernelGGL(pack_lo8_kernel, dim3((N + 3) / 4), dim3(256), 0, s, (const f16_t*)w2_rows, (unsigned char*)dst8, (unsigned char*)scale8, N, K);
+    OFX_LAUNCH_CHECK();
+    return OFX_OK;
+}

@@ -242,6 +242,9 @@ struct GemmArgs {
     // ---- split weights against ONE copy of A ("W2"): W = [N, K] with K = 2 a_wrap, row n = [hi(a_wrap) | lo(a_wrap)]; A is
     // [M, a_wrap] and its k index wraps, so C = A . (hi + lo)^T: ~22 significant weight bits for two MFMA products
     int a_wrap = 0;
+    // fp8 correction product (gemm_w2f8.hip): with a_wrap, the e4m3 copy of the rows' lo halves [N, a_wrap] bytes and its per-row scale
+    // bytes (ofx_launch_pack_lo8); when the dual-weight 256x256 kernel would run, its fp8 variant runs instead (f16 only, a_wrap % 128 == 0)
+    const void* W8 = nullptr; const void* w8_scale = nullptr;
     int k_mult = 1;     // informational (profile records): K = k_mult x the logical depth (3: three-product K-concatenation; a_wrap implies 2)
     // ---- small batches (split-K plans): let the NEXT kernel do the second pass, one launch less per linear layer.
     // defer_splits: when the plan splits K, the reduce pass is skipped and *defer_splits = number of slabs (fp32 [splits, M, N] at
@@ -281,6 +284,8 @@ struct SplitKLnArgs {       // split-K second pass + LayerNorm in one launch (no
 };
 int ofx_launch_splitk_reduce_ln(const SplitKLnArgs& a, int op_dtype, hipStream_t s, bool in_gemm_scope = false);   // in_gemm_scope: the launch closes the GEMM dispatcher's profile record
 int ofx_launch_layernorm_dev(const LnArgs& a, const int* rows_dev, int op_dtype, hipStream_t s);
+// fp8 (e4m3) copy of the lo half of split-weight rows [hi | lo] (f16) + per-row E8M0 scale bytes, in gemm_w2f8.hip's layouts
+int ofx_launch_pack_lo8(const void* w2_rows, void* dst8, void* scale8, int N, int K, hipStream_t s);
 int ofx_launch_pack_rows(const float* src, void* dst, int rows_src, int rows_dst, int K_src, int K_dst, int ld_src,
                          int mode, int op_dtype, hipStream_t s);
 int ofx_launch_patchify(const float* px, void* out, int N, int img, int patch, int op_dtype, hipStream_t s);

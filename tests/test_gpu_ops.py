@@ -88,6 +88,88 @@ def test_gemm_split_weights(force, dt, M, N, K):
     assert rel_err(out.cpu().numpy(), want) < 2e-5
 
 
+def _e4m3_decode(b):
+    """uint8 ndarray (OCP e4m3fn bit patterns) -> float64 values."""
+    b = b.astype(np.int64)
+    s, e, m = b >> 7, (b >> 3) & 15, b & 7
+    v = np.where(e == 0, m * 2.0 ** -9, (1.0 + m / 8.0) * 2.0 ** (e - 7.0))
+    return np.where(s == 1, -v, v)
+
+
+def _pack_lo8(W2, N, K):
+    """ofx_pack_lo8 on the device; returns (W8 bytes tensor, scale bytes tensor, lo values as the kernel will see them [N, K] float64
+    in natural k order = e4m3(byte) 2^-sw, per-row sw)."""
+    W8 = torch.zeros(N, K, dtype=torch.uint8, device="cuda")
+    sc = torch.zeros(N, dtype=torch.uint8, device="cuda")
+    L.check(L.load().ofx_pack_lo8(W2.data_ptr(), W8.data_ptr(), sc.data_ptr(), N, K, stream()))
+    torch.cuda.synchronize()
+    b = W8.cpu().numpy().reshape(N, K // 128, 4, 4, 8)                 # [n][block][g][s][j] <- k = 32 s + 8 g + j
+    nat = _e4m3_decode(b).transpose(0, 1, 3, 2, 4).reshape(N, K)       # [n][block][s][g][j] -> natural k
+    scb = sc.cpu().numpy().reshape(N // 128, 16, 8)                    # [(n >> 7)][n & 15][(n >> 4) & 7]
+    n = np.arange(N)
+    sw = 127 - scb[n >> 7, n & 15, (n >> 4) & 7].astype(np.int64)
+    return W8, sc, nat * 2.0 ** (-sw[:, None].astype(np.float64)), sw
+
+
+@pytest.mark.parametrize("N,K", [(256, 128), (768, 3072), (3072, 768)])
+def test_pack_lo8_rounds_and_permutes_as_stated(N, K):
+    """fp8 copy of the lo halves: per-row power-of-two scale with max |lo| 2^sw in [128, 256), round-to-nearest-even e4m3, 128-blocks
+    k-permuted; against torch's float8_e4m3fn conversion of the same scaled values."""
+    g = np.random.default_rng(N + K)
+    Wf = (g.standard_normal((N, K), dtype=np.float32) / np.float32(np.sqrt(K))).astype(np.float32)
+    Wf[3] = 0.0                                                          # an all-zero row: lo = 0, scale byte 127
+    Wf[5, :7] *= 1e-3                                                    # tiny weights: f16 lo halves that are subnormal
+    W2, _ = _split_w(Wf, "f16")
+    _, _, lo_seen, sw = _pack_lo8(W2, N, K)
+    lo = W2[:, K:].float().cpu()
+    mx = lo.abs().max(1).values.numpy().astype(np.float64)
+    live = mx > 0
+    scaled = mx[live] * 2.0 ** sw[live]
+    assert (scaled >= 128).all() and (scaled < 256).all() and (sw[~live] == 0).all()
+    want = (lo.double() * torch.from_numpy(2.0 ** sw.astype(np.float64))[:, None]).float().to(torch.float8_e4m3fn).double().numpy() * 2.0 ** (-sw[:, None].astype(np.float64))
+    assert np.array_equal(lo_seen, want)
+    assert np.abs(lo_seen - lo.double().numpy()).max() <= 2.0 ** -4 * mx.max() * 1.01          # <= half an e4m3 step of the row's top binade
+
+
+@pytest.mark.parametrize("force", [0, 6])
+@pytest.mark.parametrize("M,N,K,sat", [(1, 256, 128, 0), (255, 256, 128, 1), (300, 512, 768, 0), (1000, 768, 3072, 1), (70000, 768, 256, 0), (66000, 1024, 384, 1)])
+def test_gemm_split_weights_fp8_correction(force, M, N, K, sat):
+    """C = A hi^T + fp8(4 A) fp8(lo 2^sw)^T 2^-(2 + sw) (gemm_w2f8_kernel: forced, and chosen by the dispatcher from 256 tiles on; the
+    small problems without force run the f16 lo product of the 128x128 path instead and are held to the exact product): exact arithmetic
+    on the quantised operands with fp32 accumulation; and against the float64 product with the unquantised lo halves the correction
+    leaves ~2^-15 of the weight scale."""
+    g = np.random.default_rng(M + 3 * N + K)
+    # activation columns from 1e-2 to 30 x N(0, 1); sat: also columns beyond the fp8 range (4 a saturates at 448: the correction of those
+    # columns is then partial by design - the exact-arithmetic check covers them, the accuracy check does not)
+    A = to_op(g.standard_normal((M, K), dtype=np.float32) * g.choice(np.float32([0.01, 1.0, 30.0, 200.0] if sat else [0.01, 1.0, 30.0]), size=(1, K)), "f16")
+    W2, Wv = _split_w((g.standard_normal((N, K), dtype=np.float32) / np.float32(np.sqrt(K))).astype(np.float32), "f16")
+    W8, sc, lo_seen, _ = _pack_lo8(W2, N, K)
+    bias = dev(g.standard_normal(N, dtype=np.float32))
+    res = dev(g.standard_normal((M, N), dtype=np.float32))
+    out = torch.full((M, N), float("nan"), device="cuda")
+    lib = L.load()
+    lib.ofx_tune(2, force)
+    try:
+        L.check(lib.ofx_gemm_w2f8(A.data_ptr(), W2.data_ptr(), W8.data_ptr(), sc.data_ptr(), out.data_ptr(), bias.data_ptr(), res.data_ptr(), M, N, K, K, N, N, 0, 0, stream()))
+        torch.cuda.synchronize()
+    finally:
+        lib.ofx_tune(2, 0)
+    Ad = A.double().cpu().numpy()
+    hi = W2[:, :K].double().cpu().numpy()
+    exact = Ad @ Wv.T + bias.cpu().numpy() + res.cpu().numpy()
+    fp8_path = force == 6 or ((M + 255) // 256) * (N // 256) >= 256
+    if fp8_path:
+        A8 = (A.float() * 4.0).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).double().cpu().numpy() / 4.0
+        want = Ad @ hi.T + A8 @ lo_seen.T + bias.cpu().numpy() + res.cpu().numpy()
+        assert rel_err(out.cpu().numpy(), want) < 2e-5
+        single = Ad @ hi.T + bias.cpu().numpy() + res.cpu().numpy()
+        e_corr, e_single = rel_err(out.cpu().numpy(), exact), rel_err(single, exact)
+        print(f"w2f8 {M}x{N}x{K}: vs exact split product {e_corr:.2e} (single product {e_single:.2e})")
+        assert sat or e_corr < 0.25 * e_single + 2e-5
+    else:
+        assert rel_err(out.cpu().numpy(), exact) < 2e-5
+
+
 @pytest.mark.parametrize("kern", [2, 3, 4, 5])
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("M,N,K", [(1, 256, 64), (255, 256, 128), (257, 512, 768), (1000, 768, 3072), (5000, 256, 192)])
