@@ -17,14 +17,22 @@
 //   * per-row weight scales (E8M0, max |lo| 2^sw in [128, 256)) ride in as the instruction's per-lane scale operand, the activation
 //     scale (x4: values below 2^-8 would otherwise fall under the e4m3 subnormal step) as the other one.
 //
-// Structure: gemm_w2.hip's ping-pong (two wave groups one barrier slot apart, three 32 KiB stages [A | W_hi] at BK = 32, counted
-// vmcnt(5), persistent over tiles) plus two 32 KiB buffers for the fp8 weights of the current / next super-step (160 KiB in all).
-// Per k-step a wave issues 5 LDS-DMA pieces: 2 A, 2 W_hi and the quarter q = step & 3 of its 4 KiB of the super-step's fp8 rows.
+// Structure: gemm_w2.hip's ping-pong (two wave groups one barrier slot apart, BK = 32, counted vmcnt, persistent over tiles) with FOUR
+// 32 KiB stages [A | W_hi] and ONE 32 KiB buffer for the current super-step's fp8 weights (160 KiB in all).  Every kernel of this
+// family runs at the rate the LDS-DMA fill sustains (~20 B/clk/CU: gemm_w2 with 48 KiB per k-step, this kernel's f16-only ablation
+// with 40 KiB and the single-product kernels with 32 KiB all take bytes / 20 B/clk), so what matters is that the fill never idles:
+// the MFMA slot that carries a super-step's fp8 product is three times as long as the others, and the read slot of the partner group
+// that runs beside it issues TWO k-steps of LDS-DMA (the fourth stage makes room: an iteration t may fill steps t + 2 and t + 3):
+//   group 0:  R0: steps t+2, t+3 (beside group 1's fp8 slot)   R1: the super-step's 4 fp8 quarters   R2: t+2   R3: t+2
+//   group 1:  R0: t+3   R1: the 4 fp8 quarters   R2: t+2   R3: t+2, t+3 (beside group 0's fp8 slot)
+// i.e. 8 KiB per wave beside a long slot and 4 KiB beside a short one.
+// The fp8 buffer is refilled after both groups' fp8 slots of the previous super-step and complete (waited for + a barrier) before
+// the next ones; the counted wait of an iteration leaves exactly the pieces that iteration issued in flight.
 //   LDS image of the fp8 buffer: row n (256) x 128 B; 16-byte chunk c of row r at slot c ^ x(r & 15),
 //   x(c) = (((c >> 1) & 3) << 1) | (c >> 3): conflict-free for ds_read_b128's lane groups with 128-byte rows (each lane reads the two
 //   chunks 2 g, 2 g + 1 of row lane & 15).
-// Epilogue staging: the stage of the tile's last k-step (8 x 4 KiB); the LayerNorm-fold statistics slot of a wave sits in the part of
-// the NEXT super-step's fp8 buffer that only this wave's own later pieces (q = 2, 3) write.
+// Epilogue staging: the stage of the tile's last k-step (8 x 4 KiB; the other three hold the next tile's first steps); the
+// LayerNorm-fold statistics slots sit in the fp8 buffer, which is idle between the tile's last fp8 slot and the next tile's refill.
 #include "gemm_common.h"
 
 extern int g_w2_persist;
@@ -35,12 +43,22 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef short i16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
+// LDS-DMA through a buffer resource: 16 bytes per lane from base + voff (per lane) + soff (uniform) to lds + 16 lane; against
+// global_load_lds this needs no 64-bit per-lane address (one VGPR offset that never changes + a scalar step offset)
+__device__ __forceinline__ void bload16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, OFX_LDS char* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (OFX_LDS void*)l, 16, (int)voff, (int)soff, 0, 0);
+}
+// (reads past `bytes` return zeros: the A resource of a tile ends with the matrix, so rows beyond M need no clamping)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const char* base, size_t bytes = 0x7fffffff) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(bytes < 0x7fffffff ? bytes : 0x7fffffff), 0x00020000);
+}
+
 template <int ABL = 0>      // ABL (make DIAG=1; wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads after step 0, 3 both, 4 no fp8 product
 __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
     typedef f16_t T;
     typedef OpT<T>::v8 v8;
-    constexpr int TM = 256, TN = 256, BK2 = 32, PART = TM * BK2 * 2, STAGE = 2 * PART, NST = 3;      // 16 KiB per operand, 32 KiB per stage
-    constexpr int W8BUF = TN * 128, W8BASE = NST * STAGE;                                              // 2 x 32 KiB behind the stages
+    constexpr int TM = 256, TN = 256, BK2 = 32, PART = TM * BK2 * 2, STAGE = 2 * PART, NST = 4;      // 16 KiB per operand, 32 KiB per stage
+    constexpr int W8BASE = NST * STAGE;                                                                 // 32 KiB behind the stages
     extern __shared__ __attribute__((aligned(16))) char smem[];
     OFX_LDS char* lds = (OFX_LDS char*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -74,8 +92,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
     int vb = blockIdx.x, m0, n0;
     map_tile(vb, m0, n0);
     if (m0 >= p.M) return;
-    int base = 0;                                       // (global index of the current tile's step 0) mod 3
-    int sbase = 0;                                      // (global index of the current tile's super-step 0) mod 2
+    int base = 0;                                       // (global index of the current tile's step 0) mod 4
     bool first = true;
     for (;;) {
         const bool has_next = vb + (int)gridDim.x < p.nwg;
@@ -86,11 +103,6 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
         unsigned w_off[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) w_off[i] = ((unsigned)((wave * 2 + i) * 16 + prow) * (2 * Kh) + pchk * 8) * 2;
-        auto a_offset = [&](int mt, int i) {
-            const int row = (wave * 2 + i) * 16 + prow;
-            const int rr = mt + row < p.M ? row : p.M - 1 - mt;
-            return ((unsigned)rr * p.lda + pchk * 8) * 2;
-        };
         // fp8 piece q: 8 rows x 128 B, rows (wave * 4 + q) * 8 + (l >> 3); physical chunk l & 7 <- logical (l & 7) ^ x(row & 15),
         // row & 15 = (q & 1) * 8 + (l >> 3)  =>  x = (((l >> 4) & 3) << 1) | (q & 1)
         const unsigned w8_off = (unsigned)(wave * 32 + (ln >> 3)) * Kh + (((ln & 7) ^ (((ln >> 4) & 3) << 1)) << 4);
@@ -104,47 +116,33 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
         const char* a_base = p.A + (size_t)m0 * p.lda * 2;
         const char* w_base = p.W + (size_t)n0 * (2 * Kh) * 2;
         const char* w8_base = p.W8 + (size_t)n0 * Kh;
-        unsigned a_off[2];
+        unsigned a_off[2];                                  // tile-independent too: rows past M read zeros through the sized resource
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a_off[i] = a_offset(m0, i);
+        for (int i = 0; i < 2; ++i) a_off[i] = ((unsigned)((wave * 2 + i) * 16 + prow) * p.lda + pchk * 8) * 2;
+        int m1 = m0, n1 = n0;                               // the next tile (the block's last tile re-fills its own first steps: nobody reads them)
+        if (has_next) map_tile(vb + (int)gridDim.x, m1, n1);
         // per-row E8M0 scale bytes of this wave's 128 columns: 8 bytes per lane (fragment j -> byte j), one 8-byte load per tile
         const unsigned long long sc8 = *(const unsigned long long*)(p.w8_scale + ((size_t)((n0 >> 7) + wc) * 16 + fr) * 8);
         int sc_lo = (int)(unsigned)sc8, sc_hi = (int)(unsigned)(sc8 >> 32);
 
-        // one k-step's five pieces: A rows (2), W_hi rows (2), fp8 quarter q = step & 3 of super-step (step >> 2)
-#define OFX_F8_ISSUE(AK, A0, A1, WK, W8K, STG, W8B, Q)                                                                     \
+        // LDS-DMA pieces: the two A and two W_hi pieces of a k-step (KOFF = its byte offset in the k-contiguous rows) and quarter Q of
+        // this wave's rows of super-step SUP's fp8 weights
+#define OFX_F8_ISSUE_AW(RA, RW, A0, A1, KOFF, STG)                                                                         \
     {                                                                                                                      \
-        glds16((AK) + (A0), (STG) + dst0);                                                                                 \
-        glds16((AK) + (A1), (STG) + dst0 + 1024);                                                                          \
-        glds16((WK) + w_off[0], (STG) + PART + dst0);                                                                      \
-        glds16((WK) + w_off[1], (STG) + PART + dst0 + 1024);                                                               \
-        glds16((W8K) + ((w8_off + (unsigned)(Q) * 8u * (unsigned)Kh) ^ (((Q) & 1) << 4)), (W8B) + (wave * 4 + (Q)) * 1024); \
+        bload16(RA, A0, KOFF, (STG) + dst0); bload16(RA, A1, KOFF, (STG) + dst0 + 1024);                                    \
+        bload16(RW, w_off[0], KOFF, (STG) + PART + dst0); bload16(RW, w_off[1], KOFF, (STG) + PART + dst0 + 1024);          \
     }
-        auto issue_cur = [&](int step) {                // a step of the current tile (step < nk)
-            OFX_LDS char* stg = lds + ((base + step) % NST) * STAGE;
-            OFX_LDS char* w8b = lds + W8BASE + ((sbase + (step >> 2)) & 1) * W8BUF;
-            const char* ak = a_base + (size_t)step * BK2 * 2;
-            const char* wk = w_base + (size_t)step * BK2 * 2;
-            const char* w8k = w8_base + (size_t)(step >> 2) * 128;
-            OFX_F8_ISSUE(ak, a_off[0], a_off[1], wk, w8k, stg, w8b, step & 3)
-        };
-        auto issue_next = [&](int j) {                  // step nk + j: the next tile's step j (j = 0, 1)
-            OFX_LDS char* stg = lds + ((base + nk + j) % NST) * STAGE;
-            OFX_LDS char* w8b = lds + W8BASE + ((sbase + nsup) & 1) * W8BUF;
-            if (has_next) {
-                int m1, n1;
-                map_tile(vb + (int)gridDim.x, m1, n1);
-                const char* ak = p.A + (size_t)m1 * p.lda * 2 + (size_t)j * BK2 * 2;
-                const char* wk = p.W + (size_t)n1 * (2 * Kh) * 2 + (size_t)j * BK2 * 2;
-                const char* w8k = p.W8 + (size_t)n1 * Kh;
-                const unsigned n0_ = a_offset(m1, 0), n1_ = a_offset(m1, 1);
-                OFX_F8_ISSUE(ak, n0_, n1_, wk, w8k, stg, w8b, j)
-            } else {                                    // the block's last tile: redundant fills (uniform counted waits; nobody reads them)
-                const char* ak = a_base + (size_t)(nk - 1) * BK2 * 2;
-                const char* wk = w_base + (size_t)(nk - 1) * BK2 * 2;
-                const char* w8k = w8_base + (size_t)(nsup - 1) * 128;
-                OFX_F8_ISSUE(ak, a_off[0], a_off[1], wk, w8k, stg, w8b, j)
-            }
+#define OFX_F8_ISSUE_W8(SUP, Q)                                                                                            \
+    bload16(r_w8, w8_off ^ (((Q) & 1) << 4), (unsigned)(SUP) * 128u + (unsigned)(Q) * 8u * (unsigned)Kh, lds + W8BASE + (wave * 4 + (Q)) * 1024);
+        const size_t a_row = (size_t)p.lda * 2;
+        const __amdgpu_buffer_rsrc_t r_a = make_rsrc(a_base, (size_t)(p.M - m0) * a_row), r_w = make_rsrc(w_base), r_w8 = make_rsrc(w8_base);
+        const __amdgpu_buffer_rsrc_t r_a1 = make_rsrc(p.A + (size_t)m1 * a_row, (size_t)(p.M - m1) * a_row), r_w1 = make_rsrc(p.W + (size_t)n1 * (2 * Kh) * 2);
+        // k-step x of the tile walk: a step of this tile, or (x >= nk) step x - nk of the next one - a scalar select of resource and offset
+        auto issue_step = [&](int x) {
+            OFX_LDS char* stg = lds + ((base + x) % NST) * STAGE;
+            const bool nx = x >= nk;
+            const __amdgpu_buffer_rsrc_t ra = nx ? r_a1 : r_a, rw = nx ? r_w1 : r_w;
+            OFX_F8_ISSUE_AW(ra, rw, a_off[0], a_off[1], (unsigned)(nx ? x - nk : x) * BK2 * 2, stg)
         };
 
         f32x4 acc[4][8];
@@ -194,10 +192,10 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
     if ((J) + 2 < 8) OFX_F8_LD((J) + 2)                                                                       \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
         acc[i][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8_[(J) % 3], a8[i], acc[i][J], 0, 0, SEL, SC, 0, a_e8);
-#define OFX_F8_MFMA8(SUP)                                                                                      \
+#define OFX_F8_MFMA8()                                                                                      \
     if (ABL != 4) {                                                                                           \
         __builtin_amdgcn_sched_barrier(0);      /* the fp8 fragments take the registers the f16 fragments leave: no hoisting above */ \
-        OFX_LDS char* b8_ = lds + W8BASE + ((sbase + (SUP)) & 1) * W8BUF;                                      \
+        OFX_LDS char* b8_ = lds + W8BASE;                                                                     \
         i32x8 w8_[3];                                                                                         \
         OFX_F8_LD(0) OFX_F8_LD(1)                                                                             \
         __builtin_amdgcn_s_setprio(1);                                                                        \
@@ -206,18 +204,21 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
         __builtin_amdgcn_s_setprio(0);                                                                        \
     }
 
-        if (first) {
-            issue_cur(0); issue_cur(1);
-            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");        // step 0 landed (my pieces)
+        if (first) {                                                // group 1 runs one step further ahead (see the schedule below)
+            issue_step(0); issue_step(1);
+            if (grp == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // step 0 landed (my pieces)
+            else { issue_step(2); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // steps 0 and 1 (fetched under the previous epilogue) and that epilogue's stores
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the steps fetched under the previous epilogue and that epilogue's stores
         }
         asm volatile("" : "+v"(sc_lo), "+v"(sc_hi));                  // the scale load is waited for HERE, not inside the counted-vmcnt loop
         asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");     // MODE.FP16_OVFL: f16 -> fp8 saturates at +-448 instead of NaN
         __builtin_amdgcn_s_barrier();                               // ---- end of slot 0
-        // One iteration of group 0 (slots 2t+1, 2t+2) / group 1 (slots 2t+2, 2t+3), as in gemm_w2.hip; the fp8 product of a super-step
-        // runs at the end of the MFMA slot of its fourth k-step.
-#define OFX_F8_ITER_G0(T_, S_, ISSUE, TAIL)                                                                        \
+        // One iteration of group 0 (slots 2t+1, 2t+2) / group 1 (slots 2t+2, 2t+3), as in gemm_w2.hip; NV = the LDS-DMA pieces the
+        // iteration issues: its counted wait leaves exactly those in flight (everything issued by earlier iterations has landed: an
+        // iteration t fills steps t + 2 / t + 3, read from iteration t + 2 on, and the fp8 quarters are read two iterations later at
+        // the earliest).  The fp8 product of a super-step runs at the end of the MFMA slot of its fourth k-step.
+#define OFX_F8_ITER_G0(T_, S_, NV, ISSUE, TAIL)                                                                  \
         {                                                                                                        \
             if (ABL == 0 || ABL == 2 || ABL == 4) { ISSUE; }                                                     \
             if (ABL == 0 || ABL == 1 || ABL == 4 || (T_) == 0) OFX_F8_READ(T_)                                   \
@@ -226,14 +227,16 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
             __builtin_amdgcn_s_barrier();                                                                        \
             OFX_F8_MFMA16(S_)                                                                                    \
             TAIL                                                                                                 \
-            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    /* my pieces of step t+1 landed (step t+2 stays in flight) */ \
+            if (ABL == 0 || ABL == 2 || ABL == 4) asm volatile("s_waitcnt vmcnt(" #NV ")" ::: "memory");         \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
             __builtin_amdgcn_s_barrier();                                                                        \
         }
-#define OFX_F8_ITER_G1(T_, S_, ISSUE, TAIL)                                                                        \
+#define OFX_F8_ITER_G1(T_, S_, NV, ISSUE, TAIL)                                                                  \
         {                                                                                                        \
             if (ABL == 0 || ABL == 2 || ABL == 4) { ISSUE; }                                                     \
             if (ABL == 0 || ABL == 1 || ABL == 4 || (T_) == 0) OFX_F8_READ(T_)                                   \
-            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    /* my pieces of step t+1 landed: group 0 reads them in slot 2t+3 */ \
+            if (ABL == 0 || ABL == 2 || ABL == 4) asm volatile("s_waitcnt vmcnt(" #NV ")" ::: "memory");         \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
             __builtin_amdgcn_s_barrier();                                                                        \
@@ -241,39 +244,27 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
             TAIL                                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                        \
         }
+#define OFX_F8_W8_ALL(U) OFX_F8_ISSUE_W8(U, 0) OFX_F8_ISSUE_W8(U, 1) OFX_F8_ISSUE_W8(U, 2) OFX_F8_ISSUE_W8(U, 3)
         if (grp == 0) {
-            for (int u = 0; u < nsup - 1; ++u) {
+            for (int u = 0; u < nsup; ++u) {
                 const int t = 4 * u;
-                OFX_F8_ITER_G0(t, 0, issue_cur(t + 2), )
-                OFX_F8_ITER_G0(t + 1, 1, issue_cur(t + 3), )
-                OFX_F8_ITER_G0(t + 2, 2, issue_cur(t + 4), )
-                OFX_F8_ITER_G0(t + 3, 3, issue_cur(t + 5), OFX_F8_MFMA8(u))
+                OFX_F8_ITER_G0(t, 0, 8, issue_step(t + 2); issue_step(t + 3), )
+                OFX_F8_ITER_G0(t + 1, 1, 4, OFX_F8_W8_ALL(u), )
+                OFX_F8_ITER_G0(t + 2, 2, 4, issue_step(t + 4), )
+                OFX_F8_ITER_G0(t + 3, 3, 4, issue_step(t + 5), OFX_F8_MFMA8())
             }
-            {
-                const int t = nk - 4;
-                OFX_F8_ITER_G0(t, 0, issue_cur(t + 2), )
-                OFX_F8_ITER_G0(t + 1, 1, issue_cur(t + 3), )
-                OFX_F8_ITER_G0(t + 2, 2, issue_next(0), )
-                OFX_F8_ITER_G0(t + 3, 3, issue_next(1), OFX_F8_MFMA8(nsup - 1))
-            }
-            __builtin_amdgcn_s_barrier();                           // group 1's last MFMA slot begins: every stage read of this tile is done
+            __builtin_amdgcn_s_barrier();                           // closes group 1's last MFMA slot: every read of this tile's stages and fp8 buffer is done
         } else {
             __builtin_amdgcn_s_barrier();                           // slot 1: group 0 reads step 0
-            for (int u = 0; u < nsup - 1; ++u) {
+            for (int u = 0; u < nsup; ++u) {
                 const int t = 4 * u;
-                OFX_F8_ITER_G1(t, 0, issue_cur(t + 2), )
-                OFX_F8_ITER_G1(t + 1, 1, issue_cur(t + 3), )
-                OFX_F8_ITER_G1(t + 2, 2, issue_cur(t + 4), )
-                OFX_F8_ITER_G1(t + 3, 3, issue_cur(t + 5), OFX_F8_MFMA8(u))
-            }
-            {
-                const int t = nk - 4;
-                OFX_F8_ITER_G1(t, 0, issue_cur(t + 2), )
-                OFX_F8_ITER_G1(t + 1, 1, issue_cur(t + 3), )
-                OFX_F8_ITER_G1(t + 2, 2, issue_next(0), )
-                OFX_F8_ITER_G1(t + 3, 3, issue_next(1), OFX_F8_MFMA8(nsup - 1))
+                OFX_F8_ITER_G1(t, 0, 4, issue_step(t + 3), )
+                OFX_F8_ITER_G1(t + 1, 1, 4, OFX_F8_W8_ALL(u), )
+                OFX_F8_ITER_G1(t + 2, 2, 4, issue_step(t + 4), )
+                OFX_F8_ITER_G1(t + 3, 3, 8, issue_step(t + 5); issue_step(t + 6), OFX_F8_MFMA8())
             }
         }
+#undef OFX_F8_W8_ALL
 #undef OFX_F8_ITER_G0
 #undef OFX_F8_ITER_G1
 #undef OFX_F8_READ
@@ -282,26 +273,27 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
 #undef OFX_F8_MF
 #undef OFX_F8_LD
 #undef OFX_F8_CVT1
-#undef OFX_F8_ISSUE
+#undef OFX_F8_ISSUE_AW
+#undef OFX_F8_ISSUE_W8
         asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 0");     // the epilogue's f32 -> f16 casts keep the default overflow behaviour
-        // Epilogue staging: the stage of this tile's LAST k-step (every read of it is over, no fill targets it); statistics slot of the
-        // LayerNorm-fold consumers: this wave's own not-yet-issued quarters (q = 2, 3) of the next super-step's fp8 buffer.
+        // Epilogue staging: the stage of this tile's LAST k-step (every read of it is over, no fill targets it); statistics slots of the
+        // LayerNorm-fold consumers: the fp8 buffer (idle until the next tile's first iterations refill it, behind the barrier of its slot 0).
         OFX_LDS char* estage = lds + ((base + nk - 1) % NST) * STAGE;
         OFX_LDS char* ep = estage + wave * EPI2_BYTES_PER_WAVE;
         const int gm0 = m0 + wr * 64, gn0 = n0 + wc * 128;
         OFX_LDS float* st = nullptr;
-        if (p.row_stat && p.out_kind != 0) st = (OFX_LDS float*)(lds + W8BASE + ((sbase + nsup) & 1) * W8BUF + (wave * 4 + 2) * 1024);
+        if (p.row_stat && p.out_kind != 0) st = (OFX_LDS float*)(lds + W8BASE + wave * 1024);
         epilogue2_dispatch<T, 4, 8, 0>(p, ep, acc, gm0, gn0, ln, st);
         epilogue2_dispatch<T, 4, 8, 4>(p, ep, acc, gm0, gn0 + 64, ln, st);
         if (!has_next) break;
-        vb += gridDim.x; map_tile(vb, m0, n0); base = (base + nk) % NST; sbase = (sbase + nsup) & 1; first = false;
+        vb += gridDim.x; map_tile(vb, m0, n0); base = (base + nk) % NST; first = false;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the last tile's redundant fills have landed before the wave ends
 }
 
 template <int ABL = 0>
 static int launch_w2f8(KArgs& k, int M, int N, hipStream_t s) {
-    constexpr int LDSB = 3 * 2 * 256 * 32 * 2 + 2 * 256 * 128;          // 96 KiB of stages + 64 KiB of fp8 weight buffers = 160 KiB
+    constexpr int LDSB = 4 * 2 * 256 * 32 * 2 + 256 * 128;              // 128 KiB of stages + the 32 KiB fp8 weight buffer = 160 KiB
     static DeviceOnce attr;
     TRY(attr.run([]() -> int {
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_w2f8_kernel<ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));

@@ -26,6 +26,10 @@ def main():
         W = Wf.half()
         W2 = torch.empty(N, 2 * K, device="cuda", dtype=torch.float16)
         L.check(lib.ofx_convert(Wf.data_ptr(), W2.data_ptr(), N, K, 3, 2, s))
+        W8 = torch.empty(N, K, device="cuda", dtype=torch.uint8); sc8 = torch.empty(N, device="cuda", dtype=torch.uint8)
+        f8 = K % 128 == 0 and N % 128 == 0
+        if f8:
+            L.check(lib.ofx_pack_lo8(W2.data_ptr(), W8.data_ptr(), sc8.data_ptr(), N, K, s))
         C = torch.empty(M, N, device="cuda", dtype=torch.float16 if ep in "bg" else torch.float32)
         if ep == "r":
             C.normal_(generator=g)
@@ -43,6 +47,18 @@ def main():
             return f
         runs = {"x1": lambda: lib.ofx_gemm(A.data_ptr(), W.data_ptr(), C.data_ptr(), bias.data_ptr(), resid, M, N, K, K, N, N, act, okind, 2, s),
                 "w2": lambda: lib.ofx_gemm_w2(A.data_ptr(), W2.data_ptr(), C.data_ptr(), bias.data_ptr(), resid, M, N, K, K, N, N, act, okind, 2, s)}
+        if f8:         # the fp8 correction product (gemm_w2f8_kernel); OFX_F8_ABLATE=1,2,3,4 adds its DIAG ablations
+            runs["w2f8"] = lambda: lib.ofx_gemm_w2f8(A.data_ptr(), W2.data_ptr(), W8.data_ptr(), sc8.data_ptr(), C.data_ptr(), bias.data_ptr(), resid, M, N, K, K, N, N, act, okind, s)
+            def f8_ablated(a):
+                def f():
+                    lib.ofx_tune(1, a)
+                    try:
+                        return runs["w2f8"]()
+                    finally:
+                        lib.ofx_tune(1, 0)
+                return f
+            for a_ in [int(v) for v in os.environ.get("OFX_F8_ABLATE", "").split(",") if v]:
+                runs[f"w2f8 abl{a_}"] = f8_ablated(a_)
         for a_ in abl:
             runs[f"abl{a_}"] = ablated(a_)
         if os.environ.get("OFX_KNOB"):                  # A/B of an ofx_tune knob on the dual-weight kernel: OFX_KNOB=11:0:256 (knob:value:restore)
