@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <unordered_map>
 #include <vector>
 #include <mutex>
 #include <cstring>
@@ -150,6 +151,15 @@ struct Arena {                                      // library-owned HBM for pac
 
 struct OutfitLayer { void *w_in, *w_out, *w_1, *w_2; float *b_in, *b_out, *b_1, *b_2, *g1, *be1, *g2, *be2;
                      void *w_in_t, *w_out_t, *w_1_t, *w_2_t; };   // transposed operand copies (dgrad), single-product precisions only
+// fp8 companions of split-weight copies (gemm_w2f8.hip): [hi | lo] rows pointer -> {e4m3 lo rows, per-row scale bytes}; filled at pack
+// time for f16 towers, looked up where a split-weight GEMM is configured (process-wide: arena pointers are unique)
+struct F8Pair { void* w8; void* s8; };
+std::unordered_map<const void*, F8Pair> g_f8_of;
+static void use_split(GemmArgs& g, const void* w2, int K) {
+    g.W = w2; g.K = 2 * K; g.a_wrap = K;
+    auto it = g_f8_of.find(w2);
+    if (it != g_f8_of.end()) { g.W8 = it->second.w8; g.w8_scale = it->second.s8; }
+}
 struct ClipLayer { void *w_qkv, *w_o, *w_fc1, *w_fc2; float *b_qkv, *b_o, *b_fc1, *b_fc2, *g1, *be1, *g2, *be2;
                    // LayerNorm-folded copies: W . gamma (rounded), column sums of the rounded rows, bias + W beta
                    void *w_qkv_f, *w_fc1_f; float *cs_qkv, *bf_qkv, *cs_fc1, *bf_fc1;
@@ -309,6 +319,16 @@ extern "C" int ofx_pack_outfit_weights(ofx_handle* h, const void* const* P, int 
     return OFX_OK;
 }
 
+// fp8 copy of a split-weight matrix's lo halves (f16 towers, shapes gemm_w2f8 takes): registered for use_split
+static int pack_f8(Arena& A, const void* w2, size_t N, size_t K, int dt, hipStream_t s) {
+    g_f8_of.erase(w2);
+    if (dt != OFX_F16 || N % 128 || K % 128 || K < 256) return OFX_OK;
+    char* w8 = A.take<char>(N * K); char* s8 = A.take<char>(N);
+    TRY(ofx_launch_pack_lo8(w2, w8, s8, (int)N, (int)K, s));
+    g_f8_of[w2] = F8Pair{w8, s8};
+    return OFX_OK;
+}
+
 // q/k/v Linear weights -> one [3W, W] operand matrix in q|k|v order (+ fused bias).  `q` points at
 // the 16 per-layer tensors in HF order: k.w,k.b,v.w,v.b,q.w,q.b,out.w,out.b,ln1.w,ln1.b,fc1.w,fc1.b,fc2.w,fc2.b,ln2.w,ln2.b
 static int pack_clip_layer(Arena& A, ClipLayer& L, const void* const* q, size_t W, size_t MLP, int dt, hipStream_t s, int w2_mask = 0, bool x3 = false) {
@@ -344,8 +364,8 @@ static int pack_clip_layer(Arena& A, ClipLayer& L, const void* const* q, size_t 
     L.w_fc1_f = A.take<char>(2 * MLP * W); L.cs_fc1 = A.take<float>(MLP); L.bf_fc1 = A.take<float>(MLP);
     TRY(ofx_launch_fold_pack((const float*)q[10], (const float*)q[14], (const float*)q[15], (const float*)q[11], L.w_fc1_f, L.cs_fc1, L.bf_fc1, (int)MLP, Wi, dt, s));
     // split-weight copies: row n = [hi(K) | lo(K)]
-    if (w2_mask & OFX_W2_OUT) { L.w_o2 = A.take<char>(4 * W * W); TRY(ofx_launch_pack_rows((const float*)q[6], L.w_o2, W, W, W, W, W, 3, dt, s)); }
-    if (w2_mask & OFX_W2_FC2) { L.w_fc22 = A.take<char>(4 * W * MLP); TRY(ofx_launch_pack_rows((const float*)q[12], L.w_fc22, W, W, MLP, MLP, MLP, 3, dt, s)); }
+    if (w2_mask & OFX_W2_OUT) { L.w_o2 = A.take<char>(4 * W * W); TRY(ofx_launch_pack_rows((const float*)q[6], L.w_o2, W, W, W, W, W, 3, dt, s)); TRY(pack_f8(A, L.w_o2, W, W, dt, s)); }
+    if (w2_mask & OFX_W2_FC2) { L.w_fc22 = A.take<char>(4 * W * MLP); TRY(ofx_launch_pack_rows((const float*)q[12], L.w_fc22, W, W, MLP, MLP, MLP, 3, dt, s)); TRY(pack_f8(A, L.w_fc22, W, MLP, dt, s)); }
     if (w2_mask & OFX_W2_QKV) {        // q | k | v blocks of [hi | lo] rows (row stride 2 W), folded and plain
         char* f2 = A.take<char>(4 * 3 * W * W); L.w_qkv_f2 = f2; L.cs_qkv2 = A.take<float>(3 * W);
         float* bf_scratch = A.take<float>(3 * W);       // bias + W beta is the same as the single copy's: recomputed into scratch
@@ -356,12 +376,14 @@ static int pack_clip_layer(Arena& A, ClipLayer& L, const void* const* q, size_t 
                                      L.cs_qkv2 + i * W, bf_scratch + i * W, Wi, Wi, dt, s, 1));
             TRY(ofx_launch_pack_rows((const float*)q[src[i]], p2 + (size_t)i * 4 * W * W, W, W, W, W, W, 3, dt, s));
         }
+        TRY(pack_f8(A, f2, 3 * W, W, dt, s)); TRY(pack_f8(A, p2, 3 * W, W, dt, s));       // one [3W, W] matrix each: q | k | v row blocks
     }
     if (w2_mask & OFX_W2_FC1) {
         L.w_fc1_f2 = A.take<char>(4 * MLP * W); L.cs_fc12 = A.take<float>(MLP);
         float* bf_scratch = A.take<float>(MLP);
         TRY(ofx_launch_fold_pack((const float*)q[10], (const float*)q[14], (const float*)q[15], (const float*)q[11], L.w_fc1_f2, L.cs_fc12, bf_scratch, (int)MLP, Wi, dt, s, 1));
         L.w_fc12 = A.take<char>(4 * MLP * W); TRY(ofx_launch_pack_rows((const float*)q[10], L.w_fc12, MLP, MLP, W, W, W, 3, dt, s));
+        TRY(pack_f8(A, L.w_fc1_f2, MLP, W, dt, s)); TRY(pack_f8(A, L.w_fc12, MLP, W, dt, s));
     }
     return OFX_OK;
 }
@@ -369,7 +391,10 @@ static size_t clip_layer_bytes(size_t W, size_t MLP, int w2_mask = 0, bool x3 = 
     if (x3) return 6 * (4 * W * W + 2 * W * MLP) + 4 * (9 * W + MLP) + 32 * 256;
     return 2 * (4 * W * W + 2 * W * MLP) + 4 * (9 * W + MLP) + 2 * (3 * W * W + W * MLP) + 4 * (6 * W + 2 * MLP) +
            ((w2_mask & OFX_W2_OUT) ? 4 * W * W : 0) + ((w2_mask & OFX_W2_FC2) ? 4 * W * MLP : 0) +
-           ((w2_mask & OFX_W2_QKV) ? 24 * W * W + 24 * W : 0) + ((w2_mask & OFX_W2_FC1) ? 8 * W * MLP + 8 * MLP : 0) + 44 * 256;
+           ((w2_mask & OFX_W2_QKV) ? 24 * W * W + 24 * W : 0) + ((w2_mask & OFX_W2_FC1) ? 8 * W * MLP + 8 * MLP : 0) + 44 * 256 +
+           // fp8 companions (N K bytes + N scale bytes per split matrix)
+           ((w2_mask & OFX_W2_OUT) ? W * W + W : 0) + ((w2_mask & OFX_W2_FC2) ? W * MLP + W : 0) + ((w2_mask & OFX_W2_QKV) ? 6 * W * W + 6 * W : 0) +
+           ((w2_mask & OFX_W2_FC1) ? 2 * W * MLP + 2 * MLP : 0) + 12 * 256;
 }
 
 extern "C" int ofx_pack_vision_weights(ofx_handle* h, const void* const* P, int n, ofx_stream stream) {
@@ -380,14 +405,14 @@ extern "C" int ofx_pack_vision_weights(ofx_handle* h, const void* const* P, int 
     hipStream_t s = (hipStream_t)stream;
     const size_t W = d.vit_width, MLP = d.vit_mlp, KP = 3 * (size_t)d.vit_patch * d.vit_patch, g = d.vit_image / d.vit_patch, S = g * g + 1, PD = d.proj_dim;
     const bool vx3 = h->vit_x3 != 0;
-    TRY(h->a_vis.reserve(clip_layer_bytes(W, MLP, h->vit_w2_mask, vx3) * d.vit_layers + 6 * W * KP + 8 * PD * W + 4 * (W + S * W + 4 * W) + 18 * 256));
+    TRY(h->a_vis.reserve(clip_layer_bytes(W, MLP, h->vit_w2_mask, vx3) * d.vit_layers + 6 * W * KP + (W * KP + W + 512) + 8 * PD * W + 4 * (W + S * W + 4 * W) + 18 * 256));
     Arena& A = h->a_vis;
     CopyBatch copies;
     const int dt = h->tw_dtype;
     h->v_cls = A.take<float>(W); TRY(copy_f32(h->v_cls, P[0], W, s));
     h->v_patch_w = A.take<char>(2 * W * KP); TRY(ofx_launch_pack_rows((const float*)P[1], h->v_patch_w, W, W, KP, KP, KP, 0, dt, s));
     h->v_patch_w2 = nullptr;
-    if (h->vit_w2_mask & OFX_W2_PATCH) { h->v_patch_w2 = A.take<char>(4 * W * KP); TRY(ofx_launch_pack_rows((const float*)P[1], h->v_patch_w2, W, W, KP, KP, KP, 3, dt, s)); }
+    if (h->vit_w2_mask & OFX_W2_PATCH) { h->v_patch_w2 = A.take<char>(4 * W * KP); TRY(ofx_launch_pack_rows((const float*)P[1], h->v_patch_w2, W, W, KP, KP, KP, 3, dt, s)); TRY(pack_f8(A, h->v_patch_w2, W, KP, dt, s)); }
     h->v_pos = A.take<float>(S * W); TRY(copy_f32(h->v_pos, P[2], S * W, s));
     h->v_pre_g = A.take<float>(W); TRY(copy_f32(h->v_pre_g, P[3], W, s));
     h->v_pre_b = A.take<float>(W); TRY(copy_f32(h->v_pre_b, P[4], W, s));
@@ -682,12 +707,12 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
     if (fused) {
     } else if (fold) {
         g1.A = w.XB; g1.W = L.w_qkv_f; g1.bias = L.bf_qkv; g1.row_stat = w.S; g1.col_sum = L.cs_qkv;
-        if (qkv_w2) { g1.W = L.w_qkv_f2; g1.col_sum = L.cs_qkv2; g1.K = 2 * W; g1.a_wrap = W; wrow *= 2; }
+        if (qkv_w2) { use_split(g1, L.w_qkv_f2, W); g1.col_sum = L.cs_qkv2; wrow *= 2; }
     } else {
         LnArgs ln{w.X, nullptr, L.g1, L.be1, w.H, rows, W, W, OFX_OUT_OP, eps};
         TRY(ofx_launch_layernorm(ln, dt, s));
         g1.A = w.H; g1.W = L.w_qkv; g1.bias = L.b_qkv;
-        if (qkv_w2) { g1.W = L.w_qkv2; g1.K = 2 * W; g1.a_wrap = W; wrow *= 2; }
+        if (qkv_w2) { use_split(g1, L.w_qkv2, W); wrow *= 2; }
     }
     if (fused) {
     } else if (pool_idx && pool_first && g_prune_q) {
@@ -696,6 +721,7 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
         // columns keep stale workspace bytes; their attention outputs are never read (the tail gathers the pooled rows only).
         GemmArgs kv = g1;
         kv.W = (const char*)g1.W + (size_t)W * wrow; kv.bias = g1.bias + W; kv.C = (char*)w.QKV + (size_t)W * 2; kv.N = 2 * W;
+        if (g1.W8) { kv.W8 = (const char*)g1.W8 + (size_t)W * W; kv.w8_scale = (const char*)g1.w8_scale + W; }      // weight rows W .. 3W: fp8 rows of W bytes, scale bytes 128 per 128-row block
         if (fold) kv.col_sum = g1.col_sum + W;
         TRY(ofx_launch_gemm(kv, dt, s));
         GemmArgs q = g1;
@@ -722,19 +748,19 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
     const bool hilo = fold && g_ln_fold == 2;      // residual stream = (XB, XLO) operand-type pair, no fp32 X (ofx_tune(6, 2))
     if (fold2) { g2.xb_out = w.XB; g2.stat_part = w.P; }
     if (fold2 && hilo) { g2.xlo = w.XLO; g2.C = w.XB; g2.ldc = W; g2.out_kind = OFX_OUT_OP; g2.resid = nullptr; }
-    if (L.w_o2) { g2.W = L.w_o2; g2.K = 2 * W; g2.a_wrap = W; }                 // split weights: A . (hi + lo)^T
+    if (L.w_o2) use_split(g2, L.w_o2, W);                                       // split weights: A . (hi + lo)^T
     TRY(ofx_launch_gemm(g2, dt, s));
     GemmArgs g3{}; g3.C = U; g3.M = M; g3.N = MLP; g3.K = W; g3.lda = W;
     g3.ldc = MLP; g3.act = act; g3.out_kind = OFX_OUT_OP;
     if (fold2) {
         TRY(ofx_launch_stats_finalize(w.P, W / 64, W, eps, w.S, M, s));
         g3.A = w.XB; g3.W = L.w_fc1_f; g3.bias = L.bf_fc1; g3.row_stat = w.S; g3.col_sum = L.cs_fc1;
-        if (L.w_fc1_f2) { g3.W = L.w_fc1_f2; g3.col_sum = L.cs_fc12; g3.K = 2 * W; g3.a_wrap = W; }
+        if (L.w_fc1_f2) { use_split(g3, L.w_fc1_f2, W); g3.col_sum = L.cs_fc12; }
     } else {
         LnArgs ln2{X, nullptr, L.g2, L.be2, H, M, W, W, OFX_OUT_OP, eps};
         TRY(ofx_launch_layernorm(ln2, dt, s));
         g3.A = H; g3.W = L.w_fc1; g3.bias = L.b_fc1;
-        if (L.w_fc12) { g3.W = L.w_fc12; g3.K = 2 * W; g3.a_wrap = W; }
+        if (L.w_fc12) use_split(g3, L.w_fc12, W);
     }
     if (pool_idx) { g3.slab = w.slab; g3.slab_bytes = w.slab_bytes; }
     TRY(ofx_launch_gemm(g3, dt, s));
@@ -743,7 +769,7 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
     if (pool_idx) { g4.slab = w.slab; g4.slab_bytes = w.slab_bytes; }
     if (fold2) { g4.xb_out = w.XB; g4.stat_part = w.P; }
     if (fold2 && hilo) { g4.xlo = w.XLO; g4.C = w.XB; g4.ldc = W; g4.out_kind = OFX_OUT_OP; g4.resid = nullptr; }
-    if (L.w_fc22) { g4.W = L.w_fc22; g4.K = 2 * MLP; g4.a_wrap = MLP; }
+    if (L.w_fc22) use_split(g4, L.w_fc22, MLP);
     TRY(ofx_launch_gemm(g4, dt, s));
     if (fold2) TRY(ofx_launch_stats_finalize(w.P, W / 64, W, eps, w.S, M, s));
     return OFX_OK;
@@ -846,7 +872,7 @@ static int vit_core(ofx_handle* h, const float* pixels, const RawImages* raw, in
             TRY(ofx_launch_patchify(pixels + (size_t)n0 * px_per_img, w.U, n, d.vit_image, d.vit_patch, dt, s));
         GemmArgs gp{}; gp.A = w.U; gp.W = h->v_patch_w; gp.C = w.QKV; gp.M = n * g * g; gp.N = W; gp.K = KP; gp.lda = KP; gp.ldc = W;
         gp.act = OFX_ACT_NONE; gp.out_kind = OFX_OUT_F32;
-        if (h->v_patch_w2) { gp.W = h->v_patch_w2; gp.K = 2 * KP; gp.a_wrap = KP; }
+        if (h->v_patch_w2) use_split(gp, h->v_patch_w2, (int)KP);
         TRY(ofx_launch_gemm(gp, dt, s));
         const bool fold = clip_fold(W) && !h->vit_x3;                    // the pre-LN kernel then also emits layer 0's operand copy + statistics
         TRY(ofx_launch_vit_embed_ln((const float*)w.QKV, h->v_cls, h->v_pos, h->v_pre_g, h->v_pre_b, fold && g_ln_fold == 2 ? nullptr : w.X, n, S, W, d.ln_eps, s, fold ? w.XB : nullptr,
