@@ -1,4 +1,4 @@
-# Builds libofx_hip.so (HIP kernels + C ABI, gfx950) and the oracle's C pieces.
+# Builds libofx_hip.so (HIP kernels + C ABI, gfx950).  The oracle is Python (oracle/*.py): nothing of it is compiled.
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := outfitx_amd/csrc

@@ -287,9 +287,11 @@ def main():
         for (M_, N_, K_, km_, kind_), (c_, t_, b_) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
             useful = 2.0 * M_ * N_ * K_ * c_ / (t_ * 1e-3) / 1e12
             launched_flop += 2.0 * M_ * N_ * K_ * c_
-            table.append({"M": M_, "N": N_, "K": K_, "products_per_term": km_, "kernel": KIND.get(kind_, str(kind_)), "launches": c_,
+            # matrix-pipe work in f16-rate product equivalents: the fp8 correction product of gemm_w2f8_kernel runs at twice the f16 rate
+            pe_ = 1.5 if kind_ == 8 else float(km_)
+            table.append({"M": M_, "N": N_, "K": K_, "products_per_term": km_, "f16_rate_product_equivalents": pe_, "kernel": KIND.get(kind_, str(kind_)), "launches": c_,
                           "us_per_launch": round(t_ * 1e3 / c_, 1), "ms_per_step": round(t_, 3), "useful_tflops": round(useful, 1),
-                          "frac_useful": round(useful / PEAK_BF16_TFLOPS, 4), "executed_tflops": round(useful * km_, 1),
+                          "frac_useful": round(useful / PEAK_BF16_TFLOPS, 4), "executed_tflops": round(useful * pe_, 1),
                           "algorithmic_mb_per_launch": round(b_ / c_ / 1e6, 1), "algorithmic_tb_per_s": round(b_ / (t_ * 1e-3) / 1e12, 2)})
             k_ = by_kernel.setdefault(KIND.get(kind_, str(kind_)).split(" ")[0], [0, 0.0, 0.0, 0.0])
             k_[0] += c_; k_[1] += t_; k_[2] += b_; k_[3] += 2.0 * M_ * N_ * K_ * c_
@@ -313,8 +315,9 @@ def main():
                         "useful_tflops": round(v[3] / (v[1] * 1e-3) / 1e12, 1), "algorithmic_mb_per_launch": round(v[2] / v[0] / 1e6, 1)}
                    for kn, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][1])}
         dom = max(by_kernel.items(), key=lambda kv: kv[1][1])[0] if by_kernel else None
-        scheme = {"f16w2x": "f16w2x = f16 MFMA operands; split (hi, lo) weights (2 products per weight) on every ViT GEMM (patch embedding, qkv, out-proj, fc1, fc2); text tower, "
-                            "ViT projection tail and the outfit transformer in three-product arithmetic",
+        scheme = {"f16w2x": "f16w2x = f16 MFMA operands; split (hi, lo) weights on every ViT GEMM (patch embedding, qkv, out-proj, fc1, fc2): A hi^T in f16 + the correction A lo^T "
+                            "on the block-scaled fp8 matrix instruction (gemm_w2f8_kernel; f16 lo product on small grids); text tower, ViT projection tail and the outfit "
+                            "transformer in three-product arithmetic",
                   "f16w2": "f16w2 = f16 MFMA operands; split (hi, lo) weights (2 products per weight) on the ViT patch-embedding / out-proj / fc2 GEMMs; text tower, "
                            "ViT projection tail and the outfit transformer in three-product arithmetic",
                   "f16": "f16, one MFMA product per term", "bf16": "bf16, one MFMA product per term"}.get(a.tower_precision, a.tower_precision)

@@ -31,6 +31,9 @@ TOWER_SCHEMES = {
     "bf16": (PREC_BF16, 0, 0, 0, 0), "f16": (PREC_F16, 0, 0, 0, 0), "fp16": (PREC_F16, 0, 0, 0, 0),
     "f16w2": (PREC_F16, W2_PATCH | W2_OUT | W2_FC2, 1, 1, 0),
     "bf16w2": (PREC_BF16, W2_PATCH | W2_OUT | W2_FC2, 1, 1, 0),
+    # rungs between the two (studies: tests/studies/bench_scale_sweep.py): + qkv, or + fc1
+    "f16w2q": (PREC_F16, W2_PATCH | W2_QKV | W2_OUT | W2_FC2, 1, 1, 0),
+    "f16w2f": (PREC_F16, W2_PATCH | W2_OUT | W2_FC1 | W2_FC2, 1, 1, 0),
     # every ViT weight split (qkv then runs as dual-weight GEMM + attention kernel instead of the fused kernel)
     "f16w2x": (PREC_F16, W2_PATCH | W2_QKV | W2_OUT | W2_FC1 | W2_FC2, 1, 1, 0),
     # every tower GEMM in three products (the patch embedding against split weights; the ViT's MFMA attention core stays on f16

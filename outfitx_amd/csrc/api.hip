@@ -691,7 +691,7 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
                       bool pool_first = false) {
     // fused QKV projection + attention (non-pooled ViT layers: one 33..64-token tile per sequence, no mask): q | k | v never reach HBM
     const bool qkv_w2 = L.w_qkv_f2 != nullptr;     // split q | k | v weights: the dual-weight variant of the fused kernel, or (ofx_tune(9, 1)) the dual-weight GEMM + the attention kernel
-    const bool fused = (g_fuse_qkv & (qkv_w2 ? 2 : 1)) && !pool_idx && !causal && !key_mask && S >= 33 && S <= 64;
+    const bool fused = (g_fuse_qkv & (qkv_w2 ? 2 : 1)) && !pool_idx && !causal && !key_mask && S >= 33 && S <= 64 && (256 / S - 1) * S + 64 - 256 <= 16;   // (the kernel's key-row overshoot fits its 16 pad rows)
     if (fused) {
         if (fold) {
             TRY(ofx_launch_fused_qkv_attn(w.XB, qkv_w2 ? L.w_qkv_f2 : L.w_qkv_f, L.bf_qkv, w.S, qkv_w2 ? L.cs_qkv2 : L.cs_qkv, w.H, nseq, S, W, heads, W, W, 0.125f, dt, s, qkv_w2));

@@ -407,6 +407,9 @@ int ofx_launch_fused_qkv_attn(const void* X, const void* Wqkv, const float* bias
                               int n_img, int S, int Wm, int heads, int ldx, int ldo, float scale, int op_dtype, hipStream_t s, bool w2) {
     OFX_REQUIRE(X && Wqkv && bias && out && n_img > 0, OFX_EINVAL, "fused_qkv_attn: NULL argument");
     OFX_REQUIRE(S >= 33 && S <= 64 && Wm == heads * 64 && Wm % BK == 0 && Wm / BK >= 2, OFX_ESHAPE, "fused_qkv_attn: S=%d must be in [33,64], width %d = heads * 64", S, Wm);
+    // the last image of a block reads keys up to tile row (G - 1) S + 63; only 16 zeroed V pad rows sit behind row 255
+    OFX_REQUIRE((FQ_TM / S - 1) * S + 64 - FQ_TM <= 16, OFX_ESHAPE, "fused_qkv_attn: S=%d would read %d key rows past the tile's 16 pad rows (supported: 33, 34, 37..41, 43..64)", S,
+                (FQ_TM / S - 1) * S + 64 - FQ_TM);
     OFX_REQUIRE(ldx >= Wm && ldx % 8 == 0 && ldo >= Wm && ldo % 8 == 0, OFX_ESHAPE, "fused_qkv_attn: bad strides");
     OFX_REQUIRE(!row_stat || col_sum, OFX_EINVAL, "fused_qkv_attn: row_stat needs col_sum");
     FusedK k;

@@ -174,7 +174,7 @@ static SmallPlan plan_small(int M, int N, int K, bool allow_split, bool allow64)
     const int nk = K / BK;
     SmallPlan best{0, 1, 1e30};
     if (g_gemm_splitk >= 2) {
-        SmallPlan f{(g_gemm_splitk >> 8) & 1, g_gemm_splitk & 0xff, 0.0};
+        SmallPlan f{(g_gemm_splitk >> 8) & 1, (g_gemm_splitk & 0xff) > 16 ? 16 : (g_gemm_splitk & 0xff), 0.0};      // forced plans: at most 16 slices, as the planner's own
         if (f.tile64 && !allow64) f.tile64 = 0;
         if (!allow_split || f.splits > nk) f.splits = 1;
         const int kps = (nk + f.splits - 1) / f.splits;
@@ -197,8 +197,11 @@ static SmallPlan plan_small(int M, int N, int K, bool allow_split, bool allow64)
     return best;
 }
 int ofx_gemm_splitk_plan(int M, int N, int K) { return plan_small(M, N, K, true, M > 64).splits; }
+// Slab size for ANY plan the launcher may pick for this shape: it plans with or without 64-row tiles depending on the kernel knobs
+// and the grid (can64 in ofx_launch_gemm), so the slab covers the larger slice count of the two tile heights (forced plans: <= 16).
 size_t ofx_gemm_splitk_bytes(int M, int N, int K) {
-    const int sp = g_gemm_splitk >= 2 ? 16 : ofx_gemm_splitk_plan(M, N, K);
+    const int a = plan_small(M, N, K, true, true).splits, b = plan_small(M, N, K, true, false).splits;
+    const int sp = a > b ? a : b;
     return sp > 1 ? (size_t)sp * M * N * 4 : 0;
 }
 

@@ -1,7 +1,8 @@
 // Dual-weight ("W2") 256x256 tile kernel: C = A . (W_hi + W_lo)^T with ONE copy of A.
 //
 // The weight matrix is stored split, row n = [hi(K) | lo(K)] (hi = round(w), lo = round(w - hi), both in the operand type), so
-// the product keeps ~22 significant weight bits at two MFMAs per (A fragment, column tile) while the activation tile is loaded
+// the product keeps ~22 significant weight bits (f16: about 18 at |w| ~ 0.02, where the lo half is subnormal with an absolute step of
+// 2^-24; bf16: 16) at two MFMAs per (A fragment, column tile) while the activation tile is loaded
 // and its fragments are read ONCE: per 32-deep k-step and wave 8 A + 4 W_hi + 4 W_lo fragment reads feed 64 MFMAs (the
 // single-product kernels read 12 fragments per 32 MFMAs), so the loop is bound by the matrix pipe, not by the LDS port.
 // Used for the CLIP GEMMs whose weight rounding dominates the end-to-end error (fc2, out-proj, patch embedding: DESIGN.md §2).

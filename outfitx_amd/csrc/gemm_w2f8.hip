@@ -36,6 +36,10 @@
 #include "gemm_common.h"
 
 extern int g_w2_persist;
+#ifndef OFX_F8_PRIO
+#define OFX_F8_PRIO 1
+#endif
+#define OFX_F8_PRIO_HI __builtin_amdgcn_s_setprio(OFX_F8_PRIO)
 namespace {
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
     }
 #define OFX_F8_MFMA16(S)                                                                                      \
     {                                                                                                         \
-        __builtin_amdgcn_s_setprio(1);                                                                        \
+        OFX_F8_PRIO_HI;                                                                      \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[i][j] = OpT<T>::mfma16(wh[j], af[i], acc[i][j]); \
             if (ABL != 4) OFX_F8_CVT1(i, S)                                                                   \
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
         w8_[(J) % 3] = i32x8{c0_[0], c0_[1], c0_[2], c0_[3], c1_[0], c1_[1], c1_[2], c1_[3]};                 \
     }
 #define OFX_F8_MF(J, SEL, SC)                                                                                 \
-    if ((J) + 2 < 8) OFX_F8_LD((J) + 2)                                                                       \
+    if ((J) + 2 < 8) { OFX_F8_LD((J) + 2) __builtin_amdgcn_sched_barrier(0); }     /* keep the load two fragments ahead of its use */ \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
         acc[i][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8_[(J) % 3], a8[i], acc[i][J], 0, 0, SEL, SC, 0, a_e8);
 #define OFX_F8_MFMA8()                                                                                      \
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
         OFX_LDS char* b8_ = lds + W8BASE;                                                                     \
         i32x8 w8_[3];                                                                                         \
         OFX_F8_LD(0) OFX_F8_LD(1)                                                                             \
-        __builtin_amdgcn_s_setprio(1);                                                                        \
+        OFX_F8_PRIO_HI;                                                                      \
         OFX_F8_MF(0, 0, sc_lo) OFX_F8_MF(1, 1, sc_lo) OFX_F8_MF(2, 2, sc_lo) OFX_F8_MF(3, 3, sc_lo)           \
         OFX_F8_MF(4, 0, sc_hi) OFX_F8_MF(5, 1, sc_hi) OFX_F8_MF(6, 2, sc_hi) OFX_F8_MF(7, 3, sc_hi)           \
         __builtin_amdgcn_s_setprio(0);                                                                        \

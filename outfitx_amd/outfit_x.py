@@ -299,6 +299,13 @@ class OutfitX(nn.Module):
         eng, row0 = self._run_encoder(outfit_embedding, outfit_mask, precision=prec)
         return eng.cp_head(row0)
 
+    def sink_ready(self, skip=(1, 4)) -> bool:
+        """True when the next CP backward will add straight into the parameters' own .grad buffers (gradient-sink mode with a dense
+        fp32 .grad on every tensor of the path): only then are a layer's gradients final where the backward records its event -
+        with the autograd fallback they land in a private buffer and AccumulateGrad adds them later (trainer.CPTrainer checks this
+        before arming the overlapped reduction)."""
+        return bool(getattr(self, "grad_sink", False)) and _sink_dests(self._outfit_tensors(), skip) is not None
+
     def arm_bwd_layer_events(self, events) -> None:
         """Data-parallel overlap (trainer.CPTrainer): the next backward of the training step records events[l] when layer l's
         gradients are final."""

@@ -197,6 +197,10 @@ class CPTrainer:
         if not (self.overlap_reduce and self.layer_slices and self._world() > 1 and hasattr(self.model, "arm_bwd_layer_events")
                 and self.grads.flat.is_cuda):
             return False
+        # the events mean "final in the arena" only on the gradient-sink path; any tensor whose .grad is not the arena view (detached,
+        # non-contiguous, not fp32) sends the backward through autograd's accumulation, which runs AFTER the events: plain reduction then
+        if hasattr(self.model, "sink_ready") and not self.model.sink_ready():
+            return False
         if self._layer_events is None:
             self._layer_events = [torch.cuda.Event() for _ in self.layer_slices]
             for e in self._layer_events:

@@ -88,6 +88,33 @@ def test_gemm_split_weights(force, dt, M, N, K):
     assert rel_err(out.cpu().numpy(), want) < 2e-5
 
 
+@pytest.mark.parametrize("K", [64, 96, 192])
+def test_gemm_split_weights_persistent_grid_is_bit_identical_to_one_block_per_tile(K):
+    """The persistent dual-weight kernel at its shallowest depths (K = 64: two k-steps per tile, both peeled iterations fetch the next
+    tile's steps and the first refill targets the previous tile's epilogue stage; K = 96: three) on a many-tile shape with a ragged
+    tile count: grids of one block per tile (knob 11 = 0), one per CU (-1) and an odd 7 blocks must agree bit for bit, and with
+    float64 arithmetic on the rounded operands."""
+    M, N = 70000, 768
+    g = np.random.default_rng(K)
+    A = to_op(g.standard_normal((M, K), dtype=np.float32), "f16")
+    W2, Wv = _split_w((g.standard_normal((N, K), dtype=np.float32) / np.float32(np.sqrt(K))).astype(np.float32), "f16")
+    bias = dev(g.standard_normal(N, dtype=np.float32))
+    lib = L.load()
+    outs = []
+    lib.ofx_tune(2, 6)
+    try:
+        for persist in (0, -1, 7):
+            lib.ofx_tune(11, persist)
+            out = torch.full((M, N), float("nan"), device="cuda")
+            L.check(lib.ofx_gemm_w2(A.data_ptr(), W2.data_ptr(), out.data_ptr(), bias.data_ptr(), None, M, N, K, K, N, 0, 0, 0, DT["f16"], stream()))
+            torch.cuda.synchronize()
+            outs.append(out)
+    finally:
+        lib.ofx_tune(11, -1); lib.ofx_tune(2, 0)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert rel_err(outs[0].cpu().numpy(), A.double().cpu().numpy() @ Wv.T + bias.cpu().numpy()) < 2e-5
+
+
 def _e4m3_decode(b):
     """uint8 ndarray (OCP e4m3fn bit patterns) -> float64 values."""
     b = b.astype(np.int64)
@@ -407,7 +434,7 @@ def test_attention_f32_fixed_length_causal_and_key_mask(S, causal, masked):
 
 @pytest.mark.parametrize("fold", [0, 1])
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
-@pytest.mark.parametrize("n,S,H", [(1, 50, 12), (5, 50, 12), (13, 50, 12), (7, 64, 4), (9, 33, 2)])
+@pytest.mark.parametrize("n,S,H", [(1, 50, 12), (5, 50, 12), (13, 50, 12), (7, 64, 4), (9, 33, 2), (8, 41, 2), (13, 43, 2)])
 def test_fused_qkv_projection_attention(fold, dt, n, S, H):
     """The fused QKV-projection + attention kernel (q | k | v staged in LDS only) against (a) the unfused pair ofx_gemm ->
     ofx_attention on the same operands - the same arithmetic in the same order, so equal to the rounding of q | k | v - and
@@ -443,6 +470,17 @@ def test_fused_qkv_projection_attention(fold, dt, n, S, H):
         o2 = torch.zeros(rows, W, dtype=X.dtype, device="cuda")
         L.check(lib.ofx_attention(q2.data_ptr(), o2.data_ptr(), None, n, S, H, 3 * W, W, W, 2 * W, 0, 0, 0.125, DT[dt], stream()))
         assert rel_err(got, o2.double().cpu().numpy()) < (4e-3 if dt == "bf16" else 5e-4)
+
+
+@pytest.mark.parametrize("S", [35, 36, 42])
+def test_fused_qkv_attention_rejects_sequence_lengths_that_overrun_its_pad_rows(S):
+    """The last image of a block reads keys up to tile row (G - 1) S + 63; 16 zeroed pad rows sit behind row 255, which S = 35, 36
+    and 42 would overrun (18 - 24 rows): the launcher refuses them (OFX_ESHAPE) instead of multiplying P = 0 into stale LDS bytes."""
+    W = 2 * 64
+    X = torch.zeros(4 * S, W, dtype=torch.float16, device="cuda"); Wq = torch.zeros(3 * W, W, dtype=torch.float16, device="cuda")
+    b = torch.zeros(3 * W, device="cuda"); out = torch.zeros(4 * S, W, dtype=torch.float16, device="cuda")
+    rc = L.load().ofx_fused_qkv_attention(X.data_ptr(), Wq.data_ptr(), b.data_ptr(), None, None, out.data_ptr(), 4, S, W, 2, W, W, 0.125, DT["f16"], stream())
+    assert rc != 0 and b"pad rows" in L.load().ofx_last_error()
 
 
 @pytest.mark.parametrize("fold", [0, 1])

@@ -560,6 +560,21 @@ def test_overlapped_gradient_reduction_equals_the_plain_one():
         dist.destroy_process_group()
 
 
+def test_overlapped_reduction_is_not_armed_when_a_gradient_is_detached_from_the_arena():
+    """The layer events mean "final in the arena" only when the backward adds straight into the parameters' own .grad views
+    (gradient-sink path).  With one .grad replaced by a non-contiguous tensor the backward goes through autograd's accumulation,
+    which runs after the events: CPTrainer must then refuse to arm (plain reduction after the backward)."""
+    from outfitx_amd.trainer import CPTrainConfig, CPTrainer
+    m = make_model("bf16")
+    tr = CPTrainer(m, steps_per_epoch=2, cfg=CPTrainConfig(learning_rate=1e-3, accumulation_steps=1, n_epochs=1, fused_optimizer=False),
+                   params=list(trainable(m).values()))
+    tr._world = lambda: 2
+    assert m.sink_ready() and tr._arm_overlap()
+    w = m.transformer_encoder.layers[2].linear1.weight
+    w.grad = torch.zeros(w.shape[1], w.shape[0], device=w.device).t()        # same shape, not contiguous: no longer an arena view
+    assert not m.sink_ready() and not tr._arm_overlap()
+
+
 def test_rccl_packed_record_allgather_world1():
     """parallel.sharded_topk's ONE collective - all_gather_into_tensor of the packed (global index int64 | distance fp32) byte record -
     on RCCL itself (a world-size-1 group on this device: the byte dtype and the flat-output form are what must be accepted), and the
