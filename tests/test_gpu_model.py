@@ -712,13 +712,14 @@ def _bench_batch():
     return _BENCH_BATCH
 
 
-@pytest.mark.parametrize("wseed", [7, 44, 89, 97, 99])
+@pytest.mark.parametrize("wseed", [7, 17, 44, 75, 89, 97, 99])
 def test_cfg2_bench_batch_within_1e3_of_the_reference(wseed):
     """The configuration bench.py times - 256 outfits x 8 items, so every ViT GEMM runs through the persistent 256x256 kernels and
     not the 128x128 split-K paths of the 8-outfit tests - in the default scheme, ALL 256 CP logits against the reference ITSELF
     (src.models.OutfitX._cp_forward with encoder_input_dict, outfit_x.py:120-144, on the CPU in fp32: tests/golden/
-    cfg2_bench_logits.npz from oracle/gen_bench_golden.py).  Weight seeds: the bench's (7) and the four worst of the round-2
-    sweeps (44, 89, 97, 99: draws whose logits are all small).  Metric and bound: the north star's max|d| / max|ref| over the
+    cfg2_bench_logits.npz from oracle/gen_bench_golden.py).  Weight seeds: the bench's (7), the four worst of the round-2
+    sweeps (44, 89, 97, 99: draws whose logits are all small) and the two worst of round 3's sweep of all hundred at this batch size (75:
+    8.5e-4, 17: 6.5e-4; profiles/r03_seed_sweep_bench_scale.json: median 2.7e-4, 90th percentile 4.7e-4, none at or above 1e-3).  Metric and bound: the north star's max|d| / max|ref| over the
     batch <= 1e-3."""
     if not torch.cuda.is_available():
         pytest.skip("needs a HIP device")

@@ -55,6 +55,14 @@ for r in csv.DictReader(open(fs[-1])):
 sq, sq_calls = counters("sq")
 fe, _ = counters("fetch")
 wr, _ = counters("write")
+sq2, _ = counters("sq2")          # optional pass: where the waves' cycles go
+# algorithmic bytes per launch by kernel, from the un-profiled bench line of the same build (roofline.per_kernel)
+alg = {}
+try:
+    bl = json.load(open(os.path.join(P, "bench_line.json")))
+    alg = {k: v["algorithmic_mb_per_launch"] * 1e6 for k, v in bl["roofline"]["per_kernel"].items()}
+except Exception:
+    bl = None
 rows = []
 tot = {"ns": 0.0, "busy": 0.0, "gui": 0.0, "mops": 0.0, "bytes": 0.0}
 for k, s in sorted(stats.items(), key=lambda kv: -kv[1]["total_ns"]):
@@ -69,6 +77,18 @@ for k, s in sorted(stats.items(), key=lambda kv: -kv[1]["total_ns"]):
            "mfma_util": round(busy / (gui * 1024.0), 4) if gui else None,
            "mfma_tflops_executed": round(mops * scale / t / 1e12, 1) if mops else 0.0,
            "hbm_bytes_per_call": round(byts / max(s["calls"], 1)), "hbm_gb_s": round(byts / t / 1e9, 1) if byts else 0.0}
+    norm = lambda n: n.replace("<f16,", "<").replace("<bf16,", "<").replace("<f16>", "").replace("<bf16>", "").replace(" ", "")
+    for name, b in alg.items():          # the bench names kernels without the operand type: gemm_big_kernel<2,2,1>, gemm_w2f8_kernel, ...
+        if norm(name) == norm(k):
+            row["algorithmic_bytes_per_call"] = round(b); row["traffic_over_algorithmic"] = round(row["hbm_bytes_per_call"] / b, 3) if b else None
+    c2 = sq2.get(k, {})
+    if c2.get("SQ_WAVE_CYCLES"):
+        wc = c2["SQ_WAVE_CYCLES"]
+        row["wave_cycle_shares"] = {"wait_any": round(c2.get("SQ_WAIT_ANY", 0.0) / wc, 3), "wait_inst_any": round(c2.get("SQ_WAIT_INST_ANY", 0.0) / wc, 3),
+                                    "active_inst_any": round(c2.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 3)}
+        row["lds_bank_conflict_over_lds_active"] = round(c2.get("SQ_LDS_BANK_CONFLICT", 0.0) / c2["SQ_LDS_IDX_ACTIVE"], 4) if c2.get("SQ_LDS_IDX_ACTIVE") else None
+        if "SQ_INSTS_VALU_MFMA_MOPS_F8" in c2:
+            row["mfma_mops_f8"] = c2["SQ_INSTS_VALU_MFMA_MOPS_F8"]
     rows.append(row)
     tot["ns"] += s["total_ns"]; tot["busy"] += busy; tot["gui"] += gui; tot["mops"] += mops * scale; tot["bytes"] += byts
 gemm = [r for r in rows if "gemm" in r["kernel"] or "fused_qkv" in r["kernel"]]
@@ -85,4 +105,7 @@ print(json.dumps({
                   "mfma_tflops_executed": round(tot["mops"] / (tot["ns"] * 1e-9) / 1e12, 1), "hbm_gb_s": round(tot["bytes"] / (tot["ns"] * 1e-9) / 1e9, 1)},
     "gemm_kernels": {"launches": g_calls, "avg_launch_us": round(g_ns / 1e3 / max(g_calls, 1), 2), "gemm_hbm_bytes_per_launch": round(g_bytes / max(g_calls, 1)),
                      "hbm_gb_s": round(g_bytes / (g_ns * 1e-9) / 1e9, 1) if g_ns else 0.0},
+    "per_kernel_traffic": {r["kernel"]: {"hbm_bytes_per_call": r["hbm_bytes_per_call"], "algorithmic_bytes_per_call": r.get("algorithmic_bytes_per_call"),
+                                         "traffic_over_algorithmic": r.get("traffic_over_algorithmic")} for r in gemm},
+    "bench_line_of_the_same_build": ({k: bl[k] for k in ("value", "ms_per_step")} if bl else None),
     "kernels": rows}, indent=1))
