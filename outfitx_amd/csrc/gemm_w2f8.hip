@@ -57,7 +57,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const char* base, si
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(bytes < 0x7fffffff ? bytes : 0x7fffffff), 0x00020000);
 }
 
-template <int ABL = 0>      // ABL (make DIAG=1; wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads after step 0, 3 both, 4 no fp8 product
+template <int ABL = 0>      // ABL (make DIAG=1; wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads after step 0, 3 both, 4 no fp8 product, 5 LDS-DMA + barriers only (no reads, no MFMA: the fill rate of this slot structure), 6 the same with the fragment reads
 __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
     typedef f16_t T;
     typedef OpT<T>::v8 v8;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
         a8[I][2 * (S)] = __builtin_bit_cast(int, lo_); a8[I][2 * (S) + 1] = __builtin_bit_cast(int, hi_);      \
     }
 #define OFX_F8_MFMA16(S)                                                                                      \
-    {                                                                                                         \
+    if (ABL < 5) {                                                                                                         \
         OFX_F8_PRIO_HI;                                                                      \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[i][j] = OpT<T>::mfma16(wh[j], af[i], acc[i][j]); \
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
         acc[i][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8_[(J) % 3], a8[i], acc[i][J], 0, 0, SEL, SC, 0, a_e8);
 #define OFX_F8_MFMA8()                                                                                      \
-    if (ABL != 4) {                                                                                           \
+    if (ABL != 4 && ABL < 5) {                                                                                \
         __builtin_amdgcn_sched_barrier(0);      /* the fp8 fragments take the registers the f16 fragments leave: no hoisting above */ \
         OFX_LDS char* b8_ = lds + W8BASE;                                                                     \
         i32x8 w8_[3];                                                                                         \
@@ -224,24 +224,26 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
         // the earliest).  The fp8 product of a super-step runs at the end of the MFMA slot of its fourth k-step.
 #define OFX_F8_ITER_G0(T_, S_, NV, ISSUE, TAIL)                                                                  \
         {                                                                                                        \
-            if (ABL == 0 || ABL == 2 || ABL == 4) { ISSUE; }                                                     \
-            if (ABL == 0 || ABL == 1 || ABL == 4 || (T_) == 0) OFX_F8_READ(T_)                                   \
+            if (ABL == 0 || ABL == 2 || ABL >= 4) { ISSUE; }                                                     \
+            if (ABL == 0 || ABL == 1 || ABL == 4 || ABL == 6 || (T_) == 0) OFX_F8_READ(T_)                                   \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+            if (ABL == 6) { _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(wh[j])); _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(af[i])); } \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
             __builtin_amdgcn_s_barrier();                                                                        \
             OFX_F8_MFMA16(S_)                                                                                    \
             TAIL                                                                                                 \
-            if (ABL == 0 || ABL == 2 || ABL == 4) asm volatile("s_waitcnt vmcnt(" #NV ")" ::: "memory");         \
+            if (ABL == 0 || ABL == 2 || ABL >= 4) asm volatile("s_waitcnt vmcnt(" #NV ")" ::: "memory");         \
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
             __builtin_amdgcn_s_barrier();                                                                        \
         }
 #define OFX_F8_ITER_G1(T_, S_, NV, ISSUE, TAIL)                                                                  \
         {                                                                                                        \
-            if (ABL == 0 || ABL == 2 || ABL == 4) { ISSUE; }                                                     \
-            if (ABL == 0 || ABL == 1 || ABL == 4 || (T_) == 0) OFX_F8_READ(T_)                                   \
-            if (ABL == 0 || ABL == 2 || ABL == 4) asm volatile("s_waitcnt vmcnt(" #NV ")" ::: "memory");         \
+            if (ABL == 0 || ABL == 2 || ABL >= 4) { ISSUE; }                                                     \
+            if (ABL == 0 || ABL == 1 || ABL == 4 || ABL == 6 || (T_) == 0) OFX_F8_READ(T_)                                   \
+            if (ABL == 0 || ABL == 2 || ABL >= 4) asm volatile("s_waitcnt vmcnt(" #NV ")" ::: "memory");         \
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+            if (ABL == 6) { _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(wh[j])); _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(af[i])); } \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
             __builtin_amdgcn_s_barrier();                                                                        \
             OFX_F8_MFMA16(S_)                                                                                    \
@@ -366,6 +368,8 @@ int ofx_gemm_launch_w2f8(void* kargs, int M, int N, hipStream_t s) {
     if (g_gemm_ablate == 2) return launch_w2f8<2>(k, M, N, s);
     if (g_gemm_ablate == 3) return launch_w2f8<3>(k, M, N, s);
     if (g_gemm_ablate == 4) return launch_w2f8<4>(k, M, N, s);
+    if (g_gemm_ablate == 5) return launch_w2f8<5>(k, M, N, s);
+    if (g_gemm_ablate == 6) return launch_w2f8<6>(k, M, N, s);
 #endif
     return launch_w2f8<0>(k, M, N, s);
 }

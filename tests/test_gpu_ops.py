@@ -88,10 +88,11 @@ def test_gemm_split_weights(force, dt, M, N, K):
     assert rel_err(out.cpu().numpy(), want) < 2e-5
 
 
-@pytest.mark.parametrize("K", [64, 96, 192])
+@pytest.mark.parametrize("K", [64, 128, 192])
 def test_gemm_split_weights_persistent_grid_is_bit_identical_to_one_block_per_tile(K):
     """The persistent dual-weight kernel at its shallowest depths (K = 64: two k-steps per tile, both peeled iterations fetch the next
-    tile's steps and the first refill targets the previous tile's epilogue stage; K = 96: three) on a many-tile shape with a ragged
+    tile's steps and the first refill targets the previous tile's epilogue stage; K = 128: four; the dispatcher takes multiples of 64) on a
+    many-tile shape with a ragged
     tile count: grids of one block per tile (knob 11 = 0), one per CU (-1) and an odd 7 blocks must agree bit for bit, and with
     float64 arithmetic on the rounded operands."""
     M, N = 70000, 768

@@ -77,9 +77,15 @@ for k, s in sorted(stats.items(), key=lambda kv: -kv[1]["total_ns"]):
            "mfma_util": round(busy / (gui * 1024.0), 4) if gui else None,
            "mfma_tflops_executed": round(mops * scale / t / 1e12, 1) if mops else 0.0,
            "hbm_bytes_per_call": round(byts / max(s["calls"], 1)), "hbm_gb_s": round(byts / t / 1e9, 1) if byts else 0.0}
-    norm = lambda n: n.replace("<f16,", "<").replace("<bf16,", "<").replace("<f16>", "").replace("<bf16>", "").replace(" ", "")
-    for name, b in alg.items():          # the bench names kernels without the operand type: gemm_big_kernel<2,2,1>, gemm_w2f8_kernel, ...
-        if norm(name) == norm(k):
+    def same_kernel(bench_name, prof_name):          # bench: gemm_big_kernel<2,2,1>, gemm_w2f8_kernel; profiler: gemm_big_kernel<f16,2,2,1,0>, gemm_w2f8_kernel<0>
+        bb, _, ba = bench_name.partition("<"); pb, _, pa = prof_name.partition("<")
+        if bb.strip() != pb.strip():
+            return False
+        pa = re.sub(r"^(f16|bf16),?", "", pa)
+        return not ba or pa.startswith(ba.rstrip(">"))
+    for name, b in alg.items():
+        if same_kernel(name, k):
+            # several profiler variants (operand type, tile height) share one bench row: the per-launch figure is the row's average
             row["algorithmic_bytes_per_call"] = round(b); row["traffic_over_algorithmic"] = round(row["hbm_bytes_per_call"] / b, 3) if b else None
     c2 = sq2.get(k, {})
     if c2.get("SQ_WAVE_CYCLES"):
