@@ -57,7 +57,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const char* base, si
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(bytes < 0x7fffffff ? bytes : 0x7fffffff), 0x00020000);
 }
 
-template <int ABL = 0>      // ABL (make DIAG=1; wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads after step 0, 3 both, 4 no fp8 product, 5 LDS-DMA + barriers only (no reads, no MFMA: the fill rate of this slot structure), 6 the same with the fragment reads
+template <int ABL = 0>      // ABL (make DIAG=1; wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads after step 0, 3 both, 4 no fp8 product, 5 LDS-DMA + barriers only (no reads, no MFMA: the fill rate of this slot structure), 6 the same with the fragment reads, 7 the full kernel with SHADER_CYCLES stamps around its slots (tools/w2f8_slots.py)
 __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
     typedef f16_t T;
     typedef OpT<T>::v8 v8;
@@ -93,6 +93,11 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
     const float a_scale = p.a8_scale;
     const int a_e8 = p.a8_e8m0;
 
+    // DIAG (ABL 7): per wave, cycles summed over all iterations, [long slot (s = 3) ? 1 : 0][read+issue, wait at the mid barrier, MFMA slot, wait at the end barrier]
+    unsigned slot_cyc[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    unsigned long long st0_ = 0, st1_ = 0;
+#define OFX_F8_STAMP(V) if (ABL == 7) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(V) :: "memory");
+#define OFX_F8_ACC(S_, I) if (ABL == 7) { OFX_F8_STAMP(st1_) slot_cyc[(S_) == 3][I] += (unsigned)(st1_ - st0_); st0_ = st1_; }
     int vb = blockIdx.x, m0, n0;
     map_tile(vb, m0, n0);
     if (m0 >= p.M) return;
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
         a8[I][2 * (S)] = __builtin_bit_cast(int, lo_); a8[I][2 * (S) + 1] = __builtin_bit_cast(int, hi_);      \
     }
 #define OFX_F8_MFMA16(S)                                                                                      \
-    if (ABL < 5) {                                                                                                         \
+    if (ABL < 5 || ABL == 7) {                                                                                             \
         OFX_F8_PRIO_HI;                                                                      \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[i][j] = OpT<T>::mfma16(wh[j], af[i], acc[i][j]); \
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
         acc[i][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8_[(J) % 3], a8[i], acc[i][J], 0, 0, SEL, SC, 0, a_e8);
 #define OFX_F8_MFMA8()                                                                                      \
-    if (ABL != 4 && ABL < 5) {                                                                                \
+    if (ABL != 4 && (ABL < 5 || ABL == 7)) {                                                                                \
         __builtin_amdgcn_sched_barrier(0);      /* the fp8 fragments take the registers the f16 fragments leave: no hoisting above */ \
         OFX_LDS char* b8_ = lds + W8BASE;                                                                     \
         i32x8 w8_[3];                                                                                         \
@@ -224,31 +229,41 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
         // the earliest).  The fp8 product of a super-step runs at the end of the MFMA slot of its fourth k-step.
 #define OFX_F8_ITER_G0(T_, S_, NV, ISSUE, TAIL)                                                                  \
         {                                                                                                        \
+            OFX_F8_STAMP(st0_)                                                                                   \
             if (ABL == 0 || ABL == 2 || ABL >= 4) { ISSUE; }                                                     \
-            if (ABL == 0 || ABL == 1 || ABL == 4 || ABL == 6 || (T_) == 0) OFX_F8_READ(T_)                                   \
+            if (ABL == 0 || ABL == 1 || ABL == 4 || ABL >= 6 || (T_) == 0) OFX_F8_READ(T_)                                   \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+            OFX_F8_ACC(S_, 0)                                                                                    \
             if (ABL == 6) { _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(wh[j])); _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(af[i])); } \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
             __builtin_amdgcn_s_barrier();                                                                        \
+            OFX_F8_ACC(S_, 1)                                                                                    \
             OFX_F8_MFMA16(S_)                                                                                    \
             TAIL                                                                                                 \
+            OFX_F8_ACC(S_, 2)                                                                                    \
             if (ABL == 0 || ABL == 2 || ABL >= 4) asm volatile("s_waitcnt vmcnt(" #NV ")" ::: "memory");         \
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
             __builtin_amdgcn_s_barrier();                                                                        \
+            OFX_F8_ACC(S_, 3)                                                                                    \
         }
 #define OFX_F8_ITER_G1(T_, S_, NV, ISSUE, TAIL)                                                                  \
         {                                                                                                        \
+            OFX_F8_STAMP(st0_)                                                                                   \
             if (ABL == 0 || ABL == 2 || ABL >= 4) { ISSUE; }                                                     \
-            if (ABL == 0 || ABL == 1 || ABL == 4 || ABL == 6 || (T_) == 0) OFX_F8_READ(T_)                                   \
+            if (ABL == 0 || ABL == 1 || ABL == 4 || ABL >= 6 || (T_) == 0) OFX_F8_READ(T_)                                   \
             if (ABL == 0 || ABL == 2 || ABL >= 4) asm volatile("s_waitcnt vmcnt(" #NV ")" ::: "memory");         \
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+            OFX_F8_ACC(S_, 0)                                                                                    \
             if (ABL == 6) { _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(wh[j])); _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(af[i])); } \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
             __builtin_amdgcn_s_barrier();                                                                        \
+            OFX_F8_ACC(S_, 1)                                                                                    \
             OFX_F8_MFMA16(S_)                                                                                    \
             TAIL                                                                                                 \
+            OFX_F8_ACC(S_, 2)                                                                                    \
             __builtin_amdgcn_s_barrier();                                                                        \
+            OFX_F8_ACC(S_, 3)                                                                                    \
         }
 #define OFX_F8_W8_ALL(U) OFX_F8_ISSUE_W8(U, 0) OFX_F8_ISSUE_W8(U, 1) OFX_F8_ISSUE_W8(U, 2) OFX_F8_ISSUE_W8(U, 3)
         if (grp == 0) {
@@ -295,6 +310,14 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
         vb += gridDim.x; map_tile(vb, m0, n0); base = (base + nk) % NST; first = false;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the last tile's redundant fills have landed before the wave ends
+    if (ABL == 7 && p.dbg && (wave == 0 || wave == 4) && lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) p.dbg[(size_t)blockIdx.x * 16 + grp * 8 + a * 4 + b] = slot_cyc[a][b];
+    }
+#undef OFX_F8_STAMP
+#undef OFX_F8_ACC
 }
 
 template <int ABL = 0>
@@ -370,6 +393,7 @@ int ofx_gemm_launch_w2f8(void* kargs, int M, int N, hipStream_t s) {
     if (g_gemm_ablate == 4) return launch_w2f8<4>(k, M, N, s);
     if (g_gemm_ablate == 5) return launch_w2f8<5>(k, M, N, s);
     if (g_gemm_ablate == 6) return launch_w2f8<6>(k, M, N, s);
+    if (g_gemm_ablate == 7) return launch_w2f8<7>(k, M, N, s);
 #endif
     return launch_w2f8<0>(k, M, N, s);
 }
