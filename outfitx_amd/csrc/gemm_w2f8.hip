@@ -68,7 +68,8 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;           // 4 x 2 waves of 64 x 128; waves 0-3 (rows 0-127) are ping-pong group 0
-    const int grp = wave >> 2;
+    int grp = wave >> 2;
+    asm volatile("" : "+s"(grp));            // an opaque scalar: re-deriving it from threadIdx.x later costs a scratch reload, which drains the DMA queue
     const int Kh = p.K >> 1;                           // logical K; 2 Kh is the row stride (elements) of W = [hi | lo]
     p.K = Kh;
     if (p.m_dev) {
@@ -96,13 +97,17 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
     // DIAG (ABL 7): per wave, cycles summed over all iterations, [long slot (s = 3) ? 1 : 0][read+issue, wait at the mid barrier, MFMA slot, wait at the end barrier]
     unsigned slot_cyc[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
     unsigned long long st0_ = 0, st1_ = 0;
+    unsigned epi_cyc = 0, epi_tiles = 0, gap_cyc = 0;       // epilogue cycles summed over tiles; cycles from the end of an epilogue to the next tile's first barrier
 #define OFX_F8_STAMP(V) if (ABL == 7) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(V) :: "memory");
 #define OFX_F8_ACC(S_, I) if (ABL == 7) { OFX_F8_STAMP(st1_) slot_cyc[(S_) == 3][I] += (unsigned)(st1_ - st0_); st0_ = st1_; }
     int vb = blockIdx.x, m0, n0;
     map_tile(vb, m0, n0);
     if (m0 >= p.M) return;
     int base = 0;                                       // (global index of the current tile's step 0) mod 4
-    bool first = true;
+    bool first = true, full_prev = false;
+    // per-row E8M0 scale bytes of this wave's 128 columns: 8 bytes per lane (fragment j -> byte j); the NEXT tile's are requested before
+    // the epilogue, so that their latency is not paid at the top of every tile
+    unsigned long long sc8 = *(const unsigned long long*)(p.w8_scale + ((size_t)((n0 >> 7) + wc) * 16 + (lane & 15)) * 8);
     for (;;) {
         const bool has_next = vb + (int)gridDim.x < p.nwg;
         int ln = lane;
@@ -130,8 +135,6 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
         for (int i = 0; i < 2; ++i) a_off[i] = ((unsigned)((wave * 2 + i) * 16 + prow) * p.lda + pchk * 8) * 2;
         int m1 = m0, n1 = n0;                               // the next tile (the block's last tile re-fills its own first steps: nobody reads them)
         if (has_next) map_tile(vb + (int)gridDim.x, m1, n1);
-        // per-row E8M0 scale bytes of this wave's 128 columns: 8 bytes per lane (fragment j -> byte j), one 8-byte load per tile
-        const unsigned long long sc8 = *(const unsigned long long*)(p.w8_scale + ((size_t)((n0 >> 7) + wc) * 16 + fr) * 8);
         int sc_lo = (int)(unsigned)sc8, sc_hi = (int)(unsigned)(sc8 >> 32);
 
         // LDS-DMA pieces: the two A and two W_hi pieces of a k-step (KOFF = its byte offset in the k-contiguous rows) and quarter Q of
@@ -217,12 +220,19 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
             issue_step(0); issue_step(1);
             if (grp == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // step 0 landed (my pieces)
             else { issue_step(2); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        } else if (full_prev) {
+            // the next tile's first steps were issued BEFORE the previous epilogue, whose every variant issues at least 16 vector-memory
+            // operations per wave on a full tile (two or more 16-byte stores per 16-row pass, 8 passes; + the scale-byte load): all but the
+            // 16 youngest done = those steps have landed, while the stores drain under this tile's first slots (the counted waits of
+            // iteration 0 retire them in order)
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the steps fetched under the previous epilogue and that epilogue's stores
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // a ragged previous tile skipped stores: wait for everything
         }
         asm volatile("" : "+v"(sc_lo), "+v"(sc_hi));                  // the scale load is waited for HERE, not inside the counted-vmcnt loop
         asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");     // MODE.FP16_OVFL: f16 -> fp8 saturates at +-448 instead of NaN
         __builtin_amdgcn_s_barrier();                               // ---- end of slot 0
+        if (ABL == 7 && !first) { OFX_F8_STAMP(st1_) gap_cyc += (unsigned)(st1_ - st0_); }
         // One iteration of group 0 (slots 2t+1, 2t+2) / group 1 (slots 2t+2, 2t+3), as in gemm_w2.hip; NV = the LDS-DMA pieces the
         // iteration issues: its counted wait leaves exactly those in flight (everything issued by earlier iterations has landed: an
         // iteration t fills steps t + 2 / t + 3, read from iteration t + 2 on, and the fp8 quarters are read two iterations later at
@@ -267,23 +277,25 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
         }
 #define OFX_F8_W8_ALL(U) OFX_F8_ISSUE_W8(U, 0) OFX_F8_ISSUE_W8(U, 1) OFX_F8_ISSUE_W8(U, 2) OFX_F8_ISSUE_W8(U, 3)
         if (grp == 0) {
-            for (int u = 0; u < nsup; ++u) {
+            int u = 0;
+            do {                                                    // nsup >= 1: no trip-count guard (its flag ended up spilled, and a scratch reload drains the DMA queue)
                 const int t = 4 * u;
                 OFX_F8_ITER_G0(t, 0, 8, issue_step(t + 2); issue_step(t + 3), )
                 OFX_F8_ITER_G0(t + 1, 1, 4, OFX_F8_W8_ALL(u), )
                 OFX_F8_ITER_G0(t + 2, 2, 4, issue_step(t + 4), )
                 OFX_F8_ITER_G0(t + 3, 3, 4, issue_step(t + 5), OFX_F8_MFMA8())
-            }
+            } while (++u < nsup);
             __builtin_amdgcn_s_barrier();                           // closes group 1's last MFMA slot: every read of this tile's stages and fp8 buffer is done
         } else {
             __builtin_amdgcn_s_barrier();                           // slot 1: group 0 reads step 0
-            for (int u = 0; u < nsup; ++u) {
+            int u = 0;
+            do {                                                    // nsup >= 1: no trip-count guard (its flag ended up spilled, and a scratch reload drains the DMA queue)
                 const int t = 4 * u;
                 OFX_F8_ITER_G1(t, 0, 4, issue_step(t + 3), )
                 OFX_F8_ITER_G1(t + 1, 1, 4, OFX_F8_W8_ALL(u), )
                 OFX_F8_ITER_G1(t + 2, 2, 4, issue_step(t + 4), )
                 OFX_F8_ITER_G1(t + 3, 3, 8, issue_step(t + 5); issue_step(t + 6), OFX_F8_MFMA8())
-            }
+            } while (++u < nsup);
         }
 #undef OFX_F8_W8_ALL
 #undef OFX_F8_ITER_G0
@@ -304,9 +316,13 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
         const int gm0 = m0 + wr * 64, gn0 = n0 + wc * 128;
         OFX_LDS float* st = nullptr;
         if (p.row_stat && p.out_kind != 0) st = (OFX_LDS float*)(lds + W8BASE + wave * 1024);
+        sc8 = *(const unsigned long long*)(p.w8_scale + ((size_t)((n1 >> 7) + wc) * 16 + (ln & 15)) * 8);     // the next tile's scale bytes (this tile's own again on the last one)
+        OFX_F8_STAMP(st0_)
         epilogue2_dispatch<T, 4, 8, 0>(p, ep, acc, gm0, gn0, ln, st);
         epilogue2_dispatch<T, 4, 8, 4>(p, ep, acc, gm0, gn0 + 64, ln, st);
+        if (ABL == 7) { OFX_F8_STAMP(st1_) epi_cyc += (unsigned)(st1_ - st0_); ++epi_tiles; st0_ = st1_; }
         if (!has_next) break;
+        full_prev = m0 + TM <= p.M;
         vb += gridDim.x; map_tile(vb, m0, n0); base = (base + nk) % NST; first = false;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the last tile's redundant fills have landed before the wave ends
@@ -314,7 +330,8 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) p.dbg[(size_t)blockIdx.x * 16 + grp * 8 + a * 4 + b] = slot_cyc[a][b];
+            for (int b = 0; b < 4; ++b) p.dbg[(size_t)blockIdx.x * 32 + grp * 16 + a * 4 + b] = slot_cyc[a][b];
+        p.dbg[(size_t)blockIdx.x * 32 + grp * 16 + 8] = epi_cyc; p.dbg[(size_t)blockIdx.x * 32 + grp * 16 + 9] = epi_tiles; p.dbg[(size_t)blockIdx.x * 32 + grp * 16 + 10] = gap_cyc;
     }
 #undef OFX_F8_STAMP
 #undef OFX_F8_ACC
