@@ -257,7 +257,13 @@ def main():
     bms, bfl, bcnt = (C.c_double * 4)(), (C.c_double * 4)(), (C.c_longlong * 4)()
     L.check(lib.ofx_profile_read(bms, bfl, bcnt), "ofx_profile_read")
     lib.ofx_profile_enable(0)
+    rank_info = None
     if world > 1:
+        # whole-job time = the slowest rank's; every rank's own time, batch seed and host thread count travel to rank 0 for the line
+        mine = torch.tensor([elapsed, float(seed), float(torch.get_num_threads())], device="cpu" if rehearsal else dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rank_info = {"elapsed_s": [round(float(x[0]), 6) for x in allr], "batch_seeds": [int(x[1]) for x in allr], "host_threads": [int(x[2]) for x in allr]}
         t = torch.tensor([elapsed], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -367,6 +373,8 @@ def main():
                 "tflops_equiv_per_gpu": round(padded_outfit * B * a.steps / elapsed / 1e12, 2),
                 "frac_of_peak": round(padded_outfit * B * a.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS, 4)},
         }
+        if rank_info is not None:
+            res["ranks"] = dict(rank_info, note="value = all ranks' outfits / max(elapsed_s): the slowest rank sets the whole-job time")
         if a.cpu_outfits > 0 and world == 1:      # parity + CPU baseline: single-GPU-run data (rank 0, N = 1 only), outside the timed region
             try:
                 got_all = out.float().cpu().numpy().reshape(-1)

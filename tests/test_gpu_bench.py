@@ -44,7 +44,8 @@ def test_bench_two_ranks_rehearsal():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, OFX_BENCH_REHEARSAL="1", OMP_NUM_THREADS="4")
+    env = dict(os.environ, OFX_BENCH_REHEARSAL="1")
+    env.pop("OMP_NUM_THREADS", None)                               # bench.py caps its host threads per rank itself (host_cores() // world)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--outfits", "32"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
@@ -54,3 +55,7 @@ def test_bench_two_ranks_rehearsal():
     # whole-job aggregate: both ranks' outfits over the MAX-over-ranks time
     assert abs(j["value"] - 2 * 32 * 2 / (j["ms_per_step"] * 2e-3)) <= 1e-3 * j["value"]
     assert j["config"]["parallelism"].startswith("dp2")
+    rk = j["ranks"]
+    assert rk["batch_seeds"] == [1236, 1237]                       # rank-local batches (weak scaling: each rank scores its own outfits)
+    assert len(rk["elapsed_s"]) == 2 and abs(max(rk["elapsed_s"]) - j["ms_per_step"] * 2e-3) <= 2e-3 * max(rk["elapsed_s"])     # MAX over ranks is the job's time
+    assert all(t >= 1 for t in rk["host_threads"])
