@@ -1321,7 +1321,7 @@ extern "C" int ofx_focal_loss_ex(const float* logits, const float* labels, int B
 }
 
 // ------------------------------------------------------------------------------------- tuning
-extern int g_gemm_group_m, g_gemm_ablate, g_gemm_kernel, g_gemm_skew, g_gemm_pref, g_gemm_splitk, g_w2_persist, g_w2_fp8, g_w2_fp8_ashift;
+extern int g_gemm_group_m, g_gemm_ablate, g_gemm_kernel, g_gemm_skew, g_gemm_pref, g_gemm_splitk, g_w2_persist, g_w2_fp8, g_w2_fp8_ashift, g_w2_trim;
 extern unsigned long long* g_gemm_dbg;
 /* diagnostics: per-block {shader cycles, 100 MHz ticks} of the big-tile GEMM main loop go to buf (device, 16 B per block); NULL = off */
 extern "C" void ofx_debug_gemm_clock(void* buf) { g_gemm_dbg = (unsigned long long*)buf; }
@@ -1340,6 +1340,7 @@ extern "C" int ofx_tune(int knob, int value) {
         case 10: g_set_fuse = value; return OFX_OK;
         case 11: g_w2_persist = value; return OFX_OK;
         case 12: g_w2_fp8 = value; return OFX_OK;
+        case 14: g_w2_trim = value; return OFX_OK;
         case 13: if (value < -8 || value > 8) { ofx_set_error("ofx_tune(13): activation shift out of [-8, 8]"); return OFX_EINVAL; } g_w2_fp8_ashift = value; return OFX_OK;
         default: ofx_set_error("ofx_tune: unknown knob %d", knob); return OFX_EINVAL;
     }

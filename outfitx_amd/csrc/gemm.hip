@@ -212,6 +212,7 @@ unsigned long long* g_gemm_dbg = nullptr;   // diagnostics only
 int g_gemm_pref = 2;      // short-K big GEMMs: 0 -> 256x128 kernel, 1 -> 256x256, 2 -> 256x256 ping-pong
 int g_w2_fp8 = 1;         // split-weight GEMMs that carry an fp8 copy of their lo halves run the fp8 correction product (gemm_w2f8.hip); 0 = the f16 one, ofx_tune(12, v)
 int g_w2_fp8_ashift = 2;  // activations enter the fp8 product as e4m3(a 2^shift): 2 keeps |a| >= 2^-8 out of the subnormal step and saturates at 112, ofx_tune(13, v)
+int g_w2_trim = 0;        // 1: persistent split-weight GEMMs shrink their grid to the smallest one with the same round count (measured: +0.4 ms per step), ofx_tune(14, v)
 int g_w2_persist = -1;    // dual-weight kernel: persistent grid size (blocks walk tiles b, b + grid, ...): -1 = one block per CU of the device, 0 = one block per tile, ofx_tune(11, v)
 int g_gemm_skew = 0;      // start skew of the second co-resident block (x 8128 cycles), 256x128 kernel only
 int g_gemm_kernel = 0;    // 0 auto, 1 force 128x128, 2 force 256x256 (8 waves, 2 stages), 3 force 256x128 (4 waves, register-resident k-tile), 4 force 256x256 ping-pong, 6 force the dual-weight 256x256 kernel for split weights

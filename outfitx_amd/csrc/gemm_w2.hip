@@ -23,7 +23,7 @@
 // conflict-free for the hardware's lane groups of ds_read_b128 (MI355X_MICROARCH.md, LDS table).
 #include "gemm_common.h"
 
-extern int g_w2_persist;
+extern int g_w2_persist, g_w2_trim;
 namespace {
 
 template <typename T, int ABL = 0>      // ABL (make DIAG=1; wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads after step 0, 3 both
@@ -234,7 +234,10 @@ static int launch_w2(KArgs& k, int M, int N, hipStream_t s) {
         if (c == 0) { int v = 0; c = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256; }
         persist = c;
     }
-    const int grid = (persist && !k.m_dev && k.nwg > persist) ? persist : k.nwg;
+    int grid = (persist && !k.m_dev && k.nwg > persist) ? persist : k.nwg;
+    // ofx_tune(14, 1): the smallest grid that still finishes in the same number of rounds (1,200 or 3,600 tiles take 5 / 15 rounds on 256
+    // blocks and on 240 alike; the 16 CUs left alone would serve the side stream's text tower) - measured 0.4 ms per step SLOWER, off
+    if (g_w2_trim && grid < k.nwg) { const int rounds = (k.nwg + grid - 1) / grid; grid = (k.nwg + rounds - 1) / rounds; }
     OFX_PLAUNCH(true, (gemm_w2_kernel<T, ABL>), dim3(grid), dim3(512), LDSB, s, k);
     return OFX_OK;
 }
