@@ -13,14 +13,16 @@
 //     for the four k-steps of a super-step: fragment i's 8 VGPRs collect bytes 8 s + j <- k = 32 s + 8 g + j (s = k-step, g = lane
 //     >> 4) - a k-permutation inside the 128-block, harmless because the packed fp8 weights carry the same one (ofx_launch_pack_lo8);
 //   * the wave tile is 64 x 128 (8 waves as 4 x 2), so only 4 activation fragments = 32 VGPRs are held; the 8 weight fragments of the
-//     fp8 step stream through the registers the f16 fragments have just left (128 accumulators + 32 + 64 = 224);
+//     fp8 step stream through a 3-deep register ring loaded two fragments ahead of their use (128 accumulators + 32 + 24, in the
+//     registers the f16 fragments have just left);
 //   * per-row weight scales (E8M0, max |lo| 2^sw in [128, 256)) ride in as the instruction's per-lane scale operand, the activation
 //     scale (x4: values below 2^-8 would otherwise fall under the e4m3 subnormal step) as the other one.
 //
 // Structure: gemm_w2.hip's ping-pong (two wave groups one barrier slot apart, BK = 32, counted vmcnt, persistent over tiles) with FOUR
-// 32 KiB stages [A | W_hi] and ONE 32 KiB buffer for the current super-step's fp8 weights (160 KiB in all).  Every kernel of this
-// family runs at the rate the LDS-DMA fill sustains (~20 B/clk/CU: gemm_w2 with 48 KiB per k-step, this kernel's f16-only ablation
-// with 40 KiB and the single-product kernels with 32 KiB all take bytes / 20 B/clk), so what matters is that the fill never idles:
+// 32 KiB stages [A | W_hi] and ONE 32 KiB buffer for the current super-step's fp8 weights (160 KiB in all).  The kernels of this
+// family take time in proportion to the bytes they stage through LDS (~16-20 B/clk/CU: gemm_w2 with 48 KiB per k-step, this kernel
+// with 40 KiB, the single-product kernels with 32 KiB; DESIGN.md section 3.1: the fill itself needs that long, and every LDS-DMA
+// instruction costs the SIMD's multiplying wave ~65 cycles of issue), so what matters is that the fill never idles:
 // the MFMA slot that carries a super-step's fp8 product is three times as long as the others, and the read slot of the partner group
 // that runs beside it issues TWO k-steps of LDS-DMA (the fourth stage makes room: an iteration t may fill steps t + 2 and t + 3):
 //   group 0:  R0: steps t+2, t+3 (beside group 1's fp8 slot)   R1: the super-step's 4 fp8 quarters   R2: t+2   R3: t+2
@@ -57,7 +59,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const char* base, si
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(bytes < 0x7fffffff ? bytes : 0x7fffffff), 0x00020000);
 }
 
-template <int ABL = 0>      // ABL (make DIAG=1; wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads after step 0, 3 both, 4 no fp8 product, 5 LDS-DMA + barriers only (no reads, no MFMA: the fill rate of this slot structure), 6 the same with the fragment reads, 7 the full kernel with SHADER_CYCLES stamps around its slots (tools/w2f8_slots.py)
+template <int ABL = 0>      // ABL (make DIAG=1; wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads after step 0, 3 both, 4 no fp8 product, 5 LDS-DMA + barriers only (no reads, no MFMA: the fill rate of this slot structure), 6 the same with the fragment reads, 7 the full kernel with s_memtime stamps around its slots and epilogues (tools/w2f8_slots.py)
 __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
     typedef f16_t T;
     typedef OpT<T>::v8 v8;

@@ -116,6 +116,44 @@ def test_gemm_split_weights_persistent_grid_is_bit_identical_to_one_block_per_ti
     assert rel_err(outs[0].cpu().numpy(), A.double().cpu().numpy() @ Wv.T + bias.cpu().numpy()) < 2e-5
 
 
+def test_profile_records_carry_shape_kernel_and_algorithmic_bytes():
+    """ofx_profile_records (what bench.py's roofline block is built from): a GEMM launch is recorded with its logical shape, the
+    kernel that ran, its products per term and the ALGORITHMIC HBM bytes its own epilogue configuration implies - A once, the weight
+    rows as stored, per output element 2 B (operand type), 4 B + 4 B (fp32 with an fp32 residual), and for the fp8-correction kernel
+    2 B hi + 1 B lo per weight."""
+    import ctypes as C
+    lib = L.load()
+    g = np.random.default_rng(3)
+    M, N, K = 66000, 1024, 384
+    A = to_op(g.standard_normal((M, K), dtype=np.float32), "f16")
+    Wf = (g.standard_normal((N, K), dtype=np.float32) / np.float32(np.sqrt(K))).astype(np.float32)
+    W = to_op(Wf, "f16")
+    W2, _ = _split_w(Wf, "f16")
+    W8 = torch.zeros(N, K, dtype=torch.uint8, device="cuda"); sc = torch.zeros(N, dtype=torch.uint8, device="cuda")
+    L.check(lib.ofx_pack_lo8(W2.data_ptr(), W8.data_ptr(), sc.data_ptr(), N, K, stream()))
+    o16 = torch.empty(M, N, dtype=torch.float16, device="cuda"); o32 = torch.zeros(M, N, device="cuda")
+    lib.ofx_profile_enable(1)
+    try:
+        L.check(lib.ofx_gemm(A.data_ptr(), W.data_ptr(), o16.data_ptr(), None, None, M, N, K, K, N, 0, 0, 1, DT["f16"], stream()))
+        L.check(lib.ofx_gemm(A.data_ptr(), W.data_ptr(), o32.data_ptr(), None, o32.data_ptr(), M, N, K, K, N, N, 0, 0, DT["f16"], stream()))
+        L.check(lib.ofx_gemm_w2f8(A.data_ptr(), W2.data_ptr(), W8.data_ptr(), sc.data_ptr(), o16.data_ptr(), None, None, M, N, K, K, N, 0, 0, 1, stream()))
+        L.check(lib.ofx_gemm_w2(A.data_ptr(), W2.data_ptr(), o16.data_ptr(), None, None, M, N, K, K, N, 0, 0, 1, DT["f16"], stream()))
+        torch.cuda.synchronize()
+    finally:
+        lib.ofx_profile_enable(0)
+    recs = (L.ProfRecord * 16)()
+    n = lib.ofx_profile_records(recs, 16)
+    ms, fl, cnt = (C.c_double * 4)(), (C.c_double * 4)(), (C.c_longlong * 4)()
+    L.check(lib.ofx_profile_read(ms, fl, cnt))
+    assert n == 4
+    a_b, o2 = 2 * M * K, 2 * M * N
+    want = [(1, a_b + 2 * N * K + o2), (1, a_b + 2 * N * K + 8 * M * N), (2, a_b + 3 * N * K + o2), (2, a_b + 4 * N * K + o2)]
+    for r, (km, b) in zip(recs, want):
+        assert (r.cat, r.M, r.N, r.K, r.kmul) == (0, M, N, K, km) and r.bytes == b and r.ms > 0, (r.M, r.N, r.K, r.kmul, r.kind, r.bytes, b)
+    assert recs[2].kind == 8 and recs[3].kind == 6           # the fp8-correction kernel, the dual-weight f16 kernel
+    assert recs[2].flops == 0.75 * recs[3].flops               # matrix-pipe work in f16-rate equivalents: 1.5 products against 2
+
+
 def _e4m3_decode(b):
     """uint8 ndarray (OCP e4m3fn bit patterns) -> float64 values."""
     b = b.astype(np.int64)
