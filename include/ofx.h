@@ -165,7 +165,7 @@ int ofx_vit_b32_fwd_u8(ofx_handle* h, const uint8_t* src, const long long* offse
 /* ------------------------------------------------------------------ indexed (varlen) set input ("next" row N3) --- */
 /* The same encoder with the outfits given as ROW INDICES into a device-resident embedding table [n_table, ld] fp32
  * (the precomputed-embedding store kept in HBM) instead of a padded [B, L, D] tensor + mask: outfit b holds items
- * item_index[cu_items[b] .. cu_items[b+1]); cu_items[0] = 0; at most max_len (<= 31) items per outfit.  Replaces the
+ * item_index[cu_items[b] .. cu_items[b+1]); cu_items[0] = 0; at most max_len (<= 63; <= 31 for the training entry points) items per outfit.  Replaces the
  * reference's collate (outfit_x_base_processor.py:20-81: per-item torch.tensor + cat + stack, then a 12.6 MB/256-outfit
  * H2D copy) by a few KB of indices.  Bit-identical to the dense call on the same items.  Workspace: ofx_workspace_bytes
  * (OFX_OP_SET_ENCODER, B, max_len). */

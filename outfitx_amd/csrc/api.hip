@@ -211,7 +211,7 @@ extern "C" ofx_handle* ofx_create(int device, const ofx_model_desc* desc) {
     if (d.vit_width != d.vit_heads * 64 || d.txt_width != d.txt_heads * 64) return bad("tower head_dim must be 64");
     if (d.vit_width % 256 || d.txt_width % 256 || d.proj_dim % 128 || d.vit_mlp % 128 || d.txt_mlp % 128) return bad("tower dims must be multiples of 128/256");
     if (d.vit_image % d.vit_patch || (d.vit_image / d.vit_patch) * (d.vit_image / d.vit_patch) + 1 > 64) return bad("ViT sequence (patches+1) must be <= 64");
-    if (d.max_items < 0 || d.max_items > 31) return bad("max_items must be in [0,31]");
+    if (d.max_items < 0 || d.max_items > 63) return bad("max_items must be in [0,63]");
     if (d.tower_precision != OFX_PREC_BF16 && d.tower_precision != OFX_PREC_F16) return bad("tower_precision must be BF16 or F16");
     if (d.outfit_precision < 0 || d.outfit_precision > 2) return bad("bad outfit_precision");
     if (d.n_layers < 1 || d.vit_layers < 1 || d.txt_layers < 1 || d.d_ffn < 1) return bad("layer counts / d_ffn must be positive");
@@ -558,7 +558,7 @@ extern "C" int ofx_set_encoder_fwd(ofx_handle* h, const float* x, const uint8_t*
                                    int prefix_stride, int B, int L, float* out_row0, void* ws, size_t ws_bytes,
                                    ofx_stream stream) {
     OFX_REQUIRE(h && h->out_ready, OFX_ESTATE, "set_encoder_fwd: outfit weights not packed");
-    OFX_REQUIRE(B > 0 && L >= 0 && L <= 31, OFX_ESHAPE, "set_encoder_fwd: B=%d L=%d (L must be in [0,31])", B, L);
+    OFX_REQUIRE(B > 0 && L >= 0 && L <= 63, OFX_ESHAPE, "set_encoder_fwd: B=%d L=%d (L must be in [0,63])", B, L);
     OFX_REQUIRE((x || L == 0) && (pad_mask || L == 0) && out_row0 && ws, OFX_EINVAL, "set_encoder_fwd: NULL argument");
     SetInput in; in.x = x; in.pad_mask = pad_mask;
     return set_encoder_core(h, in, prefix, prefix_stride, B, L, out_row0, ws, ws_bytes, (hipStream_t)stream);
@@ -567,7 +567,7 @@ extern "C" int ofx_set_encoder_fwd_indexed(ofx_handle* h, const float* table, in
                                            const float* prefix, int prefix_stride, int B, int max_len, float* out_row0, void* ws, size_t ws_bytes,
                                            ofx_stream stream) {
     OFX_REQUIRE(h && h->out_ready, OFX_ESTATE, "set_encoder_fwd_indexed: outfit weights not packed");
-    OFX_REQUIRE(B > 0 && max_len >= 0 && max_len <= 31, OFX_ESHAPE, "set_encoder_fwd_indexed: B=%d max_len=%d (must be in [0,31])", B, max_len);
+    OFX_REQUIRE(B > 0 && max_len >= 0 && max_len <= 63, OFX_ESHAPE, "set_encoder_fwd_indexed: B=%d max_len=%d (must be in [0,63])", B, max_len);
     OFX_REQUIRE(table && item_index && cu_items && out_row0 && ws && n_table > 0, OFX_EINVAL, "set_encoder_fwd_indexed: NULL argument");
     SetInput in; in.table = table; in.ld = ld; in.n_table = n_table; in.item_index = item_index; in.cu_items = cu_items;
     return set_encoder_core(h, in, prefix, prefix_stride, B, max_len, out_row0, ws, ws_bytes, (hipStream_t)stream);
@@ -586,7 +586,7 @@ static int set_encoder_core(ofx_handle* h, const SetInput& in, const float* pref
     const int* m_dev = w.cu + B;
     // Small batches (split-K plans): the GEMMs' second passes ride on their consumers - the set attention sums the q | k | v slabs,
     // the out-proj / linear2 reduce also emits the LayerNorm that follows it - 8 launches per layer instead of 11 (g_set_fuse)
-    const bool fuse_att = (g_set_fuse & 1) != 0, fuse = (g_set_fuse & 2) != 0;
+    const bool fuse_att = (g_set_fuse & 1) != 0 && L + 1 <= 32, fuse = (g_set_fuse & 2) != 0;      // (the attention kernel sums split-K slabs for sets of <= 32 rows)
     bool ln1_done = false;                              // layer l's norm1 output already written by layer l-1's linear2 reduce
     for (int l = 0; l < d.n_layers; ++l) {
         const OutfitLayer& Ly = h->ol[l];

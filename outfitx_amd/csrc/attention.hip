@@ -566,7 +566,9 @@ int ofx_launch_attention_mfma(const AttnArgs& g, int op_dtype, hipStream_t s) {
 
 int ofx_launch_set_attention(const SetAttnArgs& g, int op_dtype, hipStream_t s) {
     OFX_REQUIRE(g.D == g.n_head * 64, OFX_ESHAPE, "set_attention: head_dim must be 64 (D=%d heads=%d)", g.D, g.n_head);
-    OFX_REQUIRE(g.max_len >= 1 && g.max_len <= (g.cu_seqlens ? 32 : 64), OFX_ESHAPE, "set_attention: %d rows per sequence exceed %d", g.max_len, g.cu_seqlens ? 32 : 64);
+    // 64 rows per sequence in both modes; the training features of varlen sets (hashed dropout keyed query * 32 + key, the split-K slab
+    // input, the backward kernel) stay at 32
+    OFX_REQUIRE(g.max_len >= 1 && g.max_len <= 64, OFX_ESHAPE, "set_attention: %d rows per sequence exceed 64", g.max_len);
     OFX_REQUIRE(g.max_len <= 32 || !g.drop.thresh, OFX_ESHAPE, "set_attention: dropout columns are keyed query * 32 + key");
     OFX_REQUIRE(g.ldo >= (g.out_kind == 2 ? 3 * g.D : g.D), OFX_ESHAPE, "set_attention: bad ldo=%d", g.ldo);
     OFX_REQUIRE(g.cu_seqlens || (g.fixed_len >= 1 && g.fixed_len <= g.max_len), OFX_EINVAL, "set_attention: needs cu_seqlens or a fixed length <= max_len");

@@ -232,7 +232,7 @@ class OutfitX(nn.Module):
             desc = L.default_desc()
             t = self.cfg.transformer
             desc.d_model, desc.n_head, desc.d_ffn, desc.n_layers = self.item_encoder.d_embed, t.n_head, t.d_ffn, t.n_layers
-            desc.max_items = min(self.cfg.max_length, 31)
+            desc.max_items = min(self.cfg.max_length, 63)
             desc.outfit_act = _activation_id(t.activation)
             desc.ln_eps = self.transformer_encoder.layers[0].norm1.eps
             eng = Engine(dev, desc, precision=precision)
@@ -276,7 +276,7 @@ class OutfitX(nn.Module):
         table = embedding_table if embedding_table is not None else getattr(self, "embedding_table", None)
         if table is None:
             raise ValueError("indexed input needs an embedding table: pass embedding_table= or call set_embedding_table()")
-        return table, item_index, cu_seqlens, int(max_len if max_len is not None else min(self.cfg.max_length, 31))
+        return table, item_index, cu_seqlens, int(max_len if max_len is not None else min(self.cfg.max_length, 63 if not (self.training and torch.is_grad_enabled()) else 31))
 
     def _cp_forward(self, outfit_embedding: Optional[torch.Tensor] = None, outfit_mask: Optional[torch.Tensor] = None,
                     encoder_input_dict: Optional[dict] = None, *, item_index: Optional[torch.Tensor] = None,

@@ -251,10 +251,11 @@ def test_small_batch_split_k_consumers_match_the_separate_passes(model):
 
 def test_edge_cases_empty_full_and_long_outfits(model):
     """Edge cases the collate can produce: outfits with 0 items (all slots masked), exactly full outfits, B = 1,
-    L = 31 (the kernel limit) and L = 0 (prefix token only)."""
+    L = 31, L = 40 and L = 63 (the scoring path's limit since round 3: the fp32 set attention takes 64 rows; the reference pads to the
+    batch maximum without a limit, outfit_x_base_processor.py:20-81) and L = 0 (prefix token only)."""
     CP, CIR = tasks()[0], tasks()[1]
     W = synth.outfit_transformer_weights(W_SEED)
-    for B, L, n in ((1, 16, [0]), (3, 16, [0, 16, 1]), (5, 31, [31, 0, 17, 30, 2]), (2, 1, [1, 0])):
+    for B, L, n in ((1, 16, [0]), (3, 16, [0, 16, 1]), (5, 31, [31, 0, 17, 30, 2]), (2, 1, [1, 0]), (4, 40, [40, 33, 5, 32]), (3, 63, [63, 1, 48])):
         emb, mask = synth.outfit_batch(71 + B, B, L, np.asarray(n))
         txt = synth.unit_rows(71, "t", B, 512)
         with torch.no_grad():
@@ -267,8 +268,8 @@ def test_edge_cases_empty_full_and_long_outfits(model):
         cp0 = model(task=CP, outfit_embedding=torch.zeros(4, 0, 1024, device="cuda"), outfit_mask=torch.zeros(4, 0, dtype=torch.bool, device="cuda"))
     want = O.cp_forward(np.zeros((4, 0, 1024), np.float32), np.zeros((4, 0), bool), W)
     assert rel_err(cp0.cpu().numpy(), want) < 1e-3
-    with pytest.raises(Exception):                               # beyond the 31-item kernel limit: loud failure, not garbage
-        model(task=CP, outfit_embedding=torch.zeros(1, 40, 1024, device="cuda"), outfit_mask=torch.zeros(1, 40, dtype=torch.bool, device="cuda"))
+    with pytest.raises(Exception):                               # beyond the 63-item kernel limit: loud failure, not garbage
+        model(task=CP, outfit_embedding=torch.zeros(1, 70, 1024, device="cuda"), outfit_mask=torch.zeros(1, 70, dtype=torch.bool, device="cuda"))
 
 
 def test_c_abi_error_codes():
