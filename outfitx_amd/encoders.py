@@ -353,6 +353,14 @@ class CLIPTextEncoder(_TowerBase):
         self._tok_name = model_name_or_path
         self.tokenizer = None
         self.dedup_texts = False      # opt-in: run the tower once per DISTINCT token row of a call (item texts are category names)
+        # opt-in, SURVEY.md section 8f N2: a PERSISTENT token-row -> embedding cache (Polyvore's item texts are 132 category strings): the
+        # tower runs on rows no earlier call has seen, everything else is a row gather from a device-resident table.  Dropped whenever a
+        # parameter of the tower changes (tensor version counters) or the normalize flag differs; host-resident token ids only.
+        self.cache_texts = False
+        self._cache_rows: dict = {}
+        self._cache_table: Optional[torch.Tensor] = None
+        self._cache_state = None
+        self.cache_tower_rows = 0     # rows the tower has computed through the cache (tests / diagnostics)
 
     def _desc(self) -> L.ModelDesc:
         d, c = L.default_desc(), self.model.config
@@ -417,12 +425,41 @@ class CLIPTextEncoder(_TowerBase):
         uniq_att = None if att is None else att.index_select(0, first_t)
         return uniq_ids.contiguous(), (None if uniq_att is None else uniq_att.contiguous()), torch.from_numpy(inv.astype(np.int64))
 
+    def _cache_plan(self, ids: torch.Tensor, att: Optional[torch.Tensor]):
+        """cache_texts: (table row per input row [n] int64, indices of the first occurrence of every row the table lacks, first new slot)."""
+        a = ids.numpy()
+        key = a if att is None else a * 2 + att.numpy().astype(a.dtype)
+        rows = np.empty(a.shape[0], np.int64)
+        miss, nxt = [], len(self._cache_rows)
+        for i in range(a.shape[0]):
+            k = key[i].tobytes()
+            r = self._cache_rows.get(k)
+            if r is None:
+                r = self._cache_rows[k] = nxt
+                nxt += 1
+                miss.append(i)
+            rows[i] = r
+        return rows, miss, nxt - len(miss)
+
     @torch.no_grad()
     def prepare(self, texts, tokenizer_kargs=None):
         """Host part of the text path (tokenise, optional de-duplication, EOS lengths, stage ids on the device).  ItemEncoder
         calls it before the image tower is enqueued so no blocking copy sits in the middle of the step."""
         ids, att, b = self._ids(texts, tokenizer_kargs)
         inverse = None
+        if self.cache_texts and ids.device.type == "cpu":
+            state = tuple(p._version for p in self.model.parameters())
+            if state != self._cache_state:                                          # the tower's weights changed: every cached row is stale
+                self._cache_rows, self._cache_table, self._cache_state = {}, None, state
+            rows, miss, slot0 = self._cache_plan(ids, att)
+            plan = {"rows": torch.from_numpy(rows).to(self.device, non_blocking=True), "slot0": slot0, "n_new": len(miss)}
+            if miss:
+                sel = torch.as_tensor(miss, dtype=torch.long)
+                m_ids = ids.index_select(0, sel).contiguous()
+                m_att = None if att is None else att.index_select(0, sel).contiguous()
+                plan["lengths"] = self._lengths(m_ids)
+                plan["ids"], plan["att"] = self._engine("text").stage_tokens(m_ids, m_att)
+            return None, None, None, b, plan
         dd = self._dedup(ids, att)
         if dd is not None:
             ids, att, inverse = dd
@@ -433,6 +470,22 @@ class CLIPTextEncoder(_TowerBase):
 
     def _run(self, ids, att, lengths, inverse, out: torch.Tensor, col: int, normalize: bool) -> None:
         eng = self._engine("text")
+        if isinstance(inverse, dict):                   # persistent cache: the tower on the new rows only, into their table slots; then one gather
+            plan, d = inverse, self.d_embed
+            if self._cache_table is not None and getattr(self, "_cache_norm", normalize) != normalize:
+                raise ValueError("cache_texts: the cache was filled with normalize=%s; clear it (set cache_texts again) before changing the flag" % (not normalize))
+            self._cache_norm = normalize
+            need = plan["slot0"] + plan["n_new"]
+            if self._cache_table is None or self._cache_table.shape[0] < need:
+                grown = torch.empty(max(need, 256, 2 * (0 if self._cache_table is None else self._cache_table.shape[0])), d, dtype=torch.float32, device=self.device)
+                if self._cache_table is not None:
+                    grown[:self._cache_table.shape[0]] = self._cache_table
+                self._cache_table = grown
+            if plan["n_new"]:
+                eng.text(plan["ids"], plan["att"], self._cache_table[plan["slot0"]:need], 0, normalize, plan["lengths"])
+                self.cache_tower_rows += plan["n_new"]
+            out[:, col:col + d] = self._cache_table.index_select(0, plan["rows"])
+            return
         if inverse is None:
             eng.text(ids, att, out, col, normalize, lengths)
             return
@@ -449,7 +502,7 @@ class CLIPTextEncoder(_TowerBase):
     @torch.no_grad()
     def forward(self, texts, normalize: bool = True, *args, **kwargs) -> torch.Tensor:
         ids, att, lengths, b, inverse = self.prepare(texts, kwargs.get("tokenizer_kargs"))
-        n = ids.shape[0] if inverse is None else inverse.shape[0]
+        n = inverse["rows"].shape[0] if isinstance(inverse, dict) else (ids.shape[0] if inverse is None else inverse.shape[0])
         out = torch.empty(n, self.d_embed, dtype=torch.float32, device=self.device)
         self._run(ids, att, lengths, inverse, out, 0, normalize)
         return out.view(b, -1, self.d_embed)
@@ -513,7 +566,8 @@ class ItemEncoder(nn.Module):
                 with torch.cuda.stream(side):
                     b2 = self.text_enc.encode_into(texts, out, d, self.cfg.norm_out, prepared=prepared)
                 out.record_stream(side)
-                for t in prepared[:2]:
+                plan = prepared[4] if isinstance(prepared[4], dict) else {}
+                for t in list(prepared[:2]) + [plan.get("rows"), plan.get("ids"), plan.get("att")]:
                     if t is not None:
                         t.record_stream(side)
                 b = self.image_enc.encode_into(images, out, 0, self.cfg.norm_out)

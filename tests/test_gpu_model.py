@@ -562,6 +562,46 @@ def test_text_dedup_runs_the_tower_on_distinct_rows_only(model):
         assert rows.shape[0] > 1 and torch.equal(rows, rows[:1].expand_as(rows))
 
 
+def test_text_cache_runs_the_tower_on_unseen_rows_only_and_drops_on_weight_change(model):
+    """N2's persistent category-string cache (cache_texts, opt-in): across calls the tower computes a token row once; later calls
+    gather it from the device-resident table (bit-identical rows), new rows are appended, and a change of any tower parameter drops
+    the table.  Also through ItemEncoder with the text tower on its side stream."""
+    enc = model.item_encoder.text_enc
+    base_ids, base_att = synth.token_batch(93, 9, 64, synth.ragged_lengths(93, 9, 2, 20))
+    def tok(pick):
+        return {"input_ids": torch.from_numpy(base_ids[pick]).view(len(pick), 1, 64), "attention_mask": torch.from_numpy(base_att[pick]).view(len(pick), 1, 64)}
+    g = np.random.default_rng(5)
+    p1, p2 = g.integers(0, 6, 200), g.integers(3, 9, 150)               # the second call sees rows 3-5 again and 6-8 for the first time
+    with torch.no_grad():
+        plain1, plain2 = enc(tok(p1)).view(200, 512).clone(), enc(tok(p2)).view(150, 512).clone()
+        enc.cache_texts = True
+        try:
+            n0 = enc.cache_tower_rows
+            c1 = enc(tok(p1)).view(200, 512).clone()
+            assert enc.cache_tower_rows - n0 == len(set(p1.tolist()))
+            c2 = enc(tok(p2)).view(150, 512).clone()
+            assert enc.cache_tower_rows - n0 == len(set(p1.tolist()) | set(p2.tolist()))        # only the unseen rows ran
+            assert rel_err(c1.cpu().numpy(), plain1.cpu().numpy()) < 2e-2 and rel_err(c2.cpu().numpy(), plain2.cpu().numpy()) < 2e-2
+            for k in range(3, 6):                                       # a row cached by call 1 is the same bytes in call 2
+                assert torch.equal(c1[torch.from_numpy(p1 == k)][0], c2[torch.from_numpy(p2 == k)][0])
+            # through the item encoder (side stream): equal to the plain item encoder's text half
+            px = torch.from_numpy(synth.pixel_values(94, 6)).view(6, 1, 3, 224, 224).cuda()
+            items_c = model.item_encoder(px, tok(np.arange(6)))
+            enc.cache_texts = False
+            items_p = model.item_encoder(px, tok(np.arange(6)))
+            enc.cache_texts = True
+            assert rel_err(items_c[..., 512:].cpu().numpy(), items_p[..., 512:].cpu().numpy()) < 2e-2
+            # a parameter update invalidates the table
+            w = enc.model.text_projection.weight
+            before = enc.cache_tower_rows
+            w.add_(0.0)                                                 # an in-place update: bumps the tensor's version counter
+            enc(tok(p1))
+            assert enc.cache_tower_rows - before == len(set(p1.tolist()))
+        finally:
+            enc.cache_texts = False
+            enc._cache_rows, enc._cache_table, enc._cache_state = {}, None, None
+
+
 def test_cp_forward_replays_from_a_captured_hip_graph(model):
     """Every launch goes to torch's current stream and nothing in the call synchronises or allocates outside torch's
     allocator, so the precomputed-embedding CP forward can be stream-captured (torch.cuda.graph) and replayed: same logits,
