@@ -582,8 +582,10 @@ int ofx_launch_set_attention(const SetAttnArgs& g, int op_dtype, hipStream_t s) 
     ProfScope prof(PROF_ATTN, s);
 #define SA(T, N) do { if (g.qkv_op) hipLaunchKernelGGL((set_attention_kernel<T, N, T>), dim3(grid), dim3(64), 0, s, k); \
                       else hipLaunchKernelGGL((set_attention_kernel<T, N, float>), dim3(grid), dim3(64), 0, s, k); } while (0)
-    if (op_dtype == OFX_F16) { if (g.max_len <= 20) SA(f16_t, 20); else if (g.max_len <= 32) SA(f16_t, 32); else SA(f16_t, 64); }
-    else { if (g.max_len <= 20) SA(bf16_t, 20); else if (g.max_len <= 32) SA(bf16_t, 32); else SA(bf16_t, 64); }
+    // (8 rows: category-name texts computed to their EOS - a third of the 20-row variant's LDS, so 32 instead of 12 one-wave blocks per CU
+    // hide each other's load latency)
+    if (op_dtype == OFX_F16) { if (g.max_len <= 8) SA(f16_t, 8); else if (g.max_len <= 20) SA(f16_t, 20); else if (g.max_len <= 32) SA(f16_t, 32); else SA(f16_t, 64); }
+    else { if (g.max_len <= 8) SA(bf16_t, 8); else if (g.max_len <= 20) SA(bf16_t, 20); else if (g.max_len <= 32) SA(bf16_t, 32); else SA(bf16_t, 64); }
 #undef SA
     OFX_LAUNCH_CHECK();
     return OFX_OK;
