@@ -280,7 +280,7 @@ def main():
         # fraction of the dense peak, executed TF/s (x kmul: split weights run 2, three-product GEMMs 3 MFMA products per term),
         # algorithmic HBM bytes per launch as the launch's own epilogue configuration implies (ofx_prof_record.bytes)
         KIND = {1: "gemm_128x128_kernel", 2: "gemm_big_kernel<2,4,2>", 3: "gemm_big_kernel<2,2,1>", 4: "gemm_pp_kernel", 6: "gemm_w2_kernel",
-                7: "fused_qkv_attn_kernel (N = q|k|v columns; its attention FLOPs are not in useful_tflops)", 8: "gemm_w2f8_kernel"}
+                7: "fused_qkv_attn_kernel (N = q|k|v columns; its attention FLOPs are not in useful_tflops)", 8: "gemm_w2f8_kernel", 9: "gemm_x3_kernel"}
         shapes = {}
         for i in range(nrec):
             r = recs[i]

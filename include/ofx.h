@@ -249,6 +249,7 @@ int ofx_profile_records(ofx_prof_record* out, int cap);
  *          attention sums the q | k | v slabs; reduce + LayerNorm in one launch), 0 the separate reduce and LayerNorm launches;
  * knob 12: 1 (default) split-weight GEMMs with an fp8 copy of their lo halves run the fp8 correction product, 0 = the f16 one;
  * knob 13: log2 of the activation scale of that product (default 2).
+ * knob 15: three-product GEMMs: 1 (default) the operand-tiles-loaded-once kernel from 192 tiles on, 2 always, 0 never.
  * knob 14: 1 = the persistent split-weight GEMMs launch the smallest grid that finishes in the same number of rounds (the CUs left alone
  * serve the side stream's kernels); default 0 = one block per CU (the trimmed grid measured 0.4 ms per step slower).
  * knob 11: grid size of the persistent dual-weight GEMM (default -1 = one block per CU of the device, each walking its tiles and
@@ -263,6 +264,11 @@ int ofx_gemm(const void* A, const void* W, void* C, const float* bias, const flo
 /* The same against a SPLIT weight matrix W2 [N, 2K], row n = [hi(K) | lo(K)] (ofx_convert mode 3): C = A (hi + lo)^T + ... with one
  * copy of A - two MFMA products per weight, ~22 significant weight bits.  K multiple of 64. */
 int ofx_gemm_w2(const void* A, const void* W2, void* C, const float* bias, const float* resid, int M, int N, int K,
+                int lda, int ldc, int ldr, int act, int out_kind, int op_dtype, ofx_stream stream);
+/* Three-product GEMM: A3 [M, lda >= 3K] rows [hi | lo | hi], W3 [N, 3K] rows [hi | hi | lo] (ofx_convert mode 2), C = hi.hi + lo.hi + hi.lo.
+ * From 192 tiles of 256 x 128 on (ofx_tune(15, 2): always; 0: never) the kernel that stages each operand tile once (gemm_x3.hip), else the
+ * K-concatenated single-product kernels on K' = 3K.  K multiple of 32, N of 128. */
+int ofx_gemm_x3(const void* A3, const void* W3, void* C, const float* bias, const float* resid, int M, int N, int K,
                 int lda, int ldc, int ldr, int act, int out_kind, int op_dtype, ofx_stream stream);
 /* The same with the correction product A . lo^T on the block-scaled fp8 matrix instruction (2x the f16 rate; f16 operands only):
  * ofx_pack_lo8 turns the lo halves of W2 [N, 2K] into W8 [N, K] e4m3 bytes (per row scaled to max |lo| 2^sw in [128, 256), the

@@ -1321,7 +1321,7 @@ extern "C" int ofx_focal_loss_ex(const float* logits, const float* labels, int B
 }
 
 // ------------------------------------------------------------------------------------- tuning
-extern int g_gemm_group_m, g_gemm_ablate, g_gemm_kernel, g_gemm_skew, g_gemm_pref, g_gemm_splitk, g_w2_persist, g_w2_fp8, g_w2_fp8_ashift, g_w2_trim;
+extern int g_gemm_group_m, g_gemm_ablate, g_gemm_kernel, g_gemm_skew, g_gemm_pref, g_gemm_splitk, g_w2_persist, g_w2_fp8, g_w2_fp8_ashift, g_w2_trim, g_x3_kernel;
 extern unsigned long long* g_gemm_dbg;
 /* diagnostics: per-block {shader cycles, 100 MHz ticks} of the big-tile GEMM main loop go to buf (device, 16 B per block); NULL = off */
 extern "C" void ofx_debug_gemm_clock(void* buf) { g_gemm_dbg = (unsigned long long*)buf; }
@@ -1341,6 +1341,7 @@ extern "C" int ofx_tune(int knob, int value) {
         case 11: g_w2_persist = value; return OFX_OK;
         case 12: g_w2_fp8 = value; return OFX_OK;
         case 14: g_w2_trim = value; return OFX_OK;
+        case 15: g_x3_kernel = value; return OFX_OK;
         case 13: if (value < -8 || value > 8) { ofx_set_error("ofx_tune(13): activation shift out of [-8, 8]"); return OFX_EINVAL; } g_w2_fp8_ashift = value; return OFX_OK;
         default: ofx_set_error("ofx_tune: unknown knob %d", knob); return OFX_EINVAL;
     }
@@ -1356,6 +1357,12 @@ extern "C" int ofx_gemm(const void* A, const void* W, void* C, const float* bias
 extern "C" int ofx_gemm_w2(const void* A, const void* W2, void* C, const float* bias, const float* resid, int M, int N, int K,
                            int lda, int ldc, int ldr, int act, int out_kind, int op_dtype, ofx_stream stream) {
     GemmArgs g{}; g.A = A; g.W = W2; g.C = C; g.bias = bias; g.resid = resid; g.M = M; g.N = N; g.K = 2 * K; g.a_wrap = K; g.lda = lda; g.ldc = ldc;
+    g.ldr = ldr; g.act = act; g.out_kind = out_kind;
+    return ofx_launch_gemm(g, op_dtype, (hipStream_t)stream);
+}
+extern "C" int ofx_gemm_x3(const void* A3, const void* W3, void* C, const float* bias, const float* resid, int M, int N, int K,
+                           int lda, int ldc, int ldr, int act, int out_kind, int op_dtype, ofx_stream stream) {
+    GemmArgs g{}; g.A = A3; g.W = W3; g.C = C; g.bias = bias; g.resid = resid; g.M = M; g.N = N; g.K = 3 * K; g.k_mult = 3; g.lda = lda; g.ldc = ldc;
     g.ldr = ldr; g.act = act; g.out_kind = out_kind;
     return ofx_launch_gemm(g, op_dtype, (hipStream_t)stream);
 }

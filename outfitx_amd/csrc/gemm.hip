@@ -212,6 +212,8 @@ unsigned long long* g_gemm_dbg = nullptr;   // diagnostics only
 int g_gemm_pref = 2;      // short-K big GEMMs: 0 -> 256x128 kernel, 1 -> 256x256, 2 -> 256x256 ping-pong
 int g_w2_fp8 = 1;         // split-weight GEMMs that carry an fp8 copy of their lo halves run the fp8 correction product (gemm_w2f8.hip); 0 = the f16 one, ofx_tune(12, v)
 int g_w2_fp8_ashift = 2;  // activations enter the fp8 product as e4m3(a 2^shift): 2 keeps |a| >= 2^-8 out of the subnormal step and saturates at 112, ofx_tune(13, v)
+int g_x3_kernel = 1;      // three-product GEMMs (k_mult == 3: A rows [hi | lo | hi], W rows [hi | hi | lo]): 1 = the operand-tiles-loaded-once 256x128 kernel
+                          // (gemm_x3.hip) from 192 tiles on, 2 = always, 0 = the K-concatenated single-product kernels; ofx_tune(15, v)
 int g_w2_trim = 0;        // 1: persistent split-weight GEMMs shrink their grid to the smallest one with the same round count (measured: +0.4 ms per step), ofx_tune(14, v)
 int g_w2_persist = -1;    // dual-weight kernel: persistent grid size (blocks walk tiles b, b + grid, ...): -1 = one block per CU of the device, 0 = one block per tile, ofx_tune(11, v)
 int g_gemm_skew = 0;      // start skew of the second co-resident block (x 8128 cycles), 256x128 kernel only
@@ -273,16 +275,19 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
         else if (g.N % 128 == 0 && t3 >= 512) kind = 3;                    // short K / mid-size M: 256x128, two blocks per CU
         else kind = 1;
     }
+    if (g.k_mult == 3 && !g.a_wrap && g_x3_kernel && g_gemm_kernel == 0 && g.K % 96 == 0 && g.N % 128 == 0 && g.lda >= g.K &&
+        (g_x3_kernel >= 2 || (long)((g.M + 255) / 256) * (g.N / 128) >= 192))
+        kind = 9;                  // the three products from ONE copy of each operand tile
     if ((kind == 2 || kind == 4) && g.N % 256) kind = 1;
     if (kind == 5 && g.N % 128) kind = 1;
     // record label: logical shape (K without the split-weight / three-product concatenation), the K multiplier and
-    // kernel kind (1 128x128 [+ split-K / 64-row variants], 2 256x256, 3 256x128, 4 256x256 ping-pong, 6 dual-weight 256x256, 8 the same with the fp8 correction product)
+    // kernel kind (1 128x128 [+ split-K / 64-row variants], 2 256x256, 3 256x128, 4 256x256 ping-pong, 6 dual-weight 256x256, 8 the same with the fp8 correction product, 9 three-product 256x128 with the operand tiles loaded once)
     if (g_ofx_prof_on) {
         const int km = g.a_wrap ? g.K / g.a_wrap : (g.k_mult > 0 ? g.k_mult : 1);
         // algorithmic HBM bytes of this launch: A once (its k index wraps over a_wrap columns for split weights), the weight rows as
         // stored, and per output element what the configured epilogue moves: fp32 4 (+4 residual read, +2 operand copy), operand
         // type 2 (in-place (hi, lo) stream: 4 read + 4 written), [hi | lo | hi] 6, +4 pre-activation tape copy
-        const double ab = 2.0 * g.M * (g.a_wrap ? g.a_wrap : g.K), wb = kind == 8 ? 3.0 * g.N * g.a_wrap : 2.0 * g.N * g.K;      // kind 8 reads the hi rows (2 B) + the fp8 lo rows (1 B)
+        const double ab = kind == 9 ? 2.0 * g.M * (g.K / 3) * 2 : 2.0 * g.M * (g.a_wrap ? g.a_wrap : g.K), wb = kind == 8 ? 3.0 * g.N * g.a_wrap : (kind == 9 ? 2.0 * g.N * (g.K / 3) * 2 : 2.0 * g.N * g.K);      // kind 8 reads the hi rows (2 B) + the fp8 lo rows (1 B)
         double ob = g.out_kind == 0 ? 4.0 : (g.out_kind == 2 ? 6.0 : 2.0);
         if (g.xlo) ob = 8.0;
         else { if (g.resid) ob += 4.0; if (g.xb_out) ob += 2.0; }
@@ -291,10 +296,11 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
     }
     // executed FLOPs in f16-rate equivalents: the fp8 correction product of kind 8 runs at twice the f16 rate (1.5 products, not 2)
     ProfScope prof(PROF_GEMM, s, 2.0 * g.M * g.N * g.K * (kind == 8 ? 0.75 : 1.0), true);      // events ride on the launches (OFX_PLAUNCH)
-    if (kind == 2 || kind == 3 || kind == 4 || kind == 6 || kind == 8) {
+    if (kind == 2 || kind == 3 || kind == 4 || kind == 6 || kind == 8 || kind == 9) {
         k.group_m = g_gemm_group_m > 0 ? g_gemm_group_m : (kind == 3 ? 4 : 8);
         int rc;
         if (kind == 8) { k.W8 = (const char*)g.W8; k.w8_scale = (const char*)g.w8_scale; k.a8_scale = ldexpf(1.0f, -g_w2_fp8_ashift); k.a8_e8m0 = 127 - g_w2_fp8_ashift; rc = ofx_gemm_launch_w2f8(&k, g.M, g.N, s); }
+        else if (kind == 9) rc = ofx_gemm_launch_x3(&k, op_dtype, g.M, g.N, s);
         else if (kind == 6) rc = ofx_gemm_launch_w2(&k, op_dtype, g.M, g.N, s);
         else if (kind == 4) rc = ofx_gemm_launch_pp(&k, op_dtype, g.M, g.N, s);
         else rc = ofx_gemm_launch_big(&k, kind, g_gemm_ablate, op_dtype, g.M, g.N, s);

@@ -404,3 +404,4 @@ int ofx_gemm_launch_big(void* kargs, int kind, int ablate, int op_dtype, int M, 
 int ofx_gemm_launch_pp(void* kargs, int op_dtype, int M, int N, hipStream_t s);
 int ofx_gemm_launch_w2(void* kargs, int op_dtype, int M, int N, hipStream_t s);
 int ofx_gemm_launch_w2f8(void* kargs, int M, int N, hipStream_t s);
+int ofx_gemm_launch_x3(void* kargs, int op_dtype, int M, int N, hipStream_t s);

@@ -154,6 +154,53 @@ def test_profile_records_carry_shape_kernel_and_algorithmic_bytes():
     assert recs[2].flops == 0.75 * recs[3].flops               # matrix-pipe work in f16-rate equivalents: 1.5 products against 2
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K,ep", [(1, 128, 64, 0), (255, 128, 64, 1), (300, 256, 512, 0), (1000, 512, 2048, 1), (16384, 1536, 512, 2), (40000, 640, 192, 1)])
+def test_gemm_three_products_from_operand_tiles_loaded_once(dt, M, N, K, ep):
+    """gemm_x3_kernel (forced: ofx_tune(15, 2); chosen by the dispatcher from 192 tiles on): activation rows [hi | lo | hi], weight rows
+    [hi | hi | lo], C = hi.hi + lo.hi + hi.lo with each operand tile staged once - against float64 arithmetic on the rounded operands,
+    and against the K-concatenated path (ofx_tune(15, 0)) on the same buffers (same products, another summation order).
+    ep: 0 fp32 output + bias, 1 fp32 residual in place, 2 operand-type output [hi | lo | hi] + bias."""
+    g = np.random.default_rng(M + 5 * N + K)
+    td = torch.bfloat16 if dt == "bf16" else torch.float16
+    Af = torch.from_numpy(g.standard_normal((M, K), dtype=np.float32)).cuda()
+    hi = Af.to(td); lo = (Af - hi.float()).to(td)
+    A3 = torch.cat([hi, lo, hi], 1).contiguous()
+    Wf = dev((g.standard_normal((N, K), dtype=np.float32) / np.float32(np.sqrt(K))).astype(np.float32))
+    W3 = torch.empty(N, 3 * K, dtype=td, device="cuda")
+    L.check(L.load().ofx_convert(Wf.data_ptr(), W3.data_ptr(), N, K, 2, DT[dt], stream()))
+    whi, wlo = W3[:, :K].double(), W3[:, 2 * K:].double()
+    assert torch.equal(W3[:, :K], W3[:, K:2 * K])
+    bias = dev(g.standard_normal(N, dtype=np.float32))
+    want = (hi.double() @ whi.T + lo.double() @ whi.T + hi.double() @ wlo.T).cpu().numpy()
+    lib = L.load()
+    outs = []
+    x0 = dev(g.standard_normal((M, N), dtype=np.float32))
+    for knob in (2, 0):
+        lib.ofx_tune(15, knob)
+        try:
+            if ep == 2:
+                out = torch.zeros(M, 3 * N, dtype=td, device="cuda")
+                L.check(lib.ofx_gemm_x3(A3.data_ptr(), W3.data_ptr(), out.data_ptr(), bias.data_ptr(), None, M, N, K, 3 * K, 3 * N, 0, 0, 2, DT[dt], stream()))
+                o = out.double().cpu().numpy()
+                assert np.array_equal(o[:, :N], o[:, 2 * N:])
+                got = o[:, :N] + o[:, N:2 * N]; ref = want + bias.double().cpu().numpy(); tol = 3e-5 if dt == "bf16" else 3e-6
+            elif ep == 1:
+                x = x0.clone()
+                L.check(lib.ofx_gemm_x3(A3.data_ptr(), W3.data_ptr(), x.data_ptr(), None, x.data_ptr(), M, N, K, 3 * K, N, N, 0, 0, DT[dt], stream()))
+                got = x.double().cpu().numpy(); ref = want + x0.double().cpu().numpy(); tol = 2e-5
+            else:
+                out = torch.full((M, N), float("nan"), device="cuda")
+                L.check(lib.ofx_gemm_x3(A3.data_ptr(), W3.data_ptr(), out.data_ptr(), bias.data_ptr(), None, M, N, K, 3 * K, N, 0, 0, 0, DT[dt], stream()))
+                got = out.double().cpu().numpy(); ref = want + bias.double().cpu().numpy(); tol = 2e-5
+            torch.cuda.synchronize()
+        finally:
+            lib.ofx_tune(15, 1)
+        assert rel_err(got, ref) < tol, (knob, rel_err(got, ref))
+        outs.append(got)
+    assert rel_err(outs[0], outs[1]) < 2 * tol
+
+
 def _e4m3_decode(b):
     """uint8 ndarray (OCP e4m3fn bit patterns) -> float64 values."""
     b = b.astype(np.int64)
