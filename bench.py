@@ -234,7 +234,9 @@ def main():
     # Live roofline sample: HIP events bracket every GEMM launch of ONE timed step (the middle one) on the launch
     # stream.  Bracketing all K steps costs ~1 ms/step of serialisation (246 event markers), so it is sampled.
     sample = a.steps // 2
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]      # one marker per step on torch's stream: the spread of the K steps
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(a.steps):
         if i == sample:
             model.item_encoder.overlap_towers = False        # per-launch events of concurrent kernels would count the shared time twice
@@ -243,8 +245,10 @@ def main():
         if i == sample:
             lib.ofx_profile_enable(0)
             model.item_encoder.overlap_towers = bool(a.overlap_towers)
+        marks[i + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
     recs = (L.ProfRecord * 4096)()
     nrec = lib.ofx_profile_records(recs, 4096)              # per-launch records of the sampled step (before read() clears them)
     ms, fl, cnt = (C.c_double * 4)(), (C.c_double * 4)(), (C.c_longlong * 4)()
@@ -334,6 +338,10 @@ def main():
             "unit": "outfits/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "step_ms_spread": {"min": round(min(per_step), 3), "median": round(sorted(per_step)[len(per_step) // 2], 3), "max": round(max(per_step), 3),
+                               "sampled_step": round(per_step[sample], 3),
+                               "note": "stream markers after each of the K timed steps (rank 0); the sampled step runs the towers on one stream with "
+                                       "every GEMM launch bracketed by events (the live roofline sample) and is inside the timed region"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": op,
             "data": "synthetic (seeded uniform-uint8 images after CLIP normalise, 8-token ids, random-init weights of the reference architecture)",

@@ -36,3 +36,5 @@ for rnd in range(5):
         torch.cuda.synchronize(); res[v].append((time.perf_counter() - t0) / 6)
 lib.ofx_tune(knob, vals[0])
 print("  ".join(f"knob{knob}={v}: {np.median(res[v]) * 1e3:.3f} ms" for v in vals), flush=True)
+for v in vals:
+    print(f"   knob{knob}={v} rounds: " + " ".join(f"{t * 1e3:.2f}" for t in res[v]), flush=True)
