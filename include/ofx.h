@@ -253,8 +253,13 @@ int ofx_profile_records(ofx_prof_record* out, int cap);
  * knob 14: 1 = the persistent split-weight GEMMs launch the smallest grid that finishes in the same number of rounds (the CUs left alone
  * serve the side stream's kernels); default 0 = one block per CU (the trimmed grid measured 0.4 ms per step slower).
  * knob 11: grid size of the persistent dual-weight GEMM (default -1 = one block per CU of the device, each walking its tiles and
- *          fetching the next tile's first k-steps under the current epilogue), 0 = one block per tile. */
+ *          fetching the next tile's first k-steps under the current epilogue), 0 = one block per tile.
+ * knob 16: 1 (default) gemm_x3_kernel launches one block per CU walking its tiles, 0 = one block per tile (short-lived blocks). */
 int ofx_tune(int knob, int value);
+/* A HIP stream of the LOWEST dispatch priority on `device` (hipStreamCreateWithPriority, non-blocking): the host mirror runs the text tower on it
+ * beside the ViT on the caller's stream, so that its workgroups take CUs only when the caller's stream has none ready.  Caller destroys it. */
+int ofx_stream_create_low_priority(int device, ofx_stream* out);
+int ofx_stream_destroy(ofx_stream stream);
 /* Diagnostics: when buf != NULL the big-tile GEMM writes {shader cycles, 100 MHz ticks} of its main loop per block (16 B each). */
 void ofx_debug_gemm_clock(void* buf);
 

@@ -69,6 +69,8 @@ _vp, _i, _f, _sz, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
 SIGNATURES = {
     "ofx_last_error": (C.c_char_p, []),
     "ofx_abi_version": (_i, []),
+    "ofx_stream_create_low_priority": (_i, [_i, C.POINTER(_vp)]),
+    "ofx_stream_destroy": (_i, [_vp]),
     "ofx_default_desc": (None, [C.POINTER(ModelDesc)]),
     "ofx_create": (_vp, [_i, C.POINTER(ModelDesc)]),
     "ofx_destroy": (None, [_vp]),

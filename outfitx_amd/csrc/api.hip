@@ -21,6 +21,24 @@ void ofx_set_error(const char* fmt, ...) {
 }
 extern "C" const char* ofx_last_error(void) { return g_err; }
 extern "C" int ofx_abi_version(void) { return OFX_ABI_VERSION; }
+extern "C" int ofx_stream_create_low_priority(int device, ofx_stream* out) {
+    OFX_REQUIRE(out, OFX_EINVAL, "stream_create_low_priority: NULL argument");
+    int prev = 0, least = 0, greatest = 0;
+    OFX_HIP(hipGetDevice(&prev));
+    OFX_HIP(hipSetDevice(device));
+    hipStream_t s = nullptr;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);          // numerically larger = lower priority
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least);
+    (void)hipSetDevice(prev);
+    OFX_HIP(e);
+    *out = (ofx_stream)s;
+    return OFX_OK;
+}
+extern "C" int ofx_stream_destroy(ofx_stream stream) {
+    OFX_REQUIRE(stream, OFX_EINVAL, "stream_destroy: NULL stream");
+    OFX_HIP(hipStreamDestroy((hipStream_t)stream));
+    return OFX_OK;
+}
 
 // ------------------------------------------------------------------------------- profiling
 bool g_ofx_prof_on = false;
@@ -1321,7 +1339,7 @@ extern "C" int ofx_focal_loss_ex(const float* logits, const float* labels, int B
 }
 
 // ------------------------------------------------------------------------------------- tuning
-extern int g_gemm_group_m, g_gemm_ablate, g_gemm_kernel, g_gemm_skew, g_gemm_pref, g_gemm_splitk, g_w2_persist, g_w2_fp8, g_w2_fp8_ashift, g_w2_trim, g_x3_kernel;
+extern int g_gemm_group_m, g_gemm_ablate, g_gemm_kernel, g_gemm_skew, g_gemm_pref, g_gemm_splitk, g_w2_persist, g_w2_fp8, g_w2_fp8_ashift, g_w2_trim, g_x3_kernel, g_x3_persist;
 extern unsigned long long* g_gemm_dbg;
 /* diagnostics: per-block {shader cycles, 100 MHz ticks} of the big-tile GEMM main loop go to buf (device, 16 B per block); NULL = off */
 extern "C" void ofx_debug_gemm_clock(void* buf) { g_gemm_dbg = (unsigned long long*)buf; }
@@ -1342,6 +1360,7 @@ extern "C" int ofx_tune(int knob, int value) {
         case 12: g_w2_fp8 = value; return OFX_OK;
         case 14: g_w2_trim = value; return OFX_OK;
         case 15: g_x3_kernel = value; return OFX_OK;
+        case 16: g_x3_persist = value != 0; return OFX_OK;
         case 13: if (value < -8 || value > 8) { ofx_set_error("ofx_tune(13): activation shift out of [-8, 8]"); return OFX_EINVAL; } g_w2_fp8_ashift = value; return OFX_OK;
         default: ofx_set_error("ofx_tune: unknown knob %d", knob); return OFX_EINVAL;
     }

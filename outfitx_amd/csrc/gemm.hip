@@ -212,6 +212,7 @@ unsigned long long* g_gemm_dbg = nullptr;   // diagnostics only
 int g_gemm_pref = 2;      // short-K big GEMMs: 0 -> 256x128 kernel, 1 -> 256x256, 2 -> 256x256 ping-pong
 int g_w2_fp8 = 1;         // split-weight GEMMs that carry an fp8 copy of their lo halves run the fp8 correction product (gemm_w2f8.hip); 0 = the f16 one, ofx_tune(12, v)
 int g_w2_fp8_ashift = 2;  // activations enter the fp8 product as e4m3(a 2^shift): 2 keeps |a| >= 2^-8 out of the subnormal step and saturates at 112, ofx_tune(13, v)
+int g_x3_persist = 1;     // ofx_tune(16, v): 1 (default) gemm_x3_kernel launches one block per CU walking its tiles (when it has more tiles than CUs), 0 = one block per tile
 int g_x3_kernel = 1;      // three-product GEMMs (k_mult == 3: A rows [hi | lo | hi], W rows [hi | hi | lo]): 1 = the operand-tiles-loaded-once 256x128 kernel
                           // (gemm_x3.hip) from 192 tiles on, 2 = always, 0 = the K-concatenated single-product kernels; ofx_tune(15, v)
 int g_w2_trim = 0;        // 1: persistent split-weight GEMMs shrink their grid to the smallest one with the same round count (measured: +0.4 ms per step), ofx_tune(14, v)

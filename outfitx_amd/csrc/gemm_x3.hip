@@ -14,7 +14,7 @@
 // the epilogue; LDS-DMA through buffer resources as in gemm_w2f8.hip (rows past M read zeros).
 #include "gemm_common.h"
 
-extern int g_w2_persist;
+extern int g_w2_persist, g_x3_persist;
 namespace {
 
 __device__ __forceinline__ void x3_bload16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, OFX_LDS char* l) {
@@ -177,7 +177,7 @@ static int launch_x3(KArgs& k, int M, int N, hipStream_t s) {
         return OFX_OK;
     }));
     k.tiles_n = N / 128; k.tiles_m = (M + 255) / 256; k.nwg = k.tiles_m * k.tiles_n;
-    int persist = g_w2_persist;
+    int persist = g_x3_persist == 1 ? g_w2_persist : 0;            // ofx_tune(16, 0): one block per tile (short-lived blocks: a side stream's GEMM then frees its CUs tile by tile)
     if (persist < 0) {
         static int cus[64] = {0};
         int dev = 0;

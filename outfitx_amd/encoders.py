@@ -11,6 +11,7 @@ The nn.Linear / nn.LayerNorm / nn.Embedding / nn.Conv2d objects below are PARAME
 """
 from __future__ import annotations
 
+import ctypes as C
 import itertools
 import warnings
 from types import SimpleNamespace
@@ -523,13 +524,23 @@ class ItemEncoder(nn.Module):
         # side-stream text tower: its small kernels fill the tile-quantisation tails of the big ViT GEMMs.  Neutral with round 1's
         # 1.3 ms single-product text tower; with the three-product one (5 ms) 31.85 vs 32.85 ms per cfg2 step (bench.py --overlap-towers)
         self.overlap_towers = True
+        self.side_stream_priority = "normal"        # "low": a lowest-priority HIP stream for the text tower (tools/overlap_ab.py)
         self._streams: Dict[Any, Any] = {}
 
     def _side_stream(self, dev):
-        s = self._streams.get(dev)
+        key = (dev, self.side_stream_priority)
+        s = self._streams.get(key)
         if s is None:
-            s = torch.cuda.Stream(device=dev)
-            self._streams[dev] = s
+            if self.side_stream_priority == "low":
+                # lowest dispatch priority (torch's own pools stop at HIP's normal level): the text tower's workgroups take CUs
+                # only when the ViT's stream has none ready.  The raw stream lives as long as the process (one per device).
+                raw = C.c_void_p()
+                L.check(L.load().ofx_stream_create_low_priority(dev.index if dev.index is not None else torch.cuda.current_device(), C.byref(raw)),
+                        "ofx_stream_create_low_priority")
+                s = torch.cuda.ExternalStream(raw.value, device=dev)
+            else:
+                s = torch.cuda.Stream(device=dev)
+            self._streams[key] = s
         return s
 
     def __getstate__(self):

@@ -542,6 +542,31 @@ def test_layernorm_folding_matches_the_materialised_path(model):
             assert rel_err(a, b) < 2e-3
 
 
+def test_text_tower_side_stream_variants_are_bit_identical(model):
+    """The text tower beside the ViT: torch's side stream (default), a lowest-priority HIP stream from the C ABI
+    (ofx_stream_create_low_priority) and the towers back to back on one stream write the same embeddings bit for bit; so does the
+    three-product kernel with one block per tile (ofx_tune(16, 0)).  (tools/overlap_ab.py times the variants on the headline step.)"""
+    from outfitx_amd import _lib as L
+    enc = model.item_encoder
+    B, n = 24, 8                                               # 192 texts x 8 tokens: the text GEMMs take the gemm_x3_kernel path
+    px = cu(synth.pixel_values(77, B * n).reshape(B, n, 3, 224, 224))
+    ids, att = synth.token_batch(77, B * n, 64, 8)
+    texts = {"input_ids": torch.from_numpy(ids).view(B, n, 64), "attention_mask": torch.from_numpy(att).view(B, n, 64)}
+    outs = {}
+    try:
+        with torch.no_grad():
+            for name, overlap, prio, grid in (("default", True, "normal", 1), ("low", True, "low", 1), ("serial", False, "normal", 1), ("per_tile", True, "low", 0)):
+                enc.overlap_towers, enc.side_stream_priority = overlap, prio
+                L.check(L.load().ofx_tune(16, grid))
+                outs[name] = enc(px, texts).clone()
+                torch.cuda.synchronize()
+    finally:
+        enc.overlap_towers, enc.side_stream_priority = True, "normal"
+        L.load().ofx_tune(16, 1)
+    assert all(torch.equal(outs["default"], v) for v in outs.values())
+    assert (torch.device("cuda", torch.cuda.current_device()), "low") in enc._streams
+
+
 def test_text_dedup_runs_the_tower_on_distinct_rows_only(model):
     """N2 (item texts are 132 category names): with dedup_texts the tower runs once per distinct token row of a call; the
     embeddings equal the plain path to the operand-rounding floor and duplicates are bit-identical."""
