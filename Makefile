@@ -6,7 +6,7 @@ OBJ   := build/obj
 SRCS  := $(wildcard $(CSRC)/*.hip)
 OBJS  := $(patsubst $(CSRC)/%.hip,$(OBJ)/%.o,$(SRCS))
 LIB   := outfitx_amd/libofx_hip.so
-FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $(if $(DIAG),-DOFX_DIAG,)
+FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $(if $(DIAG),-DOFX_DIAG,) $(EXTRA)
 
 all: $(LIB)
 

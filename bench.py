@@ -153,8 +153,8 @@ def cpu_baseline(px, ids, att, n_items, cfg2_outfits):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--outfits", type=int, default=256, help="outfits per GPU per step")
     ap.add_argument("--items", type=int, default=8)
     ap.add_argument("--precision", default="bf16x3", help="outfit transformer MFMA operand format")

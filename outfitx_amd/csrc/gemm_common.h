@@ -246,7 +246,11 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
         }
         // FOLD 3: the residual stream is the operand-type pair (hi at xb_out == C, lo at xlo), 16 bytes of each per lane and row,
         // fetched two passes ahead and rewritten in place (every element is owned by exactly one lane of one block)
-        v8 rh[FOLD == 3 ? 3 : 1][2], rl[FOLD == 3 ? 3 : 1][2];
+#ifndef OFX_EP3_DEPTH
+#define OFX_EP3_DEPTH 2
+#endif
+        constexpr int D3 = OFX_EP3_DEPTH < NP ? OFX_EP3_DEPTH : NP;        // passes of the (hi, lo) stream in flight ahead of the one being rewritten
+        v8 rh[FOLD == 3 ? D3 + 1 : 1][2], rl[FOLD == 3 ? D3 + 1 : 1][2];
         auto fetch_hl = [&](int pass, v8 (&dh)[2], v8 (&dl)[2]) {
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
@@ -255,10 +259,13 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
                 dl[it] = *(const v8*)((const T*)p.xlo + (size_t)gm * p.N + gn);
             }
         };
-        if (FOLD == 3) { fetch_hl(0, rh[0], rl[0]); fetch_hl(1, rh[FOLD == 3 ? 1 : 0], rl[FOLD == 3 ? 1 : 0]); }
+        if (FOLD == 3) {
+#pragma unroll
+            for (int d = 0; d < D3; ++d) fetch_hl(d, rh[FOLD == 3 ? d : 0], rl[FOLD == 3 ? d : 0]);
+        }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            if (FOLD == 3 && i + 2 < NP) fetch_hl(i + 2, rh[FOLD == 3 ? (i + 2) % 3 : 0], rl[FOLD == 3 ? (i + 2) % 3 : 0]);
+            if (FOLD == 3 && i + D3 < NP) fetch_hl(i + D3, rh[FOLD == 3 ? (i + D3) % (D3 + 1) : 0], rl[FOLD == 3 ? (i + D3) % (D3 + 1) : 0]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) *(OFX_LDS f32x4*)(ep + fr * 256 + (((j * 4 + fq) ^ (fr & 7)) << 4)) = acc[i][J0 + j];
 #pragma unroll
@@ -289,7 +296,7 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
                         } else { v0 += r0; v1 += r1; }
                     }
                     if (FOLD == 3) {
-                        const v8 h = rh[FOLD == 3 ? i % 3 : 0][it], l = rl[FOLD == 3 ? i % 3 : 0][it];
+                        const v8 h = rh[FOLD == 3 ? i % (D3 + 1) : 0][it], l = rl[FOLD == 3 ? i % (D3 + 1) : 0][it];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v0[e] += (float)h[e] + (float)l[e]; v1[e] += (float)h[4 + e] + (float)l[4 + e]; }
                     }
@@ -307,7 +314,9 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
                         const float ssum = row8_sum(((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3])));
                         const float ssq = row8_sum(((v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3])) +
                                                    ((v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3])));
+#ifndef OFX_EP3_NOSTAT          // (timing experiment: the upper bound of what consolidating the statistics stores could gain)
                         if (c8 == 7) *(f32x2*)(p.stat_part + ((size_t)gm * (p.N >> 6) + (gn0 >> 6)) * 2) = f32x2{ssum, ssq};
+#endif
                     }
                     if (p.out_kind == 2) {
                         v8 lo;

@@ -8,7 +8,7 @@ python3 $ROOT/bench.py --steps 5 --warmup 2 --cpu-outfits 0 "$@" > $OUT/bench_li
 cd /tmp && export TMPDIR=/tmp
 B="python3 $ROOT/bench.py --steps 1 --warmup 1 --cpu-outfits 0 $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B > $OUT/trace.log 2>&1 || { tail -5 $OUT/trace.log; exit 1; }
-# the default command's kernel averages (20 timed steps after 5 warm-up: the clock state bench.py's own live GEMM timing sees)
+# the default command's kernel averages (40 timed steps after 8 warm-up: the clock state bench.py's own live GEMM timing sees)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_default -- python3 $ROOT/bench.py --cpu-outfits 0 "$@" > $OUT/trace_default.log 2>&1 \
   && cp $(find $OUT/trace_default -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_default_command.csv && grep -o '{"metric.*' $OUT/trace_default.log > $OUT/bench_line_under_rocprof.json
 # the same with the towers on ONE stream: per-kernel averages that are comparable with bench.py's live per-launch timing (concurrent kernels share time)
