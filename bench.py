@@ -369,6 +369,10 @@ def main():
                          "avg_launch_us": round(gemm_ms * 1e3 / max(gemm_launches, 1), 2),
                          "algorithmic_gflop_per_outfit": round(alg_gemm_outfit / 1e9, 3),
                          "launched_gflop_per_outfit": round(launched_flop / B / 1e9, 3),
+                         "power_limited_reference": {"mfma_only_loop_tflops_random_f16_operands": [1790.8, 1833.9], "mfma_only_loop_tflops_zero_operands": 2404.7,
+                                                     "note": "not measured by this run: tools/mfma_power_probe.hip on one MI355X (profiles/r03_power_limited_clock.txt) - a "
+                                                             "register-resident v_mfma_f32_16x16x32_f16 loop on every CU sustains 0.72-0.73 of `peak` on random operands (the clock the "
+                                                             "matrix pipe's switching power leaves); this bench's GEMMs run 22-29 % faster on constant operands. `peak` stays the guide's figure"},
                          "dominant_kernel": dom, "per_kernel": kernels, "per_kernel_traffic_pmc": traffic_by_kernel,
                          "per_shape": table},
             "step_breakdown_ms": {"gemm": round(bms[0], 3), "norm_embed": round(bms[1], 3), "attention": round(bms[2], 3),

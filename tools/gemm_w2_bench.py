@@ -23,6 +23,10 @@ def main():
         lib.ofx_tune(2, 6 if name.startswith("txt") else 0)          # small grids: force the dual-weight 256x256 kernel
         A = torch.randn(M, K, device="cuda", generator=g).half()
         Wf = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+        data = os.environ.get("OFX_DATA", "randn")          # operand values: the kernels' clocks follow what the matrix pipe toggles
+        if data == "zero": A.zero_(); Wf.zero_()
+        elif data == "azero": A.zero_()
+        elif data == "const": A.fill_(1.0); Wf.fill_(0.03125)
         W = Wf.half()
         W2 = torch.empty(N, 2 * K, device="cuda", dtype=torch.float16)
         L.check(lib.ofx_convert(Wf.data_ptr(), W2.data_ptr(), N, K, 3, 2, s))
