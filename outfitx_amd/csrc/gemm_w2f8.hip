@@ -40,6 +40,12 @@
 extern int g_w2_persist, g_w2_trim;
 #ifndef OFX_F8_PRIO
 #define OFX_F8_PRIO 1
+// f16 MFMA order: 1 = the weight fragment (the instruction's FIRST operand) stays over 4 consecutive MFMAs while the activation fragment cycles.
+// Bit-identical results (every accumulator sees the same sequence); 242 VGPRs and no scratch instead of 256 + 16 B; in back-to-back launches
+// qkv 560 -> 536 us, fc1 760 -> 740 (the part is power-limited and a changing first operand costs more: tools/mfma_power_probe.hip), level in the step.
+#ifndef OFX_MFMA_WKEEP
+#define OFX_MFMA_WKEEP 1
+#endif
 #endif
 #define OFX_F8_PRIO_HI __builtin_amdgcn_s_setprio(OFX_F8_PRIO)
 namespace {
@@ -188,9 +194,16 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
 #define OFX_F8_MFMA16(S)                                                                                      \
     if (ABL < 5 || ABL == 7) {                                                                                             \
         OFX_F8_PRIO_HI;                                                                      \
+        if (OFX_MFMA_WKEEP) {       /* weight fragment (the instruction's first operand) kept over 4 consecutive MFMAs: tools/mfma_power_probe.hip */ \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                   \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[i][j] = OpT<T>::mfma16(wh[j], af[i], acc[i][j]); \
+                if (ABL != 4 && (j & 1)) OFX_F8_CVT1(j >> 1, S)                                               \
+            }                                                                                                 \
+        } else {                                                                                              \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[i][j] = OpT<T>::mfma16(wh[j], af[i], acc[i][j]); \
             if (ABL != 4) OFX_F8_CVT1(i, S)                                                                   \
+        }                                                                                                     \
         }                                                                                                     \
         __builtin_amdgcn_s_setprio(0);                                                                        \
     }

@@ -15,6 +15,9 @@
 #include "gemm_common.h"
 
 extern int g_w2_persist, g_x3_persist;
+#ifndef OFX_MFMA_WKEEP
+#define OFX_MFMA_WKEEP 0
+#endif
 namespace {
 
 __device__ __forceinline__ void x3_bload16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, OFX_LDS char* l) {
@@ -110,12 +113,20 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(KArgs p) {
 #define OFX_X3_MFMA()                                                                                         \
     {                                                                                                         \
         __builtin_amdgcn_s_setprio(1);                                                                        \
+        if (OFX_MFMA_WKEEP) {       /* the instruction's first operand kept over 8 / 4 consecutive MFMAs (tools/mfma_power_probe.hip) */ \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                   \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[i][j] = OpT<T>::mfma16(wh[j], ah[i], acc[i][j]); \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[i][j] = OpT<T>::mfma16(wh[j], al[i], acc[i][j]); \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[i][j] = OpT<T>::mfma16(wl[j], ah[i], acc[i][j]); \
+            }                                                                                                 \
+        } else {                                                                                              \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                   \
                 acc[i][j] = OpT<T>::mfma16(wh[j], ah[i], acc[i][j]);                                          \
                 acc[i][j] = OpT<T>::mfma16(wh[j], al[i], acc[i][j]);                                          \
                 acc[i][j] = OpT<T>::mfma16(wl[j], ah[i], acc[i][j]);                                          \
             }                                                                                                 \
+        }                                                                                                     \
         __builtin_amdgcn_s_setprio(0);                                                                        \
     }
         if (first) {

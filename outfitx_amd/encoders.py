@@ -576,13 +576,15 @@ class ItemEncoder(nn.Module):
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     b2 = self.text_enc.encode_into(texts, out, d, self.cfg.norm_out, prepared=prepared)
-                out.record_stream(side)
-                plan = prepared[4] if isinstance(prepared[4], dict) else {}
-                for t in list(prepared[:2]) + [plan.get("rows"), plan.get("ids"), plan.get("att")]:
-                    if t is not None:
-                        t.record_stream(side)
-                b = self.image_enc.encode_into(images, out, 0, self.cfg.norm_out)
-                main.wait_stream(side)
+                # No record_stream on `out` / the prepared token tensors: they are allocated on `main`, and `main` joins `side` below before
+                # anything later on `main` can run - so when their blocks return to main's pool and are handed out again, that use is
+                # ordered after the side stream's last access.  (record_stream would defer every free until the device has caught up with
+                # the host, which runs steps ahead: the allocator then keeps calling hipMalloc inside steady-state steps - 7-9 calls per 10
+                # steps in bench.py, +1-2 ms each and now and then a step at half speed.)
+                try:
+                    b = self.image_enc.encode_into(images, out, 0, self.cfg.norm_out)
+                finally:
+                    main.wait_stream(side)                     # the join the comment above relies on, also when the image tower raises
             else:
                 b = self.image_enc.encode_into(images, out, 0, self.cfg.norm_out)
                 b2 = self.text_enc.encode_into(texts, out, d, self.cfg.norm_out, prepared=prepared)

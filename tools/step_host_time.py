@@ -27,4 +27,8 @@ issue, total = [], []
 for _ in range(10):
     torch.cuda.synchronize(); t0 = time.perf_counter(); step(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
     issue.append((t1 - t0) * 1e3); total.append((t2 - t0) * 1e3)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10): step()
+t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print(f"10 steps back to back: the host returned after {(t1 - t0) * 1e3:.1f} ms, the device finished after {(t2 - t0) * 1e3:.1f} ms", flush=True)
 print(f"host issue time per step: median {np.median(issue):.2f} ms (min {min(issue):.2f}, max {max(issue):.2f}); step incl. device: median {np.median(total):.2f} ms", flush=True)
