@@ -164,6 +164,9 @@ def main():
     ap.add_argument("--cpu-outfits", type=int, default=8, help="outfits of the batch checked against the fp32 oracle (0 = skip the oracle check and the CPU baseline)")
     ap.add_argument("--cpu-cfg2-outfits", type=int, default=2, help="sample size of the CPU baseline's cfg2 leg")
     ap.add_argument("--vit-streams", type=int, default=1, help="split the image batch over this many HIP streams (CLIPImageEncoder.vit_streams)")
+    ap.add_argument("--graph", type=int, default=1, help="1 (default): after the warm-up the step is captured into ONE HIP graph (outfitx_amd.graphs.capture_cp_forward) and each "
+                    "timed step is one graph launch - same kernels, same streams, bit-identical logits; the step that carries the live roofline sample is issued "
+                    "launch by launch (events ride on the launches).  0: every step launch by launch")
     ap.add_argument("--overlap-towers", type=int, default=1, help="1 (default): the text tower runs on a side HIP stream beside the ViT (ItemEncoder.overlap_towers; "
                     "31.85 vs 32.85 ms/step); the ONE step sampled for the roofline and the breakdown step run single-stream so that launch times do not overlap")
     ap.add_argument("--secondary", default="bf16", help="tower scheme of the secondary (non-headline) measurement after the timed region ('' = skip)")
@@ -233,6 +236,20 @@ def main():
         out = step()
     model.item_encoder.overlap_towers = bool(a.overlap_towers)
     fence()
+    captured, graph_note = None, "off (--graph 0)"
+    if a.graph:
+        try:
+            from outfitx_amd.graphs import capture_cp_forward
+            captured = capture_cp_forward(model, mask, px, texts)
+            g_out = captured.replay()                           # first launch of an instantiated graph uploads it: not a timed step
+            torch.cuda.synchronize(dev)
+            if not torch.equal(g_out, out):
+                raise RuntimeError("captured step's logits differ from the launch-by-launch step's")
+            graph_note = "one HIP graph launch per step, captured after the warm-up; logits bit-identical to the launch-by-launch step (checked before timing)"
+        except Exception as e:                                  # the HIP path stays the one that runs: launch by launch
+            captured, graph_note = None, f"capture failed ({type(e).__name__}: {str(e)[:160]}); steps issued launch by launch"
+            _log(graph_note)
+        fence()
     _log("timed region")
     lib = L.load()
     # Live roofline sample: HIP events bracket every GEMM launch of ONE timed step (the middle one) on the launch
@@ -247,7 +264,7 @@ def main():
         if i == sample:
             model.item_encoder.overlap_towers = False        # per-launch events of concurrent kernels would count the shared time twice
             lib.ofx_profile_enable(1)
-        out = step()
+        out = step() if (captured is None or i == sample) else captured.replay()
         if i == sample:
             lib.ofx_profile_enable(0)
             model.item_encoder.overlap_towers = bool(a.overlap_towers)
@@ -357,7 +374,7 @@ def main():
             "data": "synthetic (seeded uniform-uint8 images after CLIP normalise, 8-token ids, random-init weights of the reference architecture)",
             "config": {"workload": "BASELINE configs[1]: CP forward with CLIP ViT-B/32 image+text encode, 256 outfits x 8 items per GPU, 224^2",
                        "outfits_per_gpu": B, "items": n, "parallelism": f"dp{world} (batch sharded, no data-path collective)",
-                       "tower_precision": scheme,
+                       "tower_precision": scheme, "launch": graph_note,
                        "outfit_precision": (model._tower_fed() or a.precision) + (f" (set transformer fed by the in-call {op} towers)" if model._tower_fed() else ""),
                        "parity_bound": "north star: <= 1e-3 max|d| / max|ref| over the batch on the CP logit vs the fp32 reference path; measured on THIS batch below "
                                        "(parity_rel_err_vs_reference, all logits) and at this batch size on weight seeds 7/44/89/97/99 by "

@@ -30,6 +30,9 @@ def test_bench_single_gpu_line_has_the_contract_fields():
     assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["unit"] == "outfits/s" and j["scaling"] == "weak"
     assert abs(j["value"] - 64 * 3 / (j["ms_per_step"] * 3e-3)) <= 1e-3 * j["value"]
     assert j["parity_rel_err_vs_oracle"] < 1e-3                      # the headline mode is the 1e-3-compliant one
+    assert j["config"]["launch"].startswith("one HIP graph launch per step")      # the default: steps replayed from the captured graph, logits checked equal
+    sp = j["step_ms_spread"]
+    assert len(sp["all"]) == 3 and len(sp["host_issue_ms"]) == 3 and sp["device_allocs_in_timed_region"] <= 2
     rf, cb = j["roofline"], j["cpu_baseline"]
     assert rf["bound"] == "mfma" and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["per_shape"]
     assert sum(t["launches"] for t in rf["per_shape"]) == rf["launches_per_step"]

@@ -542,6 +542,37 @@ def test_layernorm_folding_matches_the_materialised_path(model):
             assert rel_err(a, b) < 2e-3
 
 
+def test_cp_forward_as_one_hip_graph_matches_launch_by_launch(model):
+    """outfitx_amd.graphs.capture_cp_forward: the whole scoring call (towers on two streams, fuser, set transformer, head) captured
+    once and replayed with one launch - logits bit-identical to the launch-by-launch call, also after the captured input buffers are
+    overwritten with another batch (pixels on the device, token rows in their pinned host tensors)."""
+    from outfitx_amd.graphs import capture_cp_forward
+    CP = tasks()[0]
+    B, n = 6, 4
+    mk = lambda seed: (cu(synth.pixel_values(seed, B * n).reshape(B, n, 3, 224, 224)), synth.token_batch(seed, B * n, 64, 8))
+    px, (ids, att) = mk(501)
+    texts = {"input_ids": torch.from_numpy(ids).view(B, n, 64).pin_memory(), "attention_mask": torch.from_numpy(att).view(B, n, 64).pin_memory()}
+    mask = torch.zeros(B, n, dtype=torch.bool, device="cuda")
+    eager = lambda: model(task=CP, outfit_embedding=None, outfit_mask=mask, encoder_input_dict={"images": px, "texts": texts})
+    with torch.no_grad():
+        ref1 = eager().clone()
+        cap = capture_cp_forward(model, mask, px, texts)
+        assert torch.equal(cap.replay(), ref1) and torch.equal(cap.replay(), ref1)
+        px2, (ids2, att2) = mk(502)                                   # same longest token row (8): the captured text length still holds
+        px.copy_(px2); texts["input_ids"].copy_(torch.from_numpy(ids2).view(B, n, 64)); texts["attention_mask"].copy_(torch.from_numpy(att2).view(B, n, 64))
+        got2 = cap.replay().clone()
+        ref2 = eager()
+    assert torch.equal(got2, ref2) and not torch.equal(ref2, ref1) and cap.replays == 3
+    with pytest.raises(ValueError):
+        capture_cp_forward(model, mask, px, {k: v.clone() for k, v in texts.items()})        # pageable host tokens: refused
+    model.train()
+    try:
+        with pytest.raises(ValueError):
+            capture_cp_forward(model, mask, px, texts)
+    finally:
+        model.eval()
+
+
 def test_text_tower_side_stream_variants_are_bit_identical(model):
     """The text tower beside the ViT: torch's side stream (default), a lowest-priority HIP stream from the C ABI
     (ofx_stream_create_low_priority) and the towers back to back on one stream write the same embeddings bit for bit; so does the
