@@ -40,7 +40,8 @@ class CapturedCall:
                 fn()
         cur.wait_stream(cap)
         torch.cuda.synchronize(device)
-        with torch.no_grad(), torch.cuda.graph(self._graph, stream=cap):
+        # thread_local: only this thread's calls are checked against the capture (a collective library's watchdog thread polling its events must not void it)
+        with torch.no_grad(), torch.cuda.graph(self._graph, stream=cap, capture_error_mode="thread_local"):
             self.output = fn()
         torch.cuda.synchronize(device)
         self.replays = 0
