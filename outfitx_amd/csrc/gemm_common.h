@@ -263,6 +263,13 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
 #pragma unroll
             for (int d = 0; d < D3; ++d) fetch_hl(d, rh[FOLD == 3 ? d : 0], rl[FOLD == 3 ? d : 0]);
         }
+        // FOLD 3 statistics: the 8 lanes of a row all hold its (sum, sum of squares) after row8_sum; lane c8 keeps those of pass-half
+        // (2 i + it) & 7 == c8, so after the passes every lane owns NP / 4 rows and the wave writes them with NP / 4 store instructions of 64
+        // lanes instead of 2 NP of 8 lanes (the epilogue is bound by its vector-memory instruction count)
+        constexpr int KS = FOLD == 3 ? (NP + 3) / 4 : 1;
+        float keep_s[KS], keep_q[KS];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) { keep_s[k] = 0.f; keep_q[k] = 0.f; }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             if (FOLD == 3 && i + D3 < NP) fetch_hl(i + D3, rh[FOLD == 3 ? (i + D3) % (D3 + 1) : 0], rl[FOLD == 3 ? (i + D3) % (D3 + 1) : 0]);
@@ -314,9 +321,7 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
                         const float ssum = row8_sum(((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3])));
                         const float ssq = row8_sum(((v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3])) +
                                                    ((v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3])));
-#ifndef OFX_EP3_NOSTAT          // (timing experiment: the upper bound of what consolidating the statistics stores could gain)
-                        if (c8 == 7) *(f32x2*)(p.stat_part + ((size_t)gm * (p.N >> 6) + (gn0 >> 6)) * 2) = f32x2{ssum, ssq};
-#endif
+                        if (c8 == ((2 * i + it) & 7)) { keep_s[FOLD == 3 ? (2 * i + it) >> 3 : 0] = ssum; keep_q[FOLD == 3 ? (2 * i + it) >> 3 : 0] = ssq; }
                     }
                     if (p.out_kind == 2) {
                         v8 lo;
@@ -326,6 +331,14 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
                         *(v8*)(crow + 2 * p.N) = hi;
                     }
                 }
+            }
+        }
+        if (FOLD == 3) {
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                const int c = k * 8 + c8;                       // the pass-half this lane kept in slot k
+                const int gm = gm0 + (c >> 1) * 16 + (c & 1) * 8 + rsub;
+                if (c < 2 * NP && gm < p.M) *(f32x2*)(p.stat_part + ((size_t)gm * (p.N >> 6) + (gn0 >> 6)) * 2) = f32x2{keep_s[k], keep_q[k]};
             }
         }
     }
