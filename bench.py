@@ -289,10 +289,11 @@ def main():
     rank_info = None
     if world > 1:
         # whole-job time = the slowest rank's; every rank's own time, batch seed and host thread count travel to rank 0 for the line
-        mine = torch.tensor([elapsed, float(seed), float(torch.get_num_threads())], device="cpu" if rehearsal else dev, dtype=torch.float64)
+        mine = torch.tensor([elapsed, float(seed), float(torch.get_num_threads()), 1.0 if captured is not None else 0.0], device="cpu" if rehearsal else dev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        rank_info = {"elapsed_s": [round(float(x[0]), 6) for x in allr], "batch_seeds": [int(x[1]) for x in allr], "host_threads": [int(x[2]) for x in allr]}
+        rank_info = {"elapsed_s": [round(float(x[0]), 6) for x in allr], "batch_seeds": [int(x[1]) for x in allr], "host_threads": [int(x[2]) for x in allr],
+                     "graph_launch": [bool(x[3]) for x in allr]}
         t = torch.tensor([elapsed], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())

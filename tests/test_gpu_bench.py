@@ -62,3 +62,4 @@ def test_bench_two_ranks_rehearsal():
     assert rk["batch_seeds"] == [1236, 1237]                       # rank-local batches (weak scaling: each rank scores its own outfits)
     assert len(rk["elapsed_s"]) == 2 and abs(max(rk["elapsed_s"]) - j["ms_per_step"] * 2e-3) <= 2e-3 * max(rk["elapsed_s"])     # MAX over ranks is the job's time
     assert all(t >= 1 for t in rk["host_threads"])
+    assert rk["graph_launch"] == [True, True]                      # every rank replays its own captured step
