@@ -261,6 +261,21 @@ __global__ __launch_bounds__(64) void set_attention_kernel(SetK a) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < SMAX; ++j) vreg[j] = j < S ? vs[(j % VS) * STR + lane] : 0.f;
+    } else if (sizeof(TI) == 4) {
+        // fp32 q | k | v: q and k rows as 16-byte loads (16 lanes per 64-column slice, four rows per instruction) straight into their LDS
+        // rows; v stays one dword per lane and row (its lane = column layout is what the P.V loop wants).  The kernel is bound by its
+        // vector-memory instruction count, not by bytes (S = 8: 12 loads + 3 stores per wave instead of 24 + 24)
+        const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+        for (int j0 = 0; j0 < S; j0 += 4) {
+            const int j = j0 + rsub;
+            if (j < S) {
+                const float* rp = (const float*)a.qkv + (size_t)(r0 + j) * 3 * D + h * 64 + c4;
+                if (j < nq) *(f32x4*)(qs + j * STR + c4) = *(const f32x4*)rp;
+                *(f32x4*)(ks + j * STR + c4) = *(const f32x4*)(rp + D);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < SMAX; ++j) vreg[j] = j < S ? ((const float*)a.qkv)[(size_t)(r0 + j) * 3 * D + 2 * D + h * 64 + lane] : 0.f;
     } else {
 #pragma unroll
         for (int j = 0; j < SMAX; ++j) {
@@ -301,19 +316,41 @@ __global__ __launch_bounds__(64) void set_attention_kernel(SetK a) {
         else for (int j = 0; j < S; ++j) row[j] *= inv;
     }
     __syncthreads();
+    if (a.out_kind == 0) {
+        for (int i = 0; i < nq; ++i) {
+            const float* row = sc + i * (SMAX + 4);
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < SMAX; ++j) acc += (j < S ? row[j] : 0.f) * vreg[j];
+            ((float*)a.out)[(size_t)(r0 + i) * a.ldo + h * 64 + lane] = acc;
+        }
+        return;
+    }
+    // operand-type outputs: the fp32 rows go through the (now free) q staging rows and leave as 16-byte stores - 8 lanes per 64-column
+    // slice, 8 rows per instruction, one instruction per copy (hi | lo | hi) instead of one 2-byte store per lane, row and copy
+    typedef typename OpT<T>::v8 v8;
     for (int i = 0; i < nq; ++i) {
         const float* row = sc + i * (SMAX + 4);
         float acc = 0.f;
 #pragma unroll
         for (int j = 0; j < SMAX; ++j) acc += (j < S ? row[j] : 0.f) * vreg[j];
-        const size_t off = (size_t)(r0 + i) * a.ldo + h * 64 + lane;
-        if (a.out_kind == 0) {
-            ((float*)a.out)[off] = acc;
-        } else {
-            const T hi = (T)acc;
-            T* p = (T*)a.out + off;
-            p[0] = hi;
-            if (a.out_kind == 2) { p[D] = (T)(acc - (float)hi); p[2 * D] = hi; }
+        qs[i * STR + lane] = acc;
+    }
+    __syncthreads();
+    const int c8 = (lane & 7) * 8, r8 = lane >> 3;
+    for (int i0 = 0; i0 < nq; i0 += 8) {
+        const int i = i0 + r8;
+        if (i < nq) {
+            const f32x4 x0 = *(const f32x4*)(qs + i * STR + c8), x1 = *(const f32x4*)(qs + i * STR + c8 + 4);
+            v8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hi[e] = (T)x0[e]; hi[4 + e] = (T)x1[e];
+                lo[e] = (T)(x0[e] - (float)hi[e]); lo[4 + e] = (T)(x1[e] - (float)hi[4 + e]);
+            }
+            T* p = (T*)a.out + (size_t)(r0 + i) * a.ldo + h * 64 + c8;
+            *(v8*)p = hi;
+            if (a.out_kind == 2) { *(v8*)(p + D) = lo; *(v8*)(p + 2 * D) = hi; }
         }
     }
 }
@@ -570,7 +607,7 @@ int ofx_launch_set_attention(const SetAttnArgs& g, int op_dtype, hipStream_t s) 
     // input, the backward kernel) stay at 32
     OFX_REQUIRE(g.max_len >= 1 && g.max_len <= 64, OFX_ESHAPE, "set_attention: %d rows per sequence exceed 64", g.max_len);
     OFX_REQUIRE(g.max_len <= 32 || !g.drop.thresh, OFX_ESHAPE, "set_attention: dropout columns are keyed query * 32 + key");
-    OFX_REQUIRE(g.ldo >= (g.out_kind == 2 ? 3 * g.D : g.D), OFX_ESHAPE, "set_attention: bad ldo=%d", g.ldo);
+    OFX_REQUIRE(g.ldo >= (g.out_kind == 2 ? 3 * g.D : g.D) && (g.out_kind == 0 || g.ldo % 8 == 0), OFX_ESHAPE, "set_attention: bad ldo=%d (operand-type rows leave as 16-byte stores)", g.ldo);
     OFX_REQUIRE(g.cu_seqlens || (g.fixed_len >= 1 && g.fixed_len <= g.max_len), OFX_EINVAL, "set_attention: needs cu_seqlens or a fixed length <= max_len");
     SetK k;
     k.qkv = g.qkv; k.out = (char*)g.out; k.cu = g.cu_seqlens; k.nseq = g.nseq; k.n_head = g.n_head; k.D = g.D; k.ldo = g.ldo;
