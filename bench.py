@@ -159,7 +159,7 @@ def main():
     ap.add_argument("--items", type=int, default=8)
     ap.add_argument("--precision", default="bf16x3", help="outfit transformer MFMA operand format")
     ap.add_argument("--tower-precision", default="f16w2x", help="CLIP towers operand scheme: f16w2x (default: f16 operands, split (hi, lo) weights on every ViT GEMM, "
-                    "three-product text tower and projection - at this batch size inside 1e-3 of the reference on all 100 weight seeds swept, worst 8.6e-4: profiles/r03_seed_sweep_bench_scale.json) | f16w2 (split weights on patch / out-proj / fc2 only: "
+                    "three-product text tower and projection - at this batch size inside 1e-3 of the reference on all 100 weight seeds swept, worst 7.3e-4 (8.6e-4 on an earlier build of the round): profiles/r03_seed_sweep_bench_scale.json) | f16w2 (split weights on patch / out-proj / fc2 only: "
                     "faster, same sweep: all inside 1e-3 but the worst at 9.98e-4, five above 8e-4) | f16x3 | f16 | bf16 (single product, faster, 5e-4 / 4e-3 at the tower outputs)")
     ap.add_argument("--cpu-outfits", type=int, default=8, help="outfits of the batch checked against the fp32 oracle (0 = skip the oracle check and the CPU baseline)")
     ap.add_argument("--cpu-cfg2-outfits", type=int, default=2, help="sample size of the CPU baseline's cfg2 leg")
