@@ -150,6 +150,52 @@ def cpu_baseline(px, ids, att, n_items, cfg2_outfits):
                                            "note": "BASELINE configs[0] / BASELINE.md section 3: S = 17 rows as the reference's processor feeds them, 3 warm-up + 10 timed, median"}}
 
 
+def cir_leg(a, rank, world, dev, rehearsal, fence):
+    """BASELINE configs[3] on N ranks, after (never inside) the timed region: 1,000 query embeddings against a 100k-row pool that is
+    ROW-SHARDED over the ranks; every rank scores all queries against its shard (fp32-exact distances + local top-50), ONE
+    all_gather_into_tensor of the packed per-shard candidate lists (RCCL over xGMI; 600 KB per rank), deterministic merge
+    (outfitx_amd/parallel.py::cir_topk; reference call site: complementary_item_retrieval_trainer.py:240-249, which scores on one GPU).
+    Reports the time per call (MAX over ranks) and whether rank 0's UNSHARDED top-k of the first 100 queries over the whole pool is
+    torch.equal to the sharded result."""
+    import torch.distributed as dist
+    from outfitx_amd.engine import Engine
+    from outfitx_amd.parallel import cir_topk, shard_range
+    nq, npool, k = a.cir_queries, a.cir_pool, 50
+    lo, hi = shard_range(npool, rank, world)
+    eng = Engine(dev)
+    Q = torch.from_numpy((synth.item_embeddings(1244, "cir_queries", nq) * 3.0).astype(np.float32)).to(dev)
+    shards = [synth.item_embeddings(1244, f"cir_pool_shard{r}", shard_range(npool, r, world)[1] - shard_range(npool, r, world)[0]) if (r == rank or rank == 0) else None
+              for r in range(world)]                               # every shard has its own seeded stream: a rank draws its own rows, rank 0 all of them
+    mine = torch.from_numpy(shards[rank]).to(dev)
+    for _ in range(2):
+        idx, dst = cir_topk(eng, Q, mine, k, lo)
+    fence()
+    iters = 10
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        idx, dst = cir_topk(eng, Q, mine, k, lo)
+    torch.cuda.synchronize(dev)
+    dt = torch.tensor([(time.perf_counter() - t0) / iters], device="cpu" if rehearsal else dev, dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    t1 = time.perf_counter()
+    for _ in range(iters):
+        li, ld = eng.l2_topk(Q, mine, k, index_base=lo)           # the same call without the collective and the merge
+    torch.cuda.synchronize(dev)
+    local_ms = (time.perf_counter() - t1) / iters * 1e3
+    equal = None
+    if rank == 0:
+        P = torch.from_numpy(np.concatenate(shards, 0)).to(dev)
+        sub = min(100, nq)
+        ui, ud = eng.l2_topk(Q[:sub], P, k)
+        equal = bool(torch.equal(ui, idx[:sub]) and torch.equal(ud, dst[:sub]))
+        del P
+    fence()
+    return {"cir_allgather_ms": round(float(dt.item()) * 1e3, 3), "cir_local_topk_ms_rank0": round(local_ms, 3), "cir_equal": equal,
+            "cir_note": f"{nq} queries x {npool} pool rows x 1024 row-sharded over {world} ranks, k = {k}: local fp32-exact top-k + ONE all-gather of the packed candidate lists "
+                        f"({nq * k * 12} B per rank) + merge, per call, MAX over ranks, 10 calls after 2; cir_equal: rank 0's unsharded top-k of the first {min(100, nq)} queries "
+                        "over the whole pool is torch.equal (indices and distances) to the sharded result"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,9 +210,13 @@ def main():
     ap.add_argument("--cpu-outfits", type=int, default=8, help="outfits of the batch checked against the fp32 oracle (0 = skip the oracle check and the CPU baseline)")
     ap.add_argument("--cpu-cfg2-outfits", type=int, default=2, help="sample size of the CPU baseline's cfg2 leg")
     ap.add_argument("--vit-streams", type=int, default=1, help="split the image batch over this many HIP streams (CLIPImageEncoder.vit_streams)")
-    ap.add_argument("--graph", type=int, default=1, help="1 (default): after the warm-up the step is captured into ONE HIP graph (outfitx_amd.graphs.capture_cp_forward) and each "
-                    "timed step is one graph launch - same kernels, same streams, bit-identical logits; the step that carries the live roofline sample is issued "
-                    "launch by launch (events ride on the launches).  0: every step launch by launch")
+    ap.add_argument("--graph", type=int, default=1, help="1 (default): the drop-in call replays - OutfitX._cp_forward captures a repeated eval-mode call into ONE HIP graph on its second "
+                    "occurrence (OutfitX.graph_replay, outfitx_amd/graphs.py) and every later call is one graph launch - same kernels, same streams, bit-identical logits; the step that "
+                    "carries the live roofline sample is issued launch by launch (events ride on the launches).  0: every step launch by launch (also reported, after the timed "
+                    "region, as `launch_by_launch` in the default run's line)")
+    ap.add_argument("--cir-queries", type=int, default=1000, help="N > 1 only: queries of the BASELINE configs[3] retrieval leg run after the timed region (pool row-sharded over the ranks, "
+                    "ONE all-gather of the per-shard candidate lists: the only data-path collective the north star names); 0 = skip")
+    ap.add_argument("--cir-pool", type=int, default=100_000, help="pool rows of that leg (whole job; sharded over the ranks)")
     ap.add_argument("--overlap-towers", type=int, default=1, help="1 (default): the text tower runs on a side HIP stream beside the ViT (ItemEncoder.overlap_towers; "
                     "31.85 vs 32.85 ms/step); the ONE step sampled for the roofline and the breakdown step run single-stream so that launch times do not overlap")
     ap.add_argument("--secondary", default="bf16", help="tower scheme of the secondary (non-headline) measurement after the timed region ('' = skip)")
@@ -236,18 +286,28 @@ def main():
         out = step()
     model.item_encoder.overlap_towers = bool(a.overlap_towers)
     fence()
-    captured, graph_note = None, "off (--graph 0)"
+    # --graph 1 (default): nothing to set up - the drop-in call itself replays.  OutfitX._cp_forward (eval mode) captures a repeated call on its
+    # second occurrence and launches ONE HIP graph per call from the third on (outfitx_amd/graphs.py ForwardReplay); the timed steps below are
+    # plain `model(task=CP, ...)` calls.  Untimed here: make sure the capture has happened and check its logits against the launch-by-launch ones.
+    model.graph_replay = bool(a.graph)
+    graph_on, graph_note = False, "off (--graph 0): every step launch by launch"
     if a.graph:
-        try:
-            from outfitx_amd.graphs import capture_cp_forward
-            captured = capture_cp_forward(model, mask, px, texts)
-            g_out = captured.replay()                           # first launch of an instantiated graph uploads it: not a timed step
-            torch.cuda.synchronize(dev)
-            if not torch.equal(g_out, out):
-                raise RuntimeError("captured step's logits differ from the launch-by-launch step's")
-            graph_note = "one HIP graph launch per step, captured after the warm-up; logits bit-identical to the launch-by-launch step (checked before timing)"
-        except Exception as e:                                  # the HIP path stays the one that runs: launch by launch
-            captured, graph_note = None, f"capture failed ({type(e).__name__}: {str(e)[:160]}); steps issued launch by launch"
+        eager_out = out.clone()
+        for _ in range(6):
+            rp = model._replay
+            if rp is not None and rp.stats["replays"] >= 2:
+                break
+            out = step()
+        torch.cuda.synchronize(dev)
+        rp = model._replay
+        if rp is not None and rp.stats["replays"] >= 1:
+            if not torch.equal(out, eager_out):
+                raise RuntimeError("replayed step's logits differ from the launch-by-launch step's")
+            graph_on = True
+            graph_note = ("one HIP graph launch per step: the drop-in call model(task=CP, ...) replays the step it captured on its second occurrence "
+                          "(OutfitX.graph_replay, default on); logits bit-identical to the launch-by-launch step (checked before timing)")
+        else:
+            graph_note = f"capture failed ({rp.stats if rp is not None else 'call not eligible'}); steps issued launch by launch"
             _log(graph_note)
         fence()
     _log("timed region")
@@ -264,7 +324,7 @@ def main():
         if i == sample:
             model.item_encoder.overlap_towers = False        # per-launch events of concurrent kernels would count the shared time twice
             lib.ofx_profile_enable(1)
-        out = step() if (captured is None or i == sample) else captured.replay()
+        out = step()                                        # the drop-in call: one graph launch (the sampled step: launch by launch, events ride on the launches)
         if i == sample:
             lib.ofx_profile_enable(0)
             model.item_encoder.overlap_towers = bool(a.overlap_towers)
@@ -289,7 +349,7 @@ def main():
     rank_info = None
     if world > 1:
         # whole-job time = the slowest rank's; every rank's own time, batch seed and host thread count travel to rank 0 for the line
-        mine = torch.tensor([elapsed, float(seed), float(torch.get_num_threads()), 1.0 if captured is not None else 0.0], device="cpu" if rehearsal else dev, dtype=torch.float64)
+        mine = torch.tensor([elapsed, float(seed), float(torch.get_num_threads()), 1.0 if graph_on else 0.0], device="cpu" if rehearsal else dev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         rank_info = {"elapsed_s": [round(float(x[0]), 6) for x in allr], "batch_seeds": [int(x[1]) for x in allr], "host_threads": [int(x[2]) for x in allr],
@@ -297,6 +357,8 @@ def main():
         t = torch.tensor([elapsed], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if a.cir_queries > 0:
+            rank_info.update(cir_leg(a, rank, world, dev, rehearsal, fence))
 
     if rank == 0:
         T_real = 8
@@ -434,9 +496,25 @@ def main():
                 if ref_all is not None:
                     res["oracle_vs_reference_fixture"] = float(np.abs(ref.reshape(-1) - ref_all[:k]).max() / np.abs(ref_all[:k]).max())
                 res["cpu_baseline"] = cpu_baseline(px, texts["input_ids"], texts["attention_mask"], n, min(a.cpu_cfg2_outfits, B))
+                if a.graph:
+                    # the same call with graph replay off (what --graph 0 times): 10 steps after 2, outside the timed region
+                    model.graph_replay = False
+                    for _ in range(2):
+                        o1 = step()
+                    fence()
+                    t1 = time.perf_counter()
+                    for _ in range(10):
+                        o1 = step()
+                    fence()
+                    dt1 = (time.perf_counter() - t1) / 10
+                    model.graph_replay = True
+                    res["launch_by_launch"] = {"outfits_per_s": round(B / dt1, 1), "ms_per_step": round(dt1 * 1e3, 3), "steps": 10, "warmup": 2,
+                                               "bit_identical_to_replayed": bool(torch.equal(o1, out)),
+                                               "note": "the same drop-in call with OutfitX.graph_replay = False (what --graph 0 times): ~250 launches per step issued by the host"}
                 if a.secondary and a.secondary != a.tower_precision:
                     # secondary, NON-compliant mode for context (never `value`): single-product towers, same batch, 5 steps after 2 warm-up
                     _log(f"secondary measurement: {a.secondary} towers")
+                    model.graph_replay = False                 # launch by launch, as every earlier round's secondary figure
                     model.item_encoder.set_precision(a.secondary)
                     for _ in range(2):
                         o2 = step()
@@ -454,6 +532,7 @@ def main():
                                                        "parity_rel_err": float(np.abs(g2 - r2).max() / np.abs(r2).max()),
                                                        "note": "faster but outside the 1e-3 bound: reported for context only"}
                     model.item_encoder.set_precision(a.tower_precision)
+                    model.graph_replay = bool(a.graph)
             except Exception as exc:      # the throughput line must survive a failure of the (host-side) checker / baseline legs
                 res["post_timing_error"] = f"{type(exc).__name__}: {exc}"
                 _log(f"post-timing leg failed: {exc!r}")

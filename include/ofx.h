@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define OFX_ABI_VERSION 4
+#define OFX_ABI_VERSION 5
 
 enum { OFX_OK = 0, OFX_EINVAL = -1, OFX_ESHAPE = -2, OFX_EHIP = -3, OFX_EWORKSPACE = -4, OFX_ESTATE = -5 };
 enum ofx_dtype { OFX_F32 = 0, OFX_BF16 = 1, OFX_F16 = 2 };
@@ -256,6 +256,11 @@ int ofx_profile_records(ofx_prof_record* out, int cap);
  *          fetching the next tile's first k-steps under the current epilogue), 0 = one block per tile.
  * knob 16: 1 (default) gemm_x3_kernel launches one block per CU walking its tiles, 0 = one block per tile (short-lived blocks). */
 int ofx_tune(int knob, int value);
+/* A counter that every ofx_tune call bumps, and whether per-launch profiling events are being recorded: the host mirror replays a
+ * stream-captured forward (outfitx_amd/graphs.py) only while the counter still has the value it had at capture time and no recording
+ * is on (events ride on launches; a replayed graph issues none). */
+unsigned ofx_config_generation(void);
+int ofx_profile_enabled(void);
 /* A HIP stream of the LOWEST dispatch priority on `device` (hipStreamCreateWithPriority, non-blocking): the host mirror runs the text tower on it
  * beside the ViT on the caller's stream, so that its workgroups take CUs only when the caller's stream has none ready.  Caller destroys it. */
 int ofx_stream_create_low_priority(int device, ofx_stream* out);

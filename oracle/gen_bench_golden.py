@@ -5,6 +5,7 @@ encoder_input_dict, outfit_x.py:120-144) on the CPU in fp32, one row per weight 
 fixture it writes is data (expected outputs + checksums of the regenerated inputs):
 
     python oracle/gen_bench_golden.py 7 44 89 97 99        # -> tests/golden/cfg2_bench_logits.npz  (resumable: seeds are appended)
+    python oracle/gen_bench_golden.py 3o1 3o2              # weight seed 3 with synth.outlier_channels level 1 / 2 (rows "w3o1", "w3o2")
 
 bench.py's parity leg, tests/test_gpu_model.py::test_cfg2_bench_batch_* and tests/studies/bench_scale_sweep.py compare all 256
 logits of the HIP path with these rows (max|d| / max|ref| over the batch, the north star's metric).  ~2 CPU-minutes per seed on
@@ -27,7 +28,7 @@ IN_SEED, B, N_ITEMS, CHUNK = 1236, 256, 8, 16
 
 
 def main():
-    seeds = [int(a) for a in sys.argv[1:]] or [7]
+    seeds = sys.argv[1:] or ["7"]          # "<seed>" or "<seed>o<level>": that seed's weights with massive ViT channels (synth.outlier_channels)
     torch.set_grad_enabled(False)
     torch.set_num_threads(int(os.environ.get("OFX_GEN_THREADS", "6")))
     M, C, T, _, _, TableTokenizer, tf_ver = import_reference()
@@ -42,7 +43,11 @@ def main():
         if f"w{ws}" in have:
             continue
         t0 = time.time()
-        model.load_state_dict({k: t(v) for k, v in synth.full_state_dict(ws).items()}, strict=True)
+        base, _, lvl = str(ws).partition("o")
+        sd = synth.full_state_dict(int(base))
+        if lvl:
+            sd = synth.outlier_channels(sd, int(lvl))
+        model.load_state_dict({k: t(v) for k, v in sd.items()}, strict=True)
         rows = []
         for b0 in range(0, B, CHUNK):
             texts = [[f"#{(b0 + b) * N_ITEMS + l}" for l in range(N_ITEMS)] for b in range(CHUNK)]

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OFX_LIB") or os.path.join(_HERE, "libofx_hip.so")
 
 OFX_OK = 0
-ABI_VERSION = 4          # include/ofx.h OFX_ABI_VERSION
+ABI_VERSION = 5          # include/ofx.h OFX_ABI_VERSION
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU, ACT_MISH = 0, 1, 2, 3
 PREC_BF16, PREC_F16, PREC_BF16X3 = 0, 1, 2
@@ -110,6 +110,8 @@ SIGNATURES = {
     "ofx_profile_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "ofx_profile_records": (_i, [C.POINTER(ProfRecord), _i]),
     "ofx_tune": (_i, [_i, _i]),
+    "ofx_config_generation": (C.c_uint, []),
+    "ofx_profile_enabled": (_i, []),
     "ofx_debug_gemm_clock": (None, [_vp]),
     "ofx_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ofx_gemm_w2": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -5,7 +5,6 @@
 #include <string.h>
 
 #include <algorithm>
-#include <unordered_map>
 #include <vector>
 #include <mutex>
 #include <cstring>
@@ -83,6 +82,9 @@ void ofx_prof_ext_end() {
     g_ofx_launch_e0 = g_ofx_launch_e1 = nullptr;
 }
 // on: 0 off; otherwise a bit mask of categories to time (1 GEMM, 2 norm/embed, 4 attention, 8 other; 15 = all)
+static unsigned g_config_generation = 0;     // bumped by every ofx_tune call: a captured launch sequence is stale when it differs
+extern "C" unsigned ofx_config_generation(void) { return g_config_generation; }
+extern "C" int ofx_profile_enabled(void) { return g_ofx_prof_on ? 1 : 0; }
 extern "C" void ofx_profile_enable(int on) {
     // create the event pool up front (never inside a timed region): room for 4096 bracketed launches
     while (on && g_prof.size() < 4096) {
@@ -169,14 +171,12 @@ struct Arena {                                      // library-owned HBM for pac
 
 struct OutfitLayer { void *w_in, *w_out, *w_1, *w_2; float *b_in, *b_out, *b_1, *b_2, *g1, *be1, *g2, *be2;
                      void *w_in_t, *w_out_t, *w_1_t, *w_2_t; };   // transposed operand copies (dgrad), single-product precisions only
-// fp8 companions of split-weight copies (gemm_w2f8.hip): [hi | lo] rows pointer -> {e4m3 lo rows, per-row scale bytes}; filled at pack
-// time for f16 towers, looked up where a split-weight GEMM is configured (process-wide: arena pointers are unique)
-struct F8Pair { void* w8; void* s8; };
-std::unordered_map<const void*, F8Pair> g_f8_of;
-static void use_split(GemmArgs& g, const void* w2, int K) {
+// fp8 companion of a split-weight copy (gemm_w2f8.hip): {e4m3 lo rows, per-row scale bytes}; filled at pack time for f16 towers and kept
+// next to the [hi | lo] rows pointer it belongs to (in the layer / the handle: no process-wide table, nothing shared between handles or threads)
+struct F8Pair { void* w8 = nullptr; void* s8 = nullptr; };
+static void use_split(GemmArgs& g, const void* w2, int K, const F8Pair& f8) {
     g.W = w2; g.K = 2 * K; g.a_wrap = K;
-    auto it = g_f8_of.find(w2);
-    if (it != g_f8_of.end()) { g.W8 = it->second.w8; g.w8_scale = it->second.s8; }
+    g.W8 = f8.w8; g.w8_scale = f8.s8;
 }
 struct ClipLayer { void *w_qkv, *w_o, *w_fc1, *w_fc2; float *b_qkv, *b_o, *b_fc1, *b_fc2, *g1, *be1, *g2, *be2;
                    // LayerNorm-folded copies: W . gamma (rounded), column sums of the rounded rows, bias + W beta
@@ -184,7 +184,9 @@ struct ClipLayer { void *w_qkv, *w_o, *w_fc1, *w_fc2; float *b_qkv, *b_o, *b_fc1
                    // split-weight copies [hi | lo] (GemmArgs::a_wrap) of the GEMMs in the tower's w2 mask; null otherwise
                    void *w_o2 = nullptr, *w_fc22 = nullptr;
                    // ... of the LayerNorm consumers: folded (W . gamma split, column sums of hi + lo) and plain (LayerNorms materialised)
-                   void *w_qkv_f2 = nullptr, *w_fc1_f2 = nullptr, *w_qkv2 = nullptr, *w_fc12 = nullptr; float *cs_qkv2 = nullptr, *cs_fc12 = nullptr; };
+                   void *w_qkv_f2 = nullptr, *w_fc1_f2 = nullptr, *w_qkv2 = nullptr, *w_fc12 = nullptr; float *cs_qkv2 = nullptr, *cs_fc12 = nullptr;
+                   // fp8 companions of the six split copies above (null pair: the f16 lo product runs)
+                   F8Pair f8_o2, f8_fc22, f8_qkv_f2, f8_fc1_f2, f8_qkv2, f8_fc12; };
 
 }  // namespace
 
@@ -199,7 +201,7 @@ struct ofx_handle {
     // towers
     int tw_dtype;
     int vit_w2_mask = 0, txt_x3 = 0, proj_x3 = 0, vit_x3 = 0;    // operand scheme (ofx_model_desc); x3 towers hold ONLY the K-concatenated [hi | hi | lo] weight copies
-    void* v_patch_w2 = nullptr; void* v_proj_w3 = nullptr;
+    void* v_patch_w2 = nullptr; void* v_proj_w3 = nullptr; F8Pair f8_patch;
     // training: events armed for the NEXT backward call (ofx_train_arm_layer_events), one per outfit-transformer layer
     std::vector<hipEvent_t> bwd_events;
     Arena a_vis; bool vis_ready = false;
@@ -337,13 +339,13 @@ extern "C" int ofx_pack_outfit_weights(ofx_handle* h, const void* const* P, int 
     return OFX_OK;
 }
 
-// fp8 copy of a split-weight matrix's lo halves (f16 towers, shapes gemm_w2f8 takes): registered for use_split
-static int pack_f8(Arena& A, const void* w2, size_t N, size_t K, int dt, hipStream_t s) {
-    g_f8_of.erase(w2);
+// fp8 copy of a split-weight matrix's lo halves (f16 towers, shapes gemm_w2f8 takes) -> `out` (a null pair where the shape / type has none)
+static int pack_f8(Arena& A, const void* w2, size_t N, size_t K, int dt, hipStream_t s, F8Pair& out) {
+    out = F8Pair{};
     if (dt != OFX_F16 || N % 128 || K % 128 || K < 256) return OFX_OK;
     char* w8 = A.take<char>(N * K); char* s8 = A.take<char>(N);
     TRY(ofx_launch_pack_lo8(w2, w8, s8, (int)N, (int)K, s));
-    g_f8_of[w2] = F8Pair{w8, s8};
+    out = F8Pair{w8, s8};
     return OFX_OK;
 }
 
@@ -371,6 +373,7 @@ static int pack_clip_layer(Arena& A, ClipLayer& L, const void* const* q, size_t 
     L.be2 = A.take<float>(W); TRY(copy_f32(L.be2, q[15], W, s));
     L.w_qkv_f = L.w_fc1_f = nullptr; L.cs_qkv = L.bf_qkv = L.cs_fc1 = L.bf_fc1 = nullptr; L.w_o2 = L.w_fc22 = nullptr;
     L.w_qkv_f2 = L.w_fc1_f2 = L.w_qkv2 = L.w_fc12 = nullptr; L.cs_qkv2 = L.cs_fc12 = nullptr;
+    L.f8_o2 = L.f8_fc22 = L.f8_qkv_f2 = L.f8_fc1_f2 = L.f8_qkv2 = L.f8_fc12 = F8Pair{};
     if (x3) return OFX_OK;
     // folded copies (q, k, v order as above: HF stores k, v, q, out in q[0..7])
     char* wf = A.take<char>(2 * 3 * W * W);
@@ -382,8 +385,8 @@ static int pack_clip_layer(Arena& A, ClipLayer& L, const void* const* q, size_t 
     L.w_fc1_f = A.take<char>(2 * MLP * W); L.cs_fc1 = A.take<float>(MLP); L.bf_fc1 = A.take<float>(MLP);
     TRY(ofx_launch_fold_pack((const float*)q[10], (const float*)q[14], (const float*)q[15], (const float*)q[11], L.w_fc1_f, L.cs_fc1, L.bf_fc1, (int)MLP, Wi, dt, s));
     // split-weight copies: row n = [hi(K) | lo(K)]
-    if (w2_mask & OFX_W2_OUT) { L.w_o2 = A.take<char>(4 * W * W); TRY(ofx_launch_pack_rows((const float*)q[6], L.w_o2, W, W, W, W, W, 3, dt, s)); TRY(pack_f8(A, L.w_o2, W, W, dt, s)); }
-    if (w2_mask & OFX_W2_FC2) { L.w_fc22 = A.take<char>(4 * W * MLP); TRY(ofx_launch_pack_rows((const float*)q[12], L.w_fc22, W, W, MLP, MLP, MLP, 3, dt, s)); TRY(pack_f8(A, L.w_fc22, W, MLP, dt, s)); }
+    if (w2_mask & OFX_W2_OUT) { L.w_o2 = A.take<char>(4 * W * W); TRY(ofx_launch_pack_rows((const float*)q[6], L.w_o2, W, W, W, W, W, 3, dt, s)); TRY(pack_f8(A, L.w_o2, W, W, dt, s, L.f8_o2)); }
+    if (w2_mask & OFX_W2_FC2) { L.w_fc22 = A.take<char>(4 * W * MLP); TRY(ofx_launch_pack_rows((const float*)q[12], L.w_fc22, W, W, MLP, MLP, MLP, 3, dt, s)); TRY(pack_f8(A, L.w_fc22, W, MLP, dt, s, L.f8_fc22)); }
     if (w2_mask & OFX_W2_QKV) {        // q | k | v blocks of [hi | lo] rows (row stride 2 W), folded and plain
         char* f2 = A.take<char>(4 * 3 * W * W); L.w_qkv_f2 = f2; L.cs_qkv2 = A.take<float>(3 * W);
         float* bf_scratch = A.take<float>(3 * W);       // bias + W beta is the same as the single copy's: recomputed into scratch
@@ -394,14 +397,14 @@ static int pack_clip_layer(Arena& A, ClipLayer& L, const void* const* q, size_t 
                                      L.cs_qkv2 + i * W, bf_scratch + i * W, Wi, Wi, dt, s, 1));
             TRY(ofx_launch_pack_rows((const float*)q[src[i]], p2 + (size_t)i * 4 * W * W, W, W, W, W, W, 3, dt, s));
         }
-        TRY(pack_f8(A, f2, 3 * W, W, dt, s)); TRY(pack_f8(A, p2, 3 * W, W, dt, s));       // one [3W, W] matrix each: q | k | v row blocks
+        TRY(pack_f8(A, f2, 3 * W, W, dt, s, L.f8_qkv_f2)); TRY(pack_f8(A, p2, 3 * W, W, dt, s, L.f8_qkv2));       // one [3W, W] matrix each: q | k | v row blocks
     }
     if (w2_mask & OFX_W2_FC1) {
         L.w_fc1_f2 = A.take<char>(4 * MLP * W); L.cs_fc12 = A.take<float>(MLP);
         float* bf_scratch = A.take<float>(MLP);
         TRY(ofx_launch_fold_pack((const float*)q[10], (const float*)q[14], (const float*)q[15], (const float*)q[11], L.w_fc1_f2, L.cs_fc12, bf_scratch, (int)MLP, Wi, dt, s, 1));
         L.w_fc12 = A.take<char>(4 * MLP * W); TRY(ofx_launch_pack_rows((const float*)q[10], L.w_fc12, MLP, MLP, W, W, W, 3, dt, s));
-        TRY(pack_f8(A, L.w_fc1_f2, MLP, W, dt, s)); TRY(pack_f8(A, L.w_fc12, MLP, W, dt, s));
+        TRY(pack_f8(A, L.w_fc1_f2, MLP, W, dt, s, L.f8_fc1_f2)); TRY(pack_f8(A, L.w_fc12, MLP, W, dt, s, L.f8_fc12));
     }
     return OFX_OK;
 }
@@ -429,8 +432,8 @@ extern "C" int ofx_pack_vision_weights(ofx_handle* h, const void* const* P, int 
     const int dt = h->tw_dtype;
     h->v_cls = A.take<float>(W); TRY(copy_f32(h->v_cls, P[0], W, s));
     h->v_patch_w = A.take<char>(2 * W * KP); TRY(ofx_launch_pack_rows((const float*)P[1], h->v_patch_w, W, W, KP, KP, KP, 0, dt, s));
-    h->v_patch_w2 = nullptr;
-    if (h->vit_w2_mask & OFX_W2_PATCH) { h->v_patch_w2 = A.take<char>(4 * W * KP); TRY(ofx_launch_pack_rows((const float*)P[1], h->v_patch_w2, W, W, KP, KP, KP, 3, dt, s)); TRY(pack_f8(A, h->v_patch_w2, W, KP, dt, s)); }
+    h->v_patch_w2 = nullptr; h->f8_patch = F8Pair{};
+    if (h->vit_w2_mask & OFX_W2_PATCH) { h->v_patch_w2 = A.take<char>(4 * W * KP); TRY(ofx_launch_pack_rows((const float*)P[1], h->v_patch_w2, W, W, KP, KP, KP, 3, dt, s)); TRY(pack_f8(A, h->v_patch_w2, W, KP, dt, s, h->f8_patch)); }
     h->v_pos = A.take<float>(S * W); TRY(copy_f32(h->v_pos, P[2], S * W, s));
     h->v_pre_g = A.take<float>(W); TRY(copy_f32(h->v_pre_g, P[3], W, s));
     h->v_pre_b = A.take<float>(W); TRY(copy_f32(h->v_pre_b, P[4], W, s));
@@ -725,12 +728,12 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
     if (fused) {
     } else if (fold) {
         g1.A = w.XB; g1.W = L.w_qkv_f; g1.bias = L.bf_qkv; g1.row_stat = w.S; g1.col_sum = L.cs_qkv;
-        if (qkv_w2) { use_split(g1, L.w_qkv_f2, W); g1.col_sum = L.cs_qkv2; wrow *= 2; }
+        if (qkv_w2) { use_split(g1, L.w_qkv_f2, W, L.f8_qkv_f2); g1.col_sum = L.cs_qkv2; wrow *= 2; }
     } else {
         LnArgs ln{w.X, nullptr, L.g1, L.be1, w.H, rows, W, W, OFX_OUT_OP, eps};
         TRY(ofx_launch_layernorm(ln, dt, s));
         g1.A = w.H; g1.W = L.w_qkv; g1.bias = L.b_qkv;
-        if (qkv_w2) { use_split(g1, L.w_qkv2, W); wrow *= 2; }
+        if (qkv_w2) { use_split(g1, L.w_qkv2, W, L.f8_qkv2); wrow *= 2; }
     }
     if (fused) {
     } else if (pool_idx && pool_first && g_prune_q) {
@@ -766,19 +769,19 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
     const bool hilo = fold && g_ln_fold == 2;      // residual stream = (XB, XLO) operand-type pair, no fp32 X (ofx_tune(6, 2))
     if (fold2) { g2.xb_out = w.XB; g2.stat_part = w.P; }
     if (fold2 && hilo) { g2.xlo = w.XLO; g2.C = w.XB; g2.ldc = W; g2.out_kind = OFX_OUT_OP; g2.resid = nullptr; }
-    if (L.w_o2) use_split(g2, L.w_o2, W);                                       // split weights: A . (hi + lo)^T
+    if (L.w_o2) use_split(g2, L.w_o2, W, L.f8_o2);                                       // split weights: A . (hi + lo)^T
     TRY(ofx_launch_gemm(g2, dt, s));
     GemmArgs g3{}; g3.C = U; g3.M = M; g3.N = MLP; g3.K = W; g3.lda = W;
     g3.ldc = MLP; g3.act = act; g3.out_kind = OFX_OUT_OP;
     if (fold2) {
         TRY(ofx_launch_stats_finalize(w.P, W / 64, W, eps, w.S, M, s));
         g3.A = w.XB; g3.W = L.w_fc1_f; g3.bias = L.bf_fc1; g3.row_stat = w.S; g3.col_sum = L.cs_fc1;
-        if (L.w_fc1_f2) { use_split(g3, L.w_fc1_f2, W); g3.col_sum = L.cs_fc12; }
+        if (L.w_fc1_f2) { use_split(g3, L.w_fc1_f2, W, L.f8_fc1_f2); g3.col_sum = L.cs_fc12; }
     } else {
         LnArgs ln2{X, nullptr, L.g2, L.be2, H, M, W, W, OFX_OUT_OP, eps};
         TRY(ofx_launch_layernorm(ln2, dt, s));
         g3.A = H; g3.W = L.w_fc1; g3.bias = L.b_fc1;
-        if (L.w_fc12) use_split(g3, L.w_fc12, W);
+        if (L.w_fc12) use_split(g3, L.w_fc12, W, L.f8_fc12);
     }
     if (pool_idx) { g3.slab = w.slab; g3.slab_bytes = w.slab_bytes; }
     TRY(ofx_launch_gemm(g3, dt, s));
@@ -787,7 +790,7 @@ static int clip_layer(const ClipLayer& L, const ClipWs& w, int rows, int nseq, i
     if (pool_idx) { g4.slab = w.slab; g4.slab_bytes = w.slab_bytes; }
     if (fold2) { g4.xb_out = w.XB; g4.stat_part = w.P; }
     if (fold2 && hilo) { g4.xlo = w.XLO; g4.C = w.XB; g4.ldc = W; g4.out_kind = OFX_OUT_OP; g4.resid = nullptr; }
-    if (L.w_fc22) use_split(g4, L.w_fc22, MLP);
+    if (L.w_fc22) use_split(g4, L.w_fc22, MLP, L.f8_fc22);
     TRY(ofx_launch_gemm(g4, dt, s));
     if (fold2) TRY(ofx_launch_stats_finalize(w.P, W / 64, W, eps, w.S, M, s));
     return OFX_OK;
@@ -890,7 +893,7 @@ static int vit_core(ofx_handle* h, const float* pixels, const RawImages* raw, in
             TRY(ofx_launch_patchify(pixels + (size_t)n0 * px_per_img, w.U, n, d.vit_image, d.vit_patch, dt, s));
         GemmArgs gp{}; gp.A = w.U; gp.W = h->v_patch_w; gp.C = w.QKV; gp.M = n * g * g; gp.N = W; gp.K = KP; gp.lda = KP; gp.ldc = W;
         gp.act = OFX_ACT_NONE; gp.out_kind = OFX_OUT_F32;
-        if (h->v_patch_w2) use_split(gp, h->v_patch_w2, (int)KP);
+        if (h->v_patch_w2) use_split(gp, h->v_patch_w2, (int)KP, h->f8_patch);
         TRY(ofx_launch_gemm(gp, dt, s));
         const bool fold = clip_fold(W) && !h->vit_x3;                    // the pre-LN kernel then also emits layer 0's operand copy + statistics
         TRY(ofx_launch_vit_embed_ln((const float*)w.QKV, h->v_cls, h->v_pos, h->v_pre_g, h->v_pre_b, fold && g_ln_fold == 2 ? nullptr : w.X, n, S, W, d.ln_eps, s, fold ? w.XB : nullptr,
@@ -1344,6 +1347,7 @@ extern unsigned long long* g_gemm_dbg;
 /* diagnostics: per-block {shader cycles, 100 MHz ticks} of the big-tile GEMM main loop go to buf (device, 16 B per block); NULL = off */
 extern "C" void ofx_debug_gemm_clock(void* buf) { g_gemm_dbg = (unsigned long long*)buf; }
 extern "C" int ofx_tune(int knob, int value) {
+    ++g_config_generation;
     switch (knob) {
         case 0: g_gemm_group_m = value; return OFX_OK;
         case 1: g_gemm_ablate = value; return OFX_OK;

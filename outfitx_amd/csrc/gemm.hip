@@ -211,7 +211,9 @@ int g_gemm_ablate = 0;    // diagnostics only (tools/gemm_bench.py)
 unsigned long long* g_gemm_dbg = nullptr;   // diagnostics only
 int g_gemm_pref = 2;      // short-K big GEMMs: 0 -> 256x128 kernel, 1 -> 256x256, 2 -> 256x256 ping-pong
 int g_w2_fp8 = 1;         // split-weight GEMMs that carry an fp8 copy of their lo halves run the fp8 correction product (gemm_w2f8.hip); 0 = the f16 one, ofx_tune(12, v)
-int g_w2_fp8_ashift = 2;  // activations enter the fp8 product as e4m3(a 2^shift): 2 keeps |a| >= 2^-8 out of the subnormal step and saturates at 112, ofx_tune(13, v)
+int ofx_w2f8_act_is_bf8();
+int g_w2_fp8_ashift = -99; // activations enter the fp8 product as fp8(a 2^shift), ofx_tune(13, v); -99 = the build's default: 0 for the e5m2 image (f16's exponent
+                          // range, nothing to choose), 2 for the e4m3 build (-DOFX_F8_ABF8=0: keeps |a| >= 2^-8 out of the subnormal step and saturates at 112)
 int g_x3_persist = 1;     // ofx_tune(16, v): 1 (default) gemm_x3_kernel launches one block per CU walking its tiles (when it has more tiles than CUs), 0 = one block per tile
 int g_x3_kernel = 1;      // three-product GEMMs (k_mult == 3: A rows [hi | lo | hi], W rows [hi | hi | lo]): 1 = the operand-tiles-loaded-once 256x128 kernel
                           // (gemm_x3.hip) from 192 tiles on, 2 = always, 0 = the K-concatenated single-product kernels; ofx_tune(15, v)
@@ -264,7 +266,7 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
         return OFX_OK;
     }));
     // big tiles when they still fill the chip, else the 128^2 kernel
-    int kind = g_gemm_kernel;
+    int kind = g_gemm_kernel == 6 ? 0 : g_gemm_kernel;      // 6 only forces the kernel of split-weight GEMMs; every other GEMM keeps the automatic choice
     if (g.a_wrap) {        // split weights: the dual-weight 256x256 kernel when its grid fills the chip, else the 128x128 kernel with a wrapping A index
         const long t2 = (long)((g.M + 255) / 256) * (g.N / 256);
         kind = (g.K == 2 * g.a_wrap && g.a_wrap % 32 == 0 && g.a_wrap >= 64 && g.N % 256 == 0 && (t2 >= 256 || g_gemm_kernel == 6) && g_gemm_kernel != 1) ? 6 : 1;
@@ -276,7 +278,7 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
         else if (g.N % 128 == 0 && t3 >= 512) kind = 3;                    // short K / mid-size M: 256x128, two blocks per CU
         else kind = 1;
     }
-    if (g.k_mult == 3 && !g.a_wrap && g_x3_kernel && g_gemm_kernel == 0 && g.K % 96 == 0 && g.N % 128 == 0 && g.lda >= g.K &&
+    if (g.k_mult == 3 && !g.a_wrap && g_x3_kernel && (g_gemm_kernel == 0 || g_gemm_kernel == 6) && g.K % 96 == 0 && g.N % 128 == 0 && g.lda >= g.K &&
         (g_x3_kernel >= 2 || (long)((g.M + 255) / 256) * (g.N / 128) >= 192))
         kind = 9;                  // the three products from ONE copy of each operand tile
     if ((kind == 2 || kind == 4) && g.N % 256) kind = 1;
@@ -300,7 +302,10 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
     if (kind == 2 || kind == 3 || kind == 4 || kind == 6 || kind == 8 || kind == 9) {
         k.group_m = g_gemm_group_m > 0 ? g_gemm_group_m : (kind == 3 ? 4 : 8);
         int rc;
-        if (kind == 8) { k.W8 = (const char*)g.W8; k.w8_scale = (const char*)g.w8_scale; k.a8_scale = ldexpf(1.0f, -g_w2_fp8_ashift); k.a8_e8m0 = 127 - g_w2_fp8_ashift; rc = ofx_gemm_launch_w2f8(&k, g.M, g.N, s); }
+        if (kind == 8) {
+            const int ash = g_w2_fp8_ashift == -99 ? (ofx_w2f8_act_is_bf8() ? 0 : 2) : g_w2_fp8_ashift;
+            k.W8 = (const char*)g.W8; k.w8_scale = (const char*)g.w8_scale; k.a8_scale = ldexpf(1.0f, -ash); k.a8_e8m0 = 127 - ash; rc = ofx_gemm_launch_w2f8(&k, g.M, g.N, s);
+        }
         else if (kind == 9) rc = ofx_gemm_launch_x3(&k, op_dtype, g.M, g.N, s);
         else if (kind == 6) rc = ofx_gemm_launch_w2(&k, op_dtype, g.M, g.N, s);
         else if (kind == 4) rc = ofx_gemm_launch_pp(&k, op_dtype, g.M, g.N, s);

@@ -9,14 +9,22 @@
 //
 // What makes it fit (tools/mx_probe.hip pins the instruction semantics used here):
 //   * the fp8 copy of the ACTIVATIONS never exists in memory: each wave converts the f16 A fragments it has just read for the f16
-//     product (v_cvt_scalef32_pk_fp8_f16, 2 elements per instruction, MODE.FP16_OVFL = 1 so that overflow saturates) and keeps them
-//     for the four k-steps of a super-step: fragment i's 8 VGPRs collect bytes 8 s + j <- k = 32 s + 8 g + j (s = k-step, g = lane
-//     >> 4) - a k-permutation inside the 128-block, harmless because the packed fp8 weights carry the same one (ofx_launch_pack_lo8);
+//     product (2 elements per instruction) and keeps them for the four k-steps of a super-step: fragment i's 8 VGPRs collect bytes
+//     8 s + j <- k = 32 s + 8 g + j (s = k-step, g = lane >> 4) - a k-permutation inside the 128-block, harmless because the packed
+//     fp8 weights carry the same one (ofx_launch_pack_lo8);
+//   * round 4: the activation image is E5M2 (v_cvt_scalef32_pk_bf8_f16, the instruction's second operand read as bf8: blgp = 1), not
+//     E4M3.  e5m2 has f16's exponent field, so the image follows WHATEVER the f16 operand holds - massive residual-stream channels in
+//     the hundreds (trained CLIP ViTs have them, and with LayerNorm folding the raw stream is the A operand of qkv and fc1), values
+//     down to f16's subnormals - at 3 significant bits, with no scale to choose and nothing that saturates below 57,344 (MODE.
+//     FP16_OVFL = 1 clamps the f16 values above that instead of producing infinities).  The e4m3 image of rounds 3 (4 significant
+//     bits, x4 scale) saturated at |a| > 112 and then corrected only part of such a channel.  Price: the activation side of the
+//     2^-11 correction term is kept to 2^-4 instead of 2^-5 relative - still far below the f16 rounding of the main product
+//     (tests/studies/fp8_correction_cpu.py); same instruction rate (tools/mfma_power_probe.hip).  -DOFX_F8_ABF8=0 builds the e4m3 form.
 //   * the wave tile is 64 x 128 (8 waves as 4 x 2), so only 4 activation fragments = 32 VGPRs are held; the 8 weight fragments of the
 //     fp8 step stream through a 3-deep register ring loaded two fragments ahead of their use (128 accumulators + 32 + 24, in the
 //     registers the f16 fragments have just left);
 //   * per-row weight scales (E8M0, max |lo| 2^sw in [128, 256)) ride in as the instruction's per-lane scale operand, the activation
-//     scale (x4: values below 2^-8 would otherwise fall under the e4m3 subnormal step) as the other one.
+//     scale (2^0 for the e5m2 image; the e4m3 build used x4: values below 2^-8 would otherwise fall under its subnormal step) as the other one.
 //
 // Structure: gemm_w2.hip's ping-pong (two wave groups one barrier slot apart, BK = 32, counted vmcnt, persistent over tiles) with FOUR
 // 32 KiB stages [A | W_hi] and ONE 32 KiB buffer for the current super-step's fp8 weights (160 KiB in all).  The kernels of this
@@ -38,6 +46,9 @@
 #include "gemm_common.h"
 
 extern int g_w2_persist, g_w2_trim;
+#ifndef OFX_F8_ABF8
+#define OFX_F8_ABF8 1
+#endif
 #ifndef OFX_F8_PRIO
 #define OFX_F8_PRIO 1
 // f16 MFMA order: 1 = the weight fragment (the instruction's FIRST operand) stays over 4 consecutive MFMAs while the activation fragment cycles.
@@ -182,13 +193,20 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
         _Pragma("unroll") for (int i = 0; i < 4; ++i) af[i] = *(OFX_LDS v8*)(base_ + a_frag + i * 16 * 64);    \
     }
         // 32 f16 MFMAs + the conversion of the four A fragments into bytes 8 S .. 8 S + 7 of their fp8 images (S = step & 3, static)
+#if OFX_F8_ABF8
+#define OFX_F8_CVT_PK __builtin_amdgcn_cvt_scalef32_pk_bf8_f16
+#define OFX_F8_BLGP 1
+#else
+#define OFX_F8_CVT_PK __builtin_amdgcn_cvt_scalef32_pk_fp8_f16
+#define OFX_F8_BLGP 0
+#endif
 #define OFX_F8_CVT1(I, S)                                                                                      \
     {                                                                                                         \
         i16x2 lo_ = __builtin_bit_cast(i16x2, a8[I][2 * (S)]), hi_ = __builtin_bit_cast(i16x2, a8[I][2 * (S) + 1]); \
-        lo_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(lo_, f16x2{af[I][0], af[I][1]}, a_scale, false);       \
-        lo_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(lo_, f16x2{af[I][2], af[I][3]}, a_scale, true);        \
-        hi_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(hi_, f16x2{af[I][4], af[I][5]}, a_scale, false);       \
-        hi_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(hi_, f16x2{af[I][6], af[I][7]}, a_scale, true);        \
+        lo_ = OFX_F8_CVT_PK(lo_, f16x2{af[I][0], af[I][1]}, a_scale, false);                                  \
+        lo_ = OFX_F8_CVT_PK(lo_, f16x2{af[I][2], af[I][3]}, a_scale, true);                                   \
+        hi_ = OFX_F8_CVT_PK(hi_, f16x2{af[I][4], af[I][5]}, a_scale, false);                                  \
+        hi_ = OFX_F8_CVT_PK(hi_, f16x2{af[I][6], af[I][7]}, a_scale, true);                                   \
         a8[I][2 * (S)] = __builtin_bit_cast(int, lo_); a8[I][2 * (S) + 1] = __builtin_bit_cast(int, hi_);      \
     }
 #define OFX_F8_MFMA16(S)                                                                                      \
@@ -218,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
 #define OFX_F8_MF(J, SEL, SC)                                                                                 \
     if ((J) + 2 < 8) { OFX_F8_LD((J) + 2) __builtin_amdgcn_sched_barrier(0); }     /* keep the load two fragments ahead of its use */ \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
-        acc[i][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8_[(J) % 3], a8[i], acc[i][J], 0, 0, SEL, SC, 0, a_e8);
+        acc[i][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8_[(J) % 3], a8[i], acc[i][J], 0, OFX_F8_BLGP, SEL, SC, 0, a_e8);
 #define OFX_F8_MFMA8()                                                                                      \
     if (ABL != 4 && (ABL < 5 || ABL == 7)) {                                                                                \
         __builtin_amdgcn_sched_barrier(0);      /* the fp8 fragments take the registers the f16 fragments leave: no hoisting above */ \
@@ -245,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // a ragged previous tile skipped stores: wait for everything
         }
         asm volatile("" : "+v"(sc_lo), "+v"(sc_hi));                  // the scale load is waited for HERE, not inside the counted-vmcnt loop
-        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");     // MODE.FP16_OVFL: f16 -> fp8 saturates at +-448 instead of NaN
+        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");     // MODE.FP16_OVFL: the f16 -> fp8 conversion clamps at the format's largest finite value (e5m2: 57,344; e4m3: 448) instead of inf / NaN
         __builtin_amdgcn_s_barrier();                               // ---- end of slot 0
         if (ABL == 7 && !first) { OFX_F8_STAMP(st1_) gap_cyc += (unsigned)(st1_ - st0_); }
         // One iteration of group 0 (slots 2t+1, 2t+2) / group 1 (slots 2t+2, 2t+3), as in gemm_w2.hip; NV = the LDS-DMA pieces the
@@ -321,6 +339,8 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
 #undef OFX_F8_MF
 #undef OFX_F8_LD
 #undef OFX_F8_CVT1
+#undef OFX_F8_CVT_PK
+#undef OFX_F8_BLGP
 #undef OFX_F8_ISSUE_AW
 #undef OFX_F8_ISSUE_W8
         asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 0");     // the epilogue's f32 -> f16 casts keep the default overflow behaviour
@@ -417,6 +437,8 @@ __global__ __launch_bounds__(256) void pack_lo8_kernel(const f16_t* src, unsigne
 }
 
 }  // namespace
+
+int ofx_w2f8_act_is_bf8() { return OFX_F8_ABF8; }
 
 extern int g_gemm_ablate;
 int ofx_gemm_launch_w2f8(void* kargs, int M, int N, hipStream_t s) {

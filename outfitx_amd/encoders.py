@@ -427,20 +427,25 @@ class CLIPTextEncoder(_TowerBase):
         return uniq_ids.contiguous(), (None if uniq_att is None else uniq_att.contiguous()), torch.from_numpy(inv.astype(np.int64))
 
     def _cache_plan(self, ids: torch.Tensor, att: Optional[torch.Tensor]):
-        """cache_texts: (table row per input row [n] int64, indices of the first occurrence of every row the table lacks, first new slot)."""
+        """cache_texts: (table row per input row [n] int64, indices of the first occurrence of every row the table lacks, their keys,
+        first new slot).  Nothing is registered here: the new keys enter `_cache_rows` only once the tower has filled their slots
+        (`_run`), so a plan that is never run - or whose tower call raises - leaves no key pointing at an uninitialised table row."""
         a = ids.numpy()
         key = a if att is None else a * 2 + att.numpy().astype(a.dtype)
         rows = np.empty(a.shape[0], np.int64)
-        miss, nxt = [], len(self._cache_rows)
+        slot0 = len(self._cache_rows)
+        miss, new_keys, pending = [], [], {}
         for i in range(a.shape[0]):
             k = key[i].tobytes()
             r = self._cache_rows.get(k)
             if r is None:
-                r = self._cache_rows[k] = nxt
-                nxt += 1
-                miss.append(i)
+                r = pending.get(k)
+                if r is None:
+                    r = pending[k] = slot0 + len(miss)
+                    miss.append(i)
+                    new_keys.append(k)
             rows[i] = r
-        return rows, miss, nxt - len(miss)
+        return rows, miss, new_keys, slot0
 
     @torch.no_grad()
     def prepare(self, texts, tokenizer_kargs=None):
@@ -452,8 +457,8 @@ class CLIPTextEncoder(_TowerBase):
             state = tuple(p._version for p in self.model.parameters())
             if state != self._cache_state:                                          # the tower's weights changed: every cached row is stale
                 self._cache_rows, self._cache_table, self._cache_state = {}, None, state
-            rows, miss, slot0 = self._cache_plan(ids, att)
-            plan = {"rows": torch.from_numpy(rows).to(self.device, non_blocking=True), "slot0": slot0, "n_new": len(miss)}
+            rows, miss, new_keys, slot0 = self._cache_plan(ids, att)
+            plan = {"rows": torch.from_numpy(rows).to(self.device, non_blocking=True), "slot0": slot0, "n_new": len(miss), "new_keys": new_keys}
             if miss:
                 sel = torch.as_tensor(miss, dtype=torch.long)
                 m_ids = ids.index_select(0, sel).contiguous()
@@ -476,6 +481,8 @@ class CLIPTextEncoder(_TowerBase):
             if self._cache_table is not None and getattr(self, "_cache_norm", normalize) != normalize:
                 raise ValueError("cache_texts: the cache was filled with normalize=%s; clear it (set cache_texts again) before changing the flag" % (not normalize))
             self._cache_norm = normalize
+            if plan["slot0"] != len(self._cache_rows):
+                raise RuntimeError("cache_texts: this prepared batch is stale (another batch was prepared and run, or the cache was cleared, since prepare()); prepare it again")
             need = plan["slot0"] + plan["n_new"]
             if self._cache_table is None or self._cache_table.shape[0] < need:
                 grown = torch.empty(max(need, 256, 2 * (0 if self._cache_table is None else self._cache_table.shape[0])), d, dtype=torch.float32, device=self.device)
@@ -484,6 +491,8 @@ class CLIPTextEncoder(_TowerBase):
                 self._cache_table = grown
             if plan["n_new"]:
                 eng.text(plan["ids"], plan["att"], self._cache_table[plan["slot0"]:need], 0, normalize, plan["lengths"])
+                for j, k in enumerate(plan["new_keys"]):                  # registered only now: their table rows exist (in stream order)
+                    self._cache_rows[k] = plan["slot0"] + j
                 self.cache_tower_rows += plan["n_new"]
             out[:, col:col + d] = self._cache_table.index_select(0, plan["rows"])
             return
@@ -560,31 +569,32 @@ class ItemEncoder(nn.Module):
         self.image_enc.tower_precision = tower_precision
         self.text_enc.tower_precision = tower_precision
 
-    def forward(self, images, texts, *args, **kwargs) -> torch.Tensor:
+    def forward(self, images, texts, *args, prepared_texts=None, **kwargs) -> torch.Tensor:
+        """prepared_texts: the tuple CLIPTextEncoder.prepare returns, for callers that staged the tokens themselves (graphs.ForwardReplay)."""
         if self.cfg.aggregation_method == "concat":
             # concat fuser fused into the towers' epilogues: both write straight into one [B*L,1024] buffer
             dev = self.image_enc.device
             n = (images.size(0) * images.size(1)) if isinstance(images, torch.Tensor) else sum(len(s) for s in images)
             d = self.cfg.dim_per_modality
             out = torch.empty(n, 2 * d, dtype=torch.float32, device=dev)
-            prepared = self.text_enc.prepare(texts)            # host work + H2D first, then both towers are enqueued back to back
+            prepared = prepared_texts if prepared_texts is not None else self.text_enc.prepare(texts)   # host work + H2D first, then both towers are enqueued back to back
             if self.overlap_towers and dev.type == "cuda":
                 # the text tower is independent of the image tower: on a side HIP stream its small kernels fill the
                 # tile-quantisation tails of the big ViT GEMMs; both write disjoint columns of `out`
                 main = torch.cuda.current_stream(dev)
                 side = self._side_stream(dev)
                 side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    b2 = self.text_enc.encode_into(texts, out, d, self.cfg.norm_out, prepared=prepared)
                 # No record_stream on `out` / the prepared token tensors: they are allocated on `main`, and `main` joins `side` below before
                 # anything later on `main` can run - so when their blocks return to main's pool and are handed out again, that use is
                 # ordered after the side stream's last access.  (record_stream would defer every free until the device has caught up with
                 # the host, which runs steps ahead: the allocator then keeps calling hipMalloc inside steady-state steps - 7-9 calls per 10
                 # steps in bench.py, +1-2 ms each and now and then a step at half speed.)
                 try:
+                    with torch.cuda.stream(side):
+                        b2 = self.text_enc.encode_into(texts, out, d, self.cfg.norm_out, prepared=prepared)
                     b = self.image_enc.encode_into(images, out, 0, self.cfg.norm_out)
                 finally:
-                    main.wait_stream(side)                     # the join the comment above relies on, also when the image tower raises
+                    main.wait_stream(side)                     # the join the comment above relies on, also when either tower raises
             else:
                 b = self.image_enc.encode_into(images, out, 0, self.cfg.norm_out)
                 b2 = self.text_enc.encode_into(texts, out, d, self.cfg.norm_out, prepared=prepared)

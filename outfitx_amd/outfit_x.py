@@ -195,6 +195,11 @@ class OutfitX(nn.Module):
                                                     # compatibility_prediction_trainer.py:63; bf16 has the same 8-bit-or-better products and fp32's range)
         self.item_encoder.set_precision(tower_precision)
         self._engines: Dict[Any, Engine] = {}
+        # eval-mode `model(task=CP, outfit_embedding=None, ..., encoder_input_dict={'images': device tensor, 'texts': token dict})` calls of a
+        # repeated shape are stream-captured on their second occurrence and replayed as ONE graph launch from the third on (graphs.ForwardReplay:
+        # same kernels, bit-identical logits, a fresh result tensor per call); False = every call launch by launch
+        self.graph_replay = True
+        self._replay = None
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -204,6 +209,7 @@ class OutfitX(nn.Module):
     def __getstate__(self):
         s = self.__dict__.copy()
         s["_engines"] = {}
+        s["_replay"] = None
         return s
 
     def mark_weights_changed(self) -> None:
@@ -213,6 +219,8 @@ class OutfitX(nn.Module):
         hook below, and trainer.CPTrainer calls it explicitly."""
         for eng in self._engines.values():
             eng.signature["outfit"] = None
+        if getattr(self, "_replay", None) is not None:
+            self._replay.clear()              # captured steps launch on the packed copies of the old weights
 
     def _outfit_tensors(self) -> List[torch.Tensor]:
         out = [self.outfit_token, self.target_item_image_emb, self.cp_ffn[1].weight, self.cp_ffn[1].bias, self.cir_ffn[0].weight]
@@ -292,12 +300,27 @@ class OutfitX(nn.Module):
             return eng.cp_head(eng.set_encoder_indexed(*spec))
         prec = None
         if encoder_input_dict is not None:
+            if outfit_embedding is None and not self.training and getattr(self, "graph_replay", False):
+                from .graphs import ForwardReplay
+                if ForwardReplay.eligible(self, outfit_mask, encoder_input_dict):
+                    if self._replay is None:
+                        self._replay = ForwardReplay()
+                    return self._replay.run(self, outfit_mask, encoder_input_dict,
+                                            lambda: self._cp_eval(outfit_mask, encoder_input_dict["images"], None, encoder_input_dict["texts"]))
             outfit_embedding = self.item_encoder(**encoder_input_dict)
             prec = self._tower_fed()
         if self.training and torch.is_grad_enabled():
             return self._cp_train_forward(outfit_embedding, outfit_mask)
         eng, row0 = self._run_encoder(outfit_embedding, outfit_mask, precision=prec)
         return eng.cp_head(row0)
+
+    def _cp_eval(self, outfit_mask, images, prepared_texts, texts=None) -> torch.Tensor:
+        """The eval-mode CP call with the item encoder in it, launch by launch (what graphs.ForwardReplay captures; `prepared_texts` =
+        tokens already staged on the device)."""
+        with torch.no_grad():
+            emb = self.item_encoder(images, texts, prepared_texts=prepared_texts)
+            eng, row0 = self._run_encoder(emb, outfit_mask, precision=self._tower_fed())
+            return eng.cp_head(row0)
 
     def sink_ready(self, skip=(1, 4)) -> bool:
         """True when the next CP backward will add straight into the parameters' own .grad buffers (gradient-sink mode with a dense

@@ -54,8 +54,14 @@ def sharded_topk(queries: torch.Tensor, pool_shard: torch.Tensor, k: int, shard_
     rec = torch.empty(nb_i + nb_d, dtype=torch.uint8, device=idx.device)
     rec[:nb_i] = idx.contiguous().view(torch.uint8).reshape(-1)
     rec[nb_i:] = dst.contiguous().view(torch.uint8).reshape(-1)
-    flat = torch.empty(world * (nb_i + nb_d), dtype=torch.uint8, device=idx.device)     # 1-D: the form RCCL and gloo both accept
-    dist.all_gather_into_tensor(flat, rec, group=group)
+    if idx.device.type == "cuda" and dist.get_backend(group) == "gloo":
+        # gloo has no device all-gather: the record goes through the host (CPU rehearsals of the N > 1 path on a one-GPU box; RCCL takes device memory)
+        host = torch.empty(world * (nb_i + nb_d), dtype=torch.uint8)
+        dist.all_gather_into_tensor(host, rec.cpu(), group=group)
+        flat = host.to(idx.device)
+    else:
+        flat = torch.empty(world * (nb_i + nb_d), dtype=torch.uint8, device=idx.device)     # 1-D: the form RCCL and gloo both accept
+        dist.all_gather_into_tensor(flat, rec, group=group)
     allrec = flat.view(world, nb_i + nb_d)
     idx_all = allrec[:, :nb_i].contiguous().view(torch.int64).view((world,) + tuple(idx.shape))
     dst_all = allrec[:, nb_i:].contiguous().view(torch.float32).view((world,) + tuple(dst.shape))

@@ -169,6 +169,28 @@ def full_state_dict(seed: int) -> Dict[str, np.ndarray]:
     return sd
 
 
+def outlier_channels(sd: Dict[str, np.ndarray], level: int = 1) -> Dict[str, np.ndarray]:
+    """A copy of a full state dict whose ViT carries massive activations, as trained CLIP ViTs do (a handful of hidden dimensions one
+    to two orders of magnitude above the rest; every parity fixture otherwise comes from O(1) random-init weights):
+      level 1: pre-LayerNorm gains and class-embedding entries of 3 residual-stream channels x 30, one fc2 output row (layer 3) x 20;
+      level 2: those 3 channels x 100 (residual-stream values in the hundreds: with LayerNorm folding the RAW stream is the A operand
+               of qkv and fc1), one fc2 output row x 50, and fc1 rows 77 of layers 2 and 6 (weight and bias) x 50, so that single
+               hidden units of the MLP - fc2's A operand - run into the hundreds as well."""
+    sd = dict(sd)
+    p = IMG_PREFIX + "vision_model."
+    f_chan, f_row = (30.0, 20.0) if level == 1 else (100.0, 50.0)
+    for k in (p + "pre_layrnorm.weight", p + "embeddings.class_embedding"):
+        v = sd[k].copy(); v[[5, 100, 700]] *= np.float32(f_chan); sd[k] = v
+    k = p + "encoder.layers.3.mlp.fc2.weight"
+    v = sd[k].copy(); v[333] *= np.float32(f_row); sd[k] = v
+    if level >= 2:
+        for l in (2, 6):
+            for leaf in ("weight", "bias"):
+                k = p + f"encoder.layers.{l}.mlp.fc1.{leaf}"
+                v = sd[k].copy(); v[77] *= np.float32(50.0); sd[k] = v
+    return sd
+
+
 # ---- inputs ---------------------------------------------------------------
 def item_embeddings(seed: int, name: str, *lead: int) -> np.ndarray:
     """[*lead, 1024] fp32 rows shaped like ItemEncoder output: each 512-half L2-normalised

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.ofx_abi_version() == 4
+    assert lib.ofx_abi_version() == 5
     d = _lib.default_desc()
     assert (d.d_model, d.n_head, d.d_ffn, d.n_layers, d.vit_width, d.txt_width, d.proj_dim) == (1024, 16, 2024, 6, 768, 512, 512)
 

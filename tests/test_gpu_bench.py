@@ -31,6 +31,8 @@ def test_bench_single_gpu_line_has_the_contract_fields():
     assert abs(j["value"] - 64 * 3 / (j["ms_per_step"] * 3e-3)) <= 1e-3 * j["value"]
     assert j["parity_rel_err_vs_oracle"] < 1e-3                      # the headline mode is the 1e-3-compliant one
     assert j["config"]["launch"].startswith("one HIP graph launch per step")      # the default: steps replayed from the captured graph, logits checked equal
+    lbl = j["launch_by_launch"]                                       # the same call with graph replay off, reported beside the headline
+    assert lbl["bit_identical_to_replayed"] is True and lbl["ms_per_step"] > 0 and lbl["steps"] == 10
     sp = j["step_ms_spread"]
     assert len(sp["all"]) == 3 and len(sp["host_issue_ms"]) == 3 and sp["device_allocs_in_timed_region"] <= 2
     rf, cb = j["roofline"], j["cpu_baseline"]
@@ -50,7 +52,8 @@ def test_bench_two_ranks_rehearsal():
     env = dict(os.environ, OFX_BENCH_REHEARSAL="1")
     env.pop("OMP_NUM_THREADS", None)                               # bench.py caps its host threads per rank itself (host_cores() // world)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--outfits", "32"],
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--outfits", "32",
+                        "--cir-queries", "200", "--cir-pool", "20000"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _json_line(r.stdout)
@@ -63,3 +66,6 @@ def test_bench_two_ranks_rehearsal():
     assert len(rk["elapsed_s"]) == 2 and abs(max(rk["elapsed_s"]) - j["ms_per_step"] * 2e-3) <= 2e-3 * max(rk["elapsed_s"])     # MAX over ranks is the job's time
     assert all(t >= 1 for t in rk["host_threads"])
     assert rk["graph_launch"] == [True, True]                      # every rank replays its own captured step
+    # the one data-path collective the north star names (CIR: pool row-sharded, ONE all-gather of the per-shard candidate lists) ran across the two
+    # ranks and reproduced rank 0's unsharded top-k exactly
+    assert rk["cir_equal"] is True and rk["cir_allgather_ms"] > 0 and rk["cir_local_topk_ms_rank0"] > 0

@@ -195,8 +195,53 @@ def test_topk_full_size_properties_and_sharded_merge():
     oi, od = O.l2_topk(Q[:64], P, k)                            # oracle on a 64-query subset
     assert rel_err(dist[:64], od) < 1e-6
     mism = idx[:64] != oi
-    # an index may differ from the oracle only where the two candidates' distances tie within fp32 rounding
-    assert mism.mean() < 1e-3 and np.allclose(dist[:64][mism], od[mism], rtol=3e-7, atol=0)
+    # no tolerance on how many: an index may differ from the oracle ONLY where the two candidates' exact (float64, direct-form) distances
+    # agree to within fp32 rounding of the |q|^2 + |p|^2 - 2 q.p form, i.e. where the order is not defined at fp32 (the numpy oracle and the
+    # kernel sum the 1,024 products in different orders); the bit-exact comparison against the reference's own output at this size is
+    # test_topk_cfg4_vs_the_reference_fixture below
+    qs, js = np.nonzero(mism)
+    print(f"top-k 1000 x 100k vs the numpy oracle on 64 queries: {mism.sum()} of {mism.size} positions differ")
+    if len(qs):
+        d_ours = np.linalg.norm(Q[qs].astype(np.float64) - P[idx[:64][qs, js]].astype(np.float64), axis=-1)
+        d_orcl = np.linalg.norm(Q[qs].astype(np.float64) - P[oi[qs, js]].astype(np.float64), axis=-1)
+        assert (np.abs(d_ours - d_orcl) <= 4e-7 * d_orcl).all()
+
+
+def test_topk_cfg4_vs_the_reference_fixture():
+    """BASELINE configs[3] at FULL size - 1,000 queries x 100,000 pool rows, k = 50 - against the reference's own call
+    (complementary_item_retrieval_trainer.py:241-242: torch.cdist + torch.topk(largest=False), fp32 CPU; tests/golden/topk_cfg4.npz from
+    oracle/gen_topk_golden.py).  torch.equal on every query whose 51 best exact distances are separated by more than fp32 rounding (the
+    fixture's float64 `gap_rel`); on the others (the reference's own order there is decided by the summation order of its sgemm: 186 of the
+    50,000 positions sit within 4e-7 relative of their neighbour, and on 18 the reference's fp32 order is the reverse of the exact one) every
+    differing position must be such a near-tie - counted and printed, no tolerance on anything else."""
+    from outfitx_amd.engine import Engine
+    g = golden("topk_cfg4")
+    nq, npool, k = int(g["nq"]), int(g["np_"]), int(g["k"])
+    Q = (synth.item_embeddings(int(g["seed"]), "queries", nq) * 3.0).astype(np.float32)
+    P = synth.item_embeddings(int(g["seed"]), "pool", npool)
+    P[70_000:70_010] = P[123]
+    assert synth.checksum(Q) == str(g["q_crc"]) and synth.checksum(P[:4096]) == str(g["p_crc"])
+    eng = Engine(torch.device("cuda", 0))
+    idx, dist = eng.l2_topk(cu(Q), cu(P), k)
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    ref_i, ref_d, gap = g["topk_idx"].astype(np.int64), g["topk_dist"], g["gap_rel"]
+    assert rel_err(dist, ref_d) < 1e-6
+    clean = (np.abs(gap) >= 4e-7).all(1)                       # queries whose selection AND order are defined at fp32
+    assert clean.sum() > 0.8 * nq
+    assert np.array_equal(idx[clean], ref_i[clean])            # bit-exact indices wherever the problem defines them
+    mism = idx != ref_i
+    qs, js = np.nonzero(mism)
+    print(f"top-k cfg4 vs the reference's own output: {int(clean.sum())} of {nq} queries have no fp32 near-tie among their best 51 and are index-exact; "
+          f"{int(mism.sum())} of {mism.size} positions differ, all on the other {int((~clean).sum())} queries")
+    if len(qs):
+        d_ours = np.linalg.norm(Q[qs].astype(np.float64) - P[idx[qs, js]].astype(np.float64), axis=-1)
+        d_ref = np.linalg.norm(Q[qs].astype(np.float64) - P[ref_i[qs, js]].astype(np.float64), axis=-1)
+        rel = np.abs(d_ours - d_ref) / d_ref
+        worst = np.argsort(-rel)[:5]
+        print("  largest exact-distance differences among the differing positions: " +
+              ", ".join(f"query {qs[w]} rank {js[w]}: rows {idx[qs[w], js[w]]} / {ref_i[qs[w], js[w]]} ({rel[w]:.1e})" for w in worst))
+        assert (rel <= 4e-7).all()
+        assert mism.sum() <= 2 * int((np.abs(gap) < 4e-7).sum())   # a near-tie swaps at most its two positions
 
 
 def test_fitb_full_size_cfg3(model):
@@ -637,7 +682,8 @@ def test_text_cache_runs_the_tower_on_unseen_rows_only_and_drops_on_weight_chang
             assert enc.cache_tower_rows - n0 == len(set(p1.tolist()))
             c2 = enc(tok(p2)).view(150, 512).clone()
             assert enc.cache_tower_rows - n0 == len(set(p1.tolist()) | set(p2.tolist()))        # only the unseen rows ran
-            assert rel_err(c1.cpu().numpy(), plain1.cpu().numpy()) < 2e-2 and rel_err(c2.cpu().numpy(), plain2.cpu().numpy()) < 2e-2
+            # same rows through a tower call of another batch composition (other GEMM M -> other tile / split-K plans): fp32 summation order only
+            assert rel_err(c1.cpu().numpy(), plain1.cpu().numpy()) < 1e-4 and rel_err(c2.cpu().numpy(), plain2.cpu().numpy()) < 1e-4
             for k in range(3, 6):                                       # a row cached by call 1 is the same bytes in call 2
                 assert torch.equal(c1[torch.from_numpy(p1 == k)][0], c2[torch.from_numpy(p2 == k)][0])
             # through the item encoder (side stream): equal to the plain item encoder's text half
@@ -646,7 +692,21 @@ def test_text_cache_runs_the_tower_on_unseen_rows_only_and_drops_on_weight_chang
             enc.cache_texts = False
             items_p = model.item_encoder(px, tok(np.arange(6)))
             enc.cache_texts = True
-            assert rel_err(items_c[..., 512:].cpu().numpy(), items_p[..., 512:].cpu().numpy()) < 2e-2
+            assert rel_err(items_c[..., 512:].cpu().numpy(), items_p[..., 512:].cpu().numpy()) < 1e-4
+            # a prepared plan that is never run registers nothing (its slots were never filled) ...
+            fresh_ids, fresh_att = synth.token_batch(95, 4, 64, 8)
+            fresh = {"input_ids": torch.from_numpy(fresh_ids).view(4, 1, 64), "attention_mask": torch.from_numpy(fresh_att).view(4, 1, 64)}
+            n_keys = len(enc._cache_rows)
+            stale = enc.prepare(fresh)
+            assert len(enc._cache_rows) == n_keys
+            # ... the same rows then run through a second plan, and the first (now stale) plan is refused instead of gathering garbage
+            c3 = enc(fresh).view(4, 512).clone()
+            enc.cache_texts = False
+            p3 = enc(fresh).view(4, 512).clone()
+            enc.cache_texts = True
+            assert rel_err(c3.cpu().numpy(), p3.cpu().numpy()) < 1e-4 and len(enc._cache_rows) == n_keys + 4
+            with pytest.raises(RuntimeError):
+                enc.encode_into(fresh, torch.empty(4, 512, device="cuda"), 0, True, prepared=stale)
             # a parameter update invalidates the table
             w = enc.model.text_projection.weight
             before = enc.cache_tower_rows
@@ -716,19 +776,13 @@ def test_set_transformer_precision_follows_the_embedding_source(model):
     assert rel_err(a, ref) < 3e-2 and rel_err(b, ref) < 3e-2
 
 
-def _outlier_channels(sd):
-    """Give the ViT's residual stream a few massive channels, as trained CLIP ViTs have (a handful of hidden dimensions one to two
-    orders of magnitude above the rest): pre-LayerNorm gains and class-embedding entries of 3 channels x 30, one MLP output row x 20."""
-    sd = dict(sd)
-    p = synth.IMG_PREFIX + "vision_model."
-    for k, f in ((p + "pre_layrnorm.weight", 30.0), (p + "embeddings.class_embedding", 30.0)):
-        v = sd[k].copy(); v[[5, 100, 700]] *= f; sd[k] = v
-    k = p + "encoder.layers.3.mlp.fc2.weight"
-    v = sd[k].copy(); v[333] *= 20.0; sd[k] = v
-    return sd
+def _outlier_channels(sd, level=1):
+    """Massive residual-stream channels / MLP units, as trained CLIP ViTs have: outfitx_amd.synth.outlier_channels (shared with
+    oracle/gen_bench_golden.py, which writes the reference's own logits for the same weights)."""
+    return synth.outlier_channels(sd, level)
 
 
-def _cfg2_end_to_end(wseed, towers, bound):
+def _cfg2_end_to_end(wseed, towers, bound, outlier_level=1, force_split_kernel=False):
     """BASELINE configs[1] end to end (images + token ids -> towers -> fuser -> set transformer -> CP logit) in the DEFAULT operand
     scheme - the one bench.py measures - against the fp32 oracle O.cp_forward(O.item_encoder(...)), on six independent weight
     draws (the error is dominated by a fixed, per-weight-set perturbation, so the seed, not the input batch, is what varies it;
@@ -746,7 +800,7 @@ def _cfg2_end_to_end(wseed, towers, bound):
     assert m.item_encoder.image_enc.tower_precision == (towers or DEFAULT_TOWERS) and m.precision == "bf16x3"
     sd = synth.full_state_dict(wseed)
     if outliers:
-        sd = _outlier_channels(sd)
+        sd = _outlier_channels(sd, outlier_level)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     m = m.cuda().eval()
     B, L = 8, 8
@@ -757,14 +811,22 @@ def _cfg2_end_to_end(wseed, towers, bound):
     ids, att = synth.token_batch(9000 + wseed, B * L, 64, 8)
     texts = {"input_ids": torch.from_numpy(ids).view(B, L, 64), "attention_mask": torch.from_numpy(att).view(B, L, 64)}
     mask = np.zeros((B, L), bool)
-    with torch.no_grad():
-        got = m(task=CP, outfit_embedding=None, outfit_mask=cu(mask), encoder_input_dict={"images": px.cuda(), "texts": texts}).cpu().numpy()
+    from outfitx_amd import _lib as L_
+    lib = L_.load()
+    if force_split_kernel:
+        lib.ofx_tune(2, 6)          # every split-weight GEMM through the 256x256 kernel with the fp8 correction product, whatever its grid
+    try:
+        with torch.no_grad():
+            got = m(task=CP, outfit_embedding=None, outfit_mask=cu(mask), encoder_input_dict={"images": px.cuda(), "texts": texts}).cpu().numpy()
+    finally:
+        lib.ofx_tune(2, 0)
     n_img = len(synth.IMG_PREFIX)
     Wv = {k[n_img:]: v for k, v in sd.items() if k.startswith(synth.IMG_PREFIX)}
     emb = O.item_encoder(px.numpy(), ids.reshape(B, L, 64), att.reshape(B, L, 64), Wv, synth.text_weights(wseed))
     ref = O.cp_forward(emb, mask, synth.outfit_transformer_weights(wseed))
     e = rel_err(got, ref)
-    print(f"cfg2 end to end ({towers or DEFAULT_TOWERS}), weight seed {wseed}{' + outlier channels' if outliers else ''}: {e:.2e}")
+    print(f"cfg2 end to end ({towers or DEFAULT_TOWERS}), weight seed {wseed}{f' + outlier channels (level {outlier_level})' if outliers else ''}"
+          f"{', split-weight GEMMs forced onto gemm_w2f8_kernel' if force_split_kernel else ''}: {e:.2e}")
     assert e < bound, e
     del m
     torch.cuda.empty_cache()
@@ -777,6 +839,19 @@ def test_cfg2_end_to_end_within_1e3_on_every_weight_seed(wseed):
     8.9e-4, its worst of the hundred: all eight logits of that draw are small, max|ref| = 0.27) and seed 3 with massive
     residual-stream channels."""
     _cfg2_end_to_end(wseed, None, 1e-3)
+
+
+@pytest.mark.parametrize("level", [1, 2])
+@pytest.mark.parametrize("wseed", [-3, 5])
+def test_cfg2_end_to_end_through_the_fp8_correction_kernel(wseed, level):
+    """The same 8-outfit problem with EVERY split-weight GEMM forced onto gemm_w2f8_kernel (the kernel that carries 75 % of the
+    bench's step; unforced, 8 outfits run the 128x128 f16-lo path): plain weights (seed 5) and weights with massive ViT channels -
+    level 1: three residual-stream channels x 30 and an fc2 row x 20; level 2: x 100 / x 50 plus fc1 units x 50, so that the raw
+    residual stream (the A operand of qkv and fc1 under LayerNorm folding) AND the MLP hidden units (fc2's A operand) run into the
+    hundreds.  The correction product's activation image is e5m2 since round 4 (f16's exponent range): nothing saturates."""
+    if wseed > 0 and level == 2:
+        pytest.skip("plain weights have one level")
+    _cfg2_end_to_end(wseed, None, 1e-3, outlier_level=level, force_split_kernel=True)
 
 
 @pytest.mark.parametrize("wseed", [6, 14])
@@ -809,7 +884,7 @@ def _bench_batch():
     return _BENCH_BATCH
 
 
-@pytest.mark.parametrize("wseed", [7, 17, 44, 75, 89, 97, 99])
+@pytest.mark.parametrize("wseed", [7, 17, 44, 75, 89, 97, 99, "3o1", "3o2"])
 def test_cfg2_bench_batch_within_1e3_of_the_reference(wseed):
     """The configuration bench.py times - 256 outfits x 8 items, so every ViT GEMM runs through the persistent 256x256 kernels and
     not the 128x128 split-K paths of the 8-outfit tests - in the default scheme, ALL 256 CP logits against the reference ITSELF
@@ -817,7 +892,10 @@ def test_cfg2_bench_batch_within_1e3_of_the_reference(wseed):
     cfg2_bench_logits.npz from oracle/gen_bench_golden.py).  Weight seeds: the bench's (7), the four worst of the round-2
     sweeps (44, 89, 97, 99: draws whose logits are all small) and the two worst of round 3's sweep of all hundred at this batch size (75:
     8.6e-4 on an earlier build / 6.5e-4 on the final one, 17: 6.4e-4, 99: 7.3e-4; profiles/r03_seed_sweep_bench_scale.json: median 2.7e-4, 90th percentile 4.7e-4, none at or above 1e-3).  Metric and bound: the north star's max|d| / max|ref| over the
-    batch <= 1e-3."""
+    batch <= 1e-3.  "3o1" / "3o2" (round 4): weight seed 3 with massive ViT channels (synth.outlier_channels level 1 / 2: residual-stream
+    channels x 30 / x 100, an fc2 row x 20 / x 50, at level 2 also fc1 units x 50) - the stand-in for a trained checkpoint's massive
+    activations, at the size where gemm_w2f8_kernel, its LayerNorm-fold epilogue statistics and its fp8 activation image carry them;
+    the fixture rows come from the reference itself with the same weights (oracle/gen_bench_golden.py 3o1 3o2)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a HIP device")
     from src.models import OutfitX
@@ -827,7 +905,11 @@ def test_cfg2_bench_batch_within_1e3_of_the_reference(wseed):
     ref = bb["z"][f"w{wseed}"].astype(np.float32)
     m = OutfitX(OutfitXConfig(item_encoder=ItemEncoderConfig(type="clip")))
     assert m.item_encoder.image_enc.tower_precision == DEFAULT_TOWERS
-    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.full_state_dict(wseed).items()}, strict=True)
+    base, _, lvl = str(wseed).partition("o")
+    sd = synth.full_state_dict(int(base))
+    if lvl:
+        sd = synth.outlier_channels(sd, int(lvl))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     m = m.cuda().eval()
     with torch.no_grad():
         got = m(task=CP, outfit_embedding=None, outfit_mask=torch.zeros(bb["B"], bb["n"], dtype=torch.bool, device="cuda"),

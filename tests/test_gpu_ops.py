@@ -245,16 +245,17 @@ def test_pack_lo8_rounds_and_permutes_as_stated(N, K):
 
 
 @pytest.mark.parametrize("force", [0, 6])
-@pytest.mark.parametrize("M,N,K,sat", [(1, 256, 128, 0), (255, 256, 128, 1), (300, 512, 768, 0), (1000, 768, 3072, 1), (70000, 768, 256, 0), (66000, 1024, 384, 1)])
-def test_gemm_split_weights_fp8_correction(force, M, N, K, sat):
-    """C = A hi^T + fp8(4 A) fp8(lo 2^sw)^T 2^-(2 + sw) (gemm_w2f8_kernel: forced, and chosen by the dispatcher from 256 tiles on; the
-    small problems without force run the f16 lo product of the 128x128 path instead and are held to the exact product): exact arithmetic
-    on the quantised operands with fp32 accumulation; and against the float64 product with the unquantised lo halves the correction
-    leaves ~2^-15 of the weight scale."""
+@pytest.mark.parametrize("M,N,K,big", [(1, 256, 128, 0), (255, 256, 128, 1), (300, 512, 768, 0), (1000, 768, 3072, 2), (70000, 768, 256, 0), (66000, 1024, 384, 1)])
+def test_gemm_split_weights_fp8_correction(force, M, N, K, big):
+    """C = A hi^T + bf8(A) fp8(lo 2^sw)^T 2^-sw (gemm_w2f8_kernel: forced, and chosen by the dispatcher from 256 tiles on; the small
+    problems without force run the f16 lo product of the 128x128 path instead and are held to the exact product): exact arithmetic on
+    the quantised operands with fp32 accumulation; and against the float64 product with the unquantised lo halves the correction
+    leaves a small fraction of the single-product error - ALSO on activation columns in the hundreds and thousands (big = 1 / 2:
+    massive channels, as a trained ViT's residual stream has; round 3's e4m3 image saturated at |a| > 112 and corrected those
+    columns only in part, this round's e5m2 image follows f16's whole range) and on columns of 1e-4."""
     g = np.random.default_rng(M + 3 * N + K)
-    # activation columns from 1e-2 to 30 x N(0, 1); sat: also columns beyond the fp8 range (4 a saturates at 448: the correction of those
-    # columns is then partial by design - the exact-arithmetic check covers them, the accuracy check does not)
-    A = to_op(g.standard_normal((M, K), dtype=np.float32) * g.choice(np.float32([0.01, 1.0, 30.0, 200.0] if sat else [0.01, 1.0, 30.0]), size=(1, K)), "f16")
+    scales = [[1e-4, 0.01, 1.0, 30.0], [0.01, 1.0, 30.0, 200.0], [1e-4, 1.0, 300.0, 3000.0]][big]
+    A = to_op(g.standard_normal((M, K), dtype=np.float32) * g.choice(np.float32(scales), size=(1, K)), "f16")
     W2, Wv = _split_w((g.standard_normal((N, K), dtype=np.float32) / np.float32(np.sqrt(K))).astype(np.float32), "f16")
     W8, sc, lo_seen, _ = _pack_lo8(W2, N, K)
     bias = dev(g.standard_normal(N, dtype=np.float32))
@@ -268,17 +269,18 @@ def test_gemm_split_weights_fp8_correction(force, M, N, K, sat):
     finally:
         lib.ofx_tune(2, 0)
     Ad = A.double().cpu().numpy()
+    assert np.abs(Ad).max() > (100.0 if big else 1.0)
     hi = W2[:, :K].double().cpu().numpy()
     exact = Ad @ Wv.T + bias.cpu().numpy() + res.cpu().numpy()
     fp8_path = force == 6 or ((M + 255) // 256) * (N // 256) >= 256
     if fp8_path:
-        A8 = (A.float() * 4.0).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).double().cpu().numpy() / 4.0
+        A8 = A.float().clamp(-57344.0, 57344.0).to(torch.float8_e5m2).double().cpu().numpy()
         want = Ad @ hi.T + A8 @ lo_seen.T + bias.cpu().numpy() + res.cpu().numpy()
         assert rel_err(out.cpu().numpy(), want) < 2e-5
         single = Ad @ hi.T + bias.cpu().numpy() + res.cpu().numpy()
         e_corr, e_single = rel_err(out.cpu().numpy(), exact), rel_err(single, exact)
-        print(f"w2f8 {M}x{N}x{K}: vs exact split product {e_corr:.2e} (single product {e_single:.2e})")
-        assert sat or e_corr < 0.25 * e_single + 2e-5
+        print(f"w2f8 {M}x{N}x{K} (activation columns up to x{scales[-1]:g}): vs exact split product {e_corr:.2e} (single product {e_single:.2e})")
+        assert e_corr < 0.25 * e_single + 2e-5
     else:
         assert rel_err(out.cpu().numpy(), exact) < 2e-5
 

@@ -48,6 +48,14 @@ __global__ __launch_bounds__(512) void probe(const uint32_t* src, float* out, in
             for (int i = 0; i < 8; ++i) c[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i & 3].h, b[(i >> 1) & 3].h, c[i & 3], 0, 0, 0);
         }
         for (int i = 0; i < 4; ++i) sum += c[i][0] + c[i][15];
+    } else if (MODE == 6) {      // e4m3 x e5m2 (round 4: the activation image of the correction product as bf8)
+        f4 c[16];
+        for (int i = 0; i < 16; ++i) c[i] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8[i & 1].v, b8[(i >> 1) & 1].v, c[i], 0, 1, 0, 127, 0, 127);
+        }
+        for (int i = 0; i < 4; ++i) sum += c[i][0] + c[i][3];
     } else {
         f4 c[16];
         for (int i = 0; i < 16; ++i) c[i] = f4{0.f, 0.f, 0.f, 0.f};
@@ -72,7 +80,7 @@ int main() {
         // 0: random f16 bit patterns with the exponent kept small (finite, |x| < 2); 1: zeros; 2: random again (order check)
         for (auto& v : h) { const uint32_t r = rng(); v = data == 1 ? 0u : ((r & 0x83FF83FFu) | 0x38003800u); }
         hipMemcpy(src, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-        for (int mode = 0; mode < 6; ++mode) {
+        for (int mode = 0; mode < 7; ++mode) {
             float best = 1e30f;
             for (int rep = 0; rep < 3; ++rep) {
                 hipEventRecord(e0);
@@ -81,13 +89,14 @@ int main() {
                 else if (mode == 2) probe<2><<<cus, 512>>>(src, out, iters);
                 else if (mode == 3) probe<3><<<cus, 512>>>(src, out, iters);
                 else if (mode == 4) probe<4><<<cus, 512>>>(src, out, iters);
-                else probe<5><<<cus, 512>>>(src, out, iters);
+                else if (mode == 5) probe<5><<<cus, 512>>>(src, out, iters);
+                else probe<6><<<cus, 512>>>(src, out, iters);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1); if (rep > 0 && ms < best) best = ms;       // first rep warms the clocks
             }
-            const double flop_per_iter = (mode == 0 || mode >= 3) ? 16.0 * 16384 : (mode == 1 ? 8.0 * 32768 : 4.0 * 65536);
-            static const char* names[6] = {"v_mfma_f32_16x16x32_f16", "v_mfma_f32_32x32x16_f16", "v_mfma_scale_f32_16x16x128_f8f6f4", "16x16x32_f16, same operands every time",
-                                           "16x16x32_f16, A kept over 4 / B cycles", "16x16x32_f16, A and B both change"};
+            const double flop_per_iter = (mode == 0 || (mode >= 3 && mode <= 5)) ? 16.0 * 16384 : (mode == 1 ? 8.0 * 32768 : 4.0 * 65536);
+            static const char* names[7] = {"v_mfma_f32_16x16x32_f16", "v_mfma_f32_32x32x16_f16", "v_mfma_scale_f32_16x16x128_f8f6f4", "16x16x32_f16, same operands every time",
+                                           "16x16x32_f16, A kept over 4 / B cycles", "16x16x32_f16, A and B both change", "v_mfma_scale_f32_16x16x128 e4m3 x e5m2"};
             const double tf = flop_per_iter * iters * cus * 8 / (best * 1e-3) / 1e12;
             printf("%s operands  %-42s %8.2f ms  %7.1f TFLOP/s\n", data == 1 ? "zero  " : "random", names[mode], best, tf);
         }

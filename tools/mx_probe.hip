@@ -3,6 +3,8 @@
 //   1. v_cvt_scalef32_pk_fp8_f16: which way the scale acts, saturation, which half of the destination is written;
 //   2. v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 x e4m3): the A/B lane -> (row, k) map, checked with exact integer data, and how the
 //      E8M0 scale bytes act.
+//   3. (round 4) the same instruction with the SECOND operand in e5m2 (blgp = 1; v_cvt_scalef32_pk_bf8_f16 makes it from f16): an
+//      activation image that keeps f16's whole exponent range (no saturation below 57344, no scale to choose) at 3 significant bits.
 //   hipcc --offload-arch=gfx950 -O2 tools/mx_probe.hip -o build/mx_probe && build/mx_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -33,6 +35,36 @@ __global__ void cvt_kernel(const _Float16* x, float scale, uint32_t* out_lo, uin
     s2 hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(old, v, scale, true);
     out_lo[i] = ((uint32_t)(uint16_t)lo[1] << 16) | (uint16_t)lo[0];
     out_hi[i] = ((uint32_t)(uint16_t)hi[1] << 16) | (uint16_t)hi[0];
+}
+
+static float e5m2_to_float(uint8_t b) {
+    const int s = b >> 7, e = (b >> 2) & 31, m = b & 3;
+    float v;
+    if (e == 0) v = ldexpf((float)m, -16);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = ldexpf(1.0f + m / 4.0f, e - 15);
+    return s ? -v : v;
+}
+
+__global__ void cvt_bf8_kernel(const _Float16* x, float scale, uint32_t* out_lo, uint32_t* out_hi, int ovfl) {
+    const int i = threadIdx.x;
+    if (ovfl) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
+    h2 v = {x[2 * i], x[2 * i + 1]};
+    s2 old = {(short)0x1111, (short)0x2222};
+    s2 lo = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(old, v, scale, false);
+    s2 hi = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(old, v, scale, true);
+    out_lo[i] = ((uint32_t)(uint16_t)lo[1] << 16) | (uint16_t)lo[0];
+    out_hi[i] = ((uint32_t)(uint16_t)hi[1] << 16) | (uint16_t)hi[0];
+}
+
+// the same product with the second operand's bytes read as e5m2 (blgp = 1)
+__global__ void mfma_b_bf8_kernel(const uint8_t* a_bytes, const uint8_t* b_bytes, float* d, int scale_a, int scale_b) {
+    const int l = threadIdx.x;
+    i8v a, b;
+    for (int r = 0; r < 8; ++r) { a[r] = ((const int*)a_bytes)[l * 8 + r]; b[r] = ((const int*)b_bytes)[l * 8 + r]; }
+    f4 c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 1, 0, scale_a, 0, scale_b);
+    for (int r = 0; r < 4; ++r) d[l * 4 + r] = c[r];
 }
 
 // One wave: D[16x16] = A[16x128] . B[128x16] with operands given per lane as 32 bytes
@@ -117,5 +149,36 @@ int main() {
     int bad = 0;
     for (int l = 0; l < 64; ++l) for (int r = 0; r < 4; ++r) if (fabs(d[l * 4 + r] - ref[((l >> 4) * 4 + r) * 16 + (l & 15)]) > 1e-3) ++bad;
     printf("k-permuted pairing (k = 32 s + 8 g + j at byte 8 s + j of lane group g): %d of 256 differ\n", bad);
+    // ---- 3. e5m2 second operand: conversion, then the H1 product with B encoded as e5m2
+    const float ys[16] = {1.0f, -1.5f, 0.3f, 448.f, 500.f, 1000.f, 0.0019f, 0.001f, 3.3f, 100.f, 57344.f, 60000.f, 65504.f, -0.2f, 6.0e-5f, 1e-5f};
+    for (int i = 0; i < 16; ++i) hx[i] = (_Float16)ys[i];
+    hipMemcpy(dx, hx, sizeof(hx), hipMemcpyHostToDevice);
+    for (int pass = 0; pass < 2; ++pass) {
+        cvt_bf8_kernel<<<1, 8>>>(dx, 1.0f, dlo, dhi, pass);
+        uint32_t lo[8], hi[8];
+        hipMemcpy(lo, dlo, 32, hipMemcpyDeviceToHost); hipMemcpy(hi, dhi, 32, hipMemcpyDeviceToHost);
+        printf("cvt_bf8 scale 1, MODE.FP16_OVFL = %d:\n", pass);
+        for (int i = 0; i < 8; ++i)
+            printf("  x = (%g, %g)  dst_hi=0 -> %08x  [%g, %g]   dst_hi=1 -> %08x  [%g, %g]\n", (float)hx[2 * i], (float)hx[2 * i + 1], lo[i],
+                   e5m2_to_float(lo[i] & 0xff), e5m2_to_float((lo[i] >> 8) & 0xff), hi[i], e5m2_to_float((hi[i] >> 16) & 0xff), e5m2_to_float(hi[i] >> 24));
+    }
+    auto enc5 = [](int v) -> uint8_t {     // e5m2 of small integers |v| <= 4 (exact: 1, 2, 3, 4 need <= 2 mantissa bits)
+        const int s = v < 0; int a = s ? -v : v;
+        if (a == 0) return 0;
+        int e = 0; while ((a >> (e + 1)) != 0) ++e;
+        const int m = (int)lroundf((a / (float)(1 << e) - 1.0f) * 4.0f);
+        return (uint8_t)((s << 7) | ((e + 15) << 2) | m);
+    };
+    for (int l = 0; l < 64; ++l) for (int i = 0; i < 32; ++i) {
+        const int r = l & 15, g = l >> 4, k = 32 * g + i;
+        ab[l * 32 + i] = enc(Ai[r * 128 + k]);
+        bb[l * 32 + i] = enc5(Bi[k * 16 + r]);
+    }
+    hipMemcpy(da, ab.data(), 2048, hipMemcpyHostToDevice); hipMemcpy(db, bb.data(), 2048, hipMemcpyHostToDevice);
+    mfma_b_bf8_kernel<<<1, 64>>>(da, db, dd, 127, 127);
+    hipMemcpy(d, dd, 1024, hipMemcpyDeviceToHost);
+    bad = 0;
+    for (int l = 0; l < 64; ++l) for (int r = 0; r < 4; ++r) if (fabs(d[l * 4 + r] - ref[((l >> 4) * 4 + r) * 16 + (l & 15)]) > 1e-3) ++bad;
+    printf("e4m3 x e5m2 (blgp = 1), H1 layout: %d of 256 differ\n", bad);
     return 0;
 }
