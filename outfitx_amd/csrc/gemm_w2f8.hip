@@ -76,7 +76,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const char* base, si
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(bytes < 0x7fffffff ? bytes : 0x7fffffff), 0x00020000);
 }
 
-template <int ABL = 0>      // ABL (make DIAG=1; wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads after step 0, 3 both, 4 no fp8 product, 5 LDS-DMA + barriers only (no reads, no MFMA: the fill rate of this slot structure), 6 the same with the fragment reads, 7 the full kernel with s_memtime stamps around its slots and epilogues (tools/w2f8_slots.py)
+// ABL (make DIAG=1; wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads after step 0, 3 both, 4 no fp8 product, 5 LDS-DMA + barriers only (no reads, no MFMA: the
+// fill rate of this slot structure), 6 the same with the fragment reads, 7 the full kernel with s_memtime stamps around its slots and epilogues (tools/w2f8_slots.py);
+// round 4, the fill wall split into L2-hit rate and miss cost: 8 = 5 and 9 = the full kernel, both with every block LOADING from one of four operand tiles (two A
+// panels x two W panels: 1.9 MiB at K = 768, resident in every XCD's 4 MiB L2 after the first touch) while the epilogue still writes the block's own tile
+template <int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
     typedef f16_t T;
     typedef OpT<T>::v8 v8;
@@ -146,14 +150,17 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
         // fp8 weight fragment j: row wc * 128 + j * 16 + fr, logical chunks 2 fq, 2 fq + 1
         const int x8 = (((fr >> 1) & 3) << 1) | (fr >> 3);
         const int w8_frag0 = (wc * 128 + fr) * 128 + (((2 * fq) ^ x8) << 4), w8_frag1 = (wc * 128 + fr) * 128 + (((2 * fq + 1) ^ x8) << 4);
-        const char* a_base = p.A + (size_t)m0 * p.lda * 2;
-        const char* w_base = p.W + (size_t)n0 * (2 * Kh) * 2;
-        const char* w8_base = p.W8 + (size_t)n0 * Kh;
+        constexpr bool L2RES = ABL == 8 || ABL == 9;         // DIAG: operand loads come from four L2-resident tiles
+        const int lm0 = L2RES ? (vb & 1) * TM : m0, ln0 = L2RES ? ((vb >> 1) & 1) * TN : n0;
+        const char* a_base = p.A + (size_t)lm0 * p.lda * 2;
+        const char* w_base = p.W + (size_t)ln0 * (2 * Kh) * 2;
+        const char* w8_base = p.W8 + (size_t)ln0 * Kh;
         unsigned a_off[2];                                  // tile-independent too: rows past M read zeros through the sized resource
 #pragma unroll
         for (int i = 0; i < 2; ++i) a_off[i] = ((unsigned)((wave * 2 + i) * 16 + prow) * p.lda + pchk * 8) * 2;
         int m1 = m0, n1 = n0;                               // the next tile (the block's last tile re-fills its own first steps: nobody reads them)
         if (has_next) map_tile(vb + (int)gridDim.x, m1, n1);
+        const int lm1 = L2RES ? ((vb + (int)gridDim.x) & 1) * TM : m1, ln1 = L2RES ? (((vb + (int)gridDim.x) >> 1) & 1) * TN : n1;
         int sc_lo = (int)(unsigned)sc8, sc_hi = (int)(unsigned)(sc8 >> 32);
 
         // LDS-DMA pieces: the two A and two W_hi pieces of a k-step (KOFF = its byte offset in the k-contiguous rows) and quarter Q of
@@ -166,8 +173,8 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
 #define OFX_F8_ISSUE_W8(SUP, Q)                                                                                            \
     bload16(r_w8, w8_off ^ (((Q) & 1) << 4), (unsigned)(SUP) * 128u + (unsigned)(Q) * 8u * (unsigned)Kh, lds + W8BASE + (wave * 4 + (Q)) * 1024);
         const size_t a_row = (size_t)p.lda * 2;
-        const __amdgpu_buffer_rsrc_t r_a = make_rsrc(a_base, (size_t)(p.M - m0) * a_row), r_w = make_rsrc(w_base), r_w8 = make_rsrc(w8_base);
-        const __amdgpu_buffer_rsrc_t r_a1 = make_rsrc(p.A + (size_t)m1 * a_row, (size_t)(p.M - m1) * a_row), r_w1 = make_rsrc(p.W + (size_t)n1 * (2 * Kh) * 2);
+        const __amdgpu_buffer_rsrc_t r_a = make_rsrc(a_base, (size_t)(p.M - lm0) * a_row), r_w = make_rsrc(w_base), r_w8 = make_rsrc(w8_base);
+        const __amdgpu_buffer_rsrc_t r_a1 = make_rsrc(p.A + (size_t)lm1 * a_row, (size_t)(p.M - lm1) * a_row), r_w1 = make_rsrc(p.W + (size_t)ln1 * (2 * Kh) * 2);
         // k-step x of the tile walk: a step of this tile, or (x >= nk) step x - nk of the next one - a scalar select of resource and offset
         auto issue_step = [&](int x) {
             OFX_LDS char* stg = lds + ((base + x) % NST) * STAGE;
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
         a8[I][2 * (S)] = __builtin_bit_cast(int, lo_); a8[I][2 * (S) + 1] = __builtin_bit_cast(int, hi_);      \
     }
 #define OFX_F8_MFMA16(S)                                                                                      \
-    if (ABL < 5 || ABL == 7) {                                                                                             \
+    if (ABL < 5 || ABL == 7 || ABL == 9) {                                                                                             \
         OFX_F8_PRIO_HI;                                                                      \
         if (OFX_MFMA_WKEEP) {       /* weight fragment (the instruction's first operand) kept over 4 consecutive MFMAs: tools/mfma_power_probe.hip */ \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                   \
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
         acc[i][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8_[(J) % 3], a8[i], acc[i][J], 0, OFX_F8_BLGP, SEL, SC, 0, a_e8);
 #define OFX_F8_MFMA8()                                                                                      \
-    if (ABL != 4 && (ABL < 5 || ABL == 7)) {                                                                                \
+    if (ABL != 4 && (ABL < 5 || ABL == 7 || ABL == 9)) {                                                                                \
         __builtin_amdgcn_sched_barrier(0);      /* the fp8 fragments take the registers the f16 fragments leave: no hoisting above */ \
         OFX_LDS char* b8_ = lds + W8BASE;                                                                     \
         i32x8 w8_[3];                                                                                         \
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
         {                                                                                                        \
             OFX_F8_STAMP(st0_)                                                                                   \
             if (ABL == 0 || ABL == 2 || ABL >= 4) { ISSUE; }                                                     \
-            if (ABL == 0 || ABL == 1 || ABL == 4 || ABL >= 6 || (T_) == 0) OFX_F8_READ(T_)                                   \
+            if (ABL == 0 || ABL == 1 || ABL == 4 || ABL == 6 || ABL == 7 || ABL == 9 || (T_) == 0) OFX_F8_READ(T_)           \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
             OFX_F8_ACC(S_, 0)                                                                                    \
             if (ABL == 6) { _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(wh[j])); _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(af[i])); } \
@@ -293,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
         {                                                                                                        \
             OFX_F8_STAMP(st0_)                                                                                   \
             if (ABL == 0 || ABL == 2 || ABL >= 4) { ISSUE; }                                                     \
-            if (ABL == 0 || ABL == 1 || ABL == 4 || ABL >= 6 || (T_) == 0) OFX_F8_READ(T_)                                   \
+            if (ABL == 0 || ABL == 1 || ABL == 4 || ABL == 6 || ABL == 7 || ABL == 9 || (T_) == 0) OFX_F8_READ(T_)           \
             if (ABL == 0 || ABL == 2 || ABL >= 4) asm volatile("s_waitcnt vmcnt(" #NV ")" ::: "memory");         \
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
@@ -451,6 +458,8 @@ int ofx_gemm_launch_w2f8(void* kargs, int M, int N, hipStream_t s) {
     if (g_gemm_ablate == 5) return launch_w2f8<5>(k, M, N, s);
     if (g_gemm_ablate == 6) return launch_w2f8<6>(k, M, N, s);
     if (g_gemm_ablate == 7) return launch_w2f8<7>(k, M, N, s);
+    if (g_gemm_ablate == 8) return launch_w2f8<8>(k, M, N, s);
+    if (g_gemm_ablate == 9) return launch_w2f8<9>(k, M, N, s);
 #endif
     return launch_w2f8<0>(k, M, N, s);
 }

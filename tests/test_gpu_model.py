@@ -408,6 +408,51 @@ def cu_(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
+def test_embedding_store_file_to_hbm_table_to_cp_forward(model, tmp_path):
+    """N4 on the device, end to end: the reference's precompute output - one pickle per rank, {'ids': list[int], 'embeddings': ndarray[N, 1024]}
+    named "<model_name>_embedding_subset_<rank>.pkl" (precompute_embedding_script.py:47-55) - -> EmbeddingTable (mmap variant) -> HBM-resident
+    table (OutfitX.set_embedding_table) -> the index-emitting collate over FashionItem ids -> CP forward by index.  The result is bit-identical
+    to the padded forward of the same outfits and matches the REFERENCE's own logits for them (tests/golden/ot_ragged.npz) at 1e-3."""
+    import pickle
+    from outfitx_amd import embedding_store as S
+    from outfitx_amd.configs import OutfitXConfig
+    from outfitx_amd.datatypes import FashionItem
+    from outfitx_amd.processor import OutfitXIndexedProcessor
+    CP = tasks()[0]
+    g = golden("ot_ragged")
+    B, seed, n_items = int(g["B"]), int(g["seed"]), g["n_items"]
+    emb, mask = synth.outfit_batch(seed, B, 16, n_items)
+    assert synth.checksum(emb) == str(g["emb_crc"])
+    # every real item row becomes an item of the store under an arbitrary id; the items are dealt to two "ranks" in shuffled order, as two
+    # precompute processes would write them
+    rows = [(b, l) for b in range(B) for l in range(int(n_items[b]))]
+    rng = np.random.default_rng(7)
+    item_id = {bl: int(i) for bl, i in zip(rows, rng.permutation(10_000)[:len(rows)] + 100)}
+    order = rng.permutation(len(rows))
+    for rank, part in enumerate(np.array_split(order, 2)):
+        path = S.save_pickle_shard(str(tmp_path), "fashion-clip", rank, [item_id[rows[i]] for i in part], np.stack([emb[rows[i]] for i in part]))
+        with open(path, "rb") as f:
+            d = pickle.load(f)
+        assert set(d) == {"ids", "embeddings"} and isinstance(d["ids"], list) and d["embeddings"].shape == (len(part), 1024)
+    S.convert_to_mmap(str(tmp_path), "fashion-clip")
+    table = S.EmbeddingTable.open(str(tmp_path), "fashion-clip")
+    assert isinstance(table.embeddings, np.memmap) and table.embeddings.shape == (len(rows), 1024)
+    model.set_embedding_table(torch.from_numpy(np.ascontiguousarray(table.embeddings)))      # file -> HBM, once
+    assert model.embedding_table.device.type == "cuda"
+    collate = OutfitXIndexedProcessor(CP, OutfitXConfig(), id_to_row=table.index())
+    batch = [(CP(outfit=[FashionItem(item_id=item_id[(b, l)]) for l in range(int(n_items[b]))]), 1.0) for b in range(B)]
+    out = collate(batch)["input_dict"]
+    assert out["task"] is CP and out["item_index"].numel() == len(rows) and out["cu_seqlens"].numel() == B + 1
+    model.precision = "bf16x3"
+    with torch.no_grad():
+        by_index = model(**out)
+        padded = model(task=CP, outfit_embedding=cu_(emb), outfit_mask=cu_(mask))
+    assert torch.equal(by_index, padded)
+    e = rel_err(by_index.cpu().numpy(), g["cp_logits"])
+    print(f"store file -> HBM table -> CP forward by index vs the reference's logits (ot_ragged): {e:.2e}")
+    assert e < 1e-3
+
+
 def test_gpu_image_preprocessing_is_bit_identical_to_pil_pipeline(model):
     """N2: resize (PIL antialiased bicubic) + centre crop + normalise on the GPU from packed uint8 images == the PIL-based host
     pipeline AND the numpy oracle, bit for bit; mixed sizes, portrait / landscape / upscale / one-axis / grey."""
