@@ -44,6 +44,45 @@ TOWER_SCHEMES = {
     "f16x3": (PREC_F16, W2_PATCH, 1, 1, 1), "bf16x3": (PREC_BF16, W2_PATCH, 1, 1, 1),
 }
 DEFAULT_TOWER_PRECISION = "f16w2x"
+
+
+def _layer_bits(spec: str) -> int:
+    """'0-5,8' -> bit mask of ViT layers."""
+    m = 0
+    for part in spec.split(","):
+        a, _, b = part.partition("-")
+        for l in range(int(a), int(b or a) + 1):
+            m |= 1 << l
+    return m
+
+
+def tower_scheme(name: str) -> dict:
+    """A tower_precision string -> the ofx_model_desc fields it sets.  A key of TOWER_SCHEMES, optionally followed by '@' and ';'-separated
+    options (the finer rungs of round 4, tests/studies/bench_scale_sweep.py):
+      txt=w2            the text tower in the ViT's scheme (f16 activations x split weights on qkv / out / fc1 / fc2) instead of three products;
+      qkv=0-5  fc1=0-3,8   ViT layers whose qkv / fc1 GEMM keeps its split weights (the others run the single-product copy).
+    Raises ValueError on anything else."""
+    base, _, opts = name.partition("@")
+    if base not in TOWER_SCHEMES:
+        raise ValueError(f"unknown tower_precision {name!r}; one of {sorted(TOWER_SCHEMES)} [+ '@txt=w2;qkv=<layers>;fc1=<layers>']")
+    prec, mask, txt_x3, proj_x3, vit_x3 = TOWER_SCHEMES[base]
+    d = {"tower_precision": prec, "vit_w2_mask": mask, "txt_x3": txt_x3, "proj_x3": proj_x3, "vit_x3": vit_x3,
+         "txt_w2_mask": 0, "vit_w2_qkv_layers": 0, "vit_w2_fc1_layers": 0}
+    for o in filter(None, opts.split(";")):
+        k, _, v = o.partition("=")
+        try:
+            if k == "txt" and v == "w2":
+                d["txt_x3"], d["txt_w2_mask"] = 0, W2_QKV | W2_OUT | W2_FC1 | W2_FC2
+            elif k in ("qkv", "fc1"):
+                bits = _layer_bits(v) if v not in ("", "none") else 0
+                if bits == 0:
+                    d["vit_w2_mask"] &= ~(W2_QKV if k == "qkv" else W2_FC1)
+                d[f"vit_w2_{k}_layers"] = bits
+            else:
+                raise ValueError
+        except ValueError:
+            raise ValueError(f"tower_precision {name!r}: bad option {o!r} (txt=w2 | qkv=<layers> | fc1=<layers>, layers like 0-5,8 or none)") from None
+    return d
 ACTS = {"none": ACT_NONE, "quick_gelu": ACT_QUICK_GELU, "gelu": ACT_GELU, "mish": ACT_MISH}
 
 
@@ -56,7 +95,7 @@ class ModelDesc(C.Structure):
         "d_model", "n_head", "d_ffn", "n_layers", "max_items", "outfit_act", "outfit_precision",
         "vit_width", "vit_layers", "vit_heads", "vit_mlp", "vit_patch", "vit_image", "vit_act",
         "txt_width", "txt_layers", "txt_heads", "txt_mlp", "txt_vocab", "txt_max_pos", "txt_act", "txt_eos_id",
-        "proj_dim", "tower_precision")] + [("ln_eps", C.c_float)] + [(n, C.c_int) for n in ("vit_w2_mask", "txt_x3", "proj_x3", "vit_x3")]
+        "proj_dim", "tower_precision")] + [("ln_eps", C.c_float)] + [(n, C.c_int) for n in ("vit_w2_mask", "txt_x3", "proj_x3", "vit_x3", "txt_w2_mask", "vit_w2_qkv_layers", "vit_w2_fc1_layers")]
 
 
 class ProfRecord(C.Structure):

@@ -200,7 +200,7 @@ struct ofx_handle {
     float *outfit_token, *tgt_img_emb, *cp_w, *cp_b; void* cir_w; void* cir_w_t = nullptr;   // cir_w_t: W^T operand copy (training dgrad)
     // towers
     int tw_dtype;
-    int vit_w2_mask = 0, txt_x3 = 0, proj_x3 = 0, vit_x3 = 0;    // operand scheme (ofx_model_desc); x3 towers hold ONLY the K-concatenated [hi | hi | lo] weight copies
+    int vit_w2_mask = 0, txt_x3 = 0, proj_x3 = 0, vit_x3 = 0, txt_w2_mask = 0;    // operand scheme (ofx_model_desc); x3 towers hold ONLY the K-concatenated [hi | hi | lo] weight copies
     void* v_patch_w2 = nullptr; void* v_proj_w3 = nullptr; F8Pair f8_patch;
     // training: events armed for the NEXT backward call (ofx_train_arm_layer_events), one per outfit-transformer layer
     std::vector<hipEvent_t> bwd_events;
@@ -236,6 +236,8 @@ extern "C" ofx_handle* ofx_create(int device, const ofx_model_desc* desc) {
     if (d.outfit_precision < 0 || d.outfit_precision > 2) return bad("bad outfit_precision");
     if (d.n_layers < 1 || d.vit_layers < 1 || d.txt_layers < 1 || d.d_ffn < 1) return bad("layer counts / d_ffn must be positive");
     if (d.vit_w2_mask & ~(OFX_W2_PATCH | OFX_W2_QKV | OFX_W2_OUT | OFX_W2_FC1 | OFX_W2_FC2)) return bad("vit_w2_mask: unknown bit");
+    if (d.txt_w2_mask & ~(OFX_W2_QKV | OFX_W2_OUT | OFX_W2_FC1 | OFX_W2_FC2)) return bad("txt_w2_mask: unknown bit");
+    if (d.txt_w2_mask && d.txt_x3) return bad("txt_w2_mask applies to the single-product text tower (txt_x3 = 0)");
     if (hipSetDevice(device) != hipSuccess) return bad("hipSetDevice failed");
     ofx_handle* h = new ofx_handle();
     h->device = device; h->d = d;
@@ -243,7 +245,7 @@ extern "C" ofx_handle* ofx_create(int device, const ofx_model_desc* desc) {
     h->ot_kmul = d.outfit_precision == OFX_PREC_BF16X3 ? 3 : 1;
     h->ot_ffn_pad = pad128(d.d_ffn);
     h->tw_dtype = d.tower_precision == OFX_PREC_F16 ? OFX_F16 : OFX_BF16;
-    h->vit_w2_mask = d.vit_w2_mask; h->txt_x3 = d.txt_x3 != 0; h->vit_x3 = d.vit_x3 != 0; h->proj_x3 = d.proj_x3 != 0 || h->vit_x3;
+    h->vit_w2_mask = d.vit_w2_mask; h->txt_w2_mask = d.txt_w2_mask; h->txt_x3 = d.txt_x3 != 0; h->vit_x3 = d.vit_x3 != 0; h->proj_x3 = d.proj_x3 != 0 || h->vit_x3;
     return h;
 }
 
@@ -438,7 +440,12 @@ extern "C" int ofx_pack_vision_weights(ofx_handle* h, const void* const* P, int 
     h->v_pre_g = A.take<float>(W); TRY(copy_f32(h->v_pre_g, P[3], W, s));
     h->v_pre_b = A.take<float>(W); TRY(copy_f32(h->v_pre_b, P[4], W, s));
     h->vl.resize(d.vit_layers);
-    for (int l = 0; l < d.vit_layers; ++l) TRY(pack_clip_layer(A, h->vl[l], P + 5 + 16 * l, W, MLP, dt, s, h->vit_w2_mask, vx3));
+    for (int l = 0; l < d.vit_layers; ++l) {       // per-layer rungs: a layer outside vit_w2_qkv_layers / vit_w2_fc1_layers keeps the single-product copy of that GEMM
+        int m = h->vit_w2_mask;
+        if (d.vit_w2_qkv_layers && !((d.vit_w2_qkv_layers >> l) & 1)) m &= ~OFX_W2_QKV;
+        if (d.vit_w2_fc1_layers && !((d.vit_w2_fc1_layers >> l) & 1)) m &= ~OFX_W2_FC1;
+        TRY(pack_clip_layer(A, h->vl[l], P + 5 + 16 * l, W, MLP, dt, s, m, vx3));
+    }
     const void* const* t = P + 5 + 16 * d.vit_layers;
     h->v_post_g = A.take<float>(W); TRY(copy_f32(h->v_post_g, t[0], W, s));
     h->v_post_b = A.take<float>(W); TRY(copy_f32(h->v_post_b, t[1], W, s));
@@ -458,19 +465,20 @@ extern "C" int ofx_pack_text_weights(ofx_handle* h, const void* const* P, int n,
     for (int i = 0; i < n; ++i) OFX_REQUIRE(P[i], OFX_EINVAL, "pack_text: tensor %d is NULL", i);
     hipStream_t s = (hipStream_t)stream;
     const size_t W = d.txt_width, MLP = d.txt_mlp, V = d.txt_vocab, NP = d.txt_max_pos, PD = d.proj_dim;
-    const bool x3 = h->txt_x3 != 0;
-    TRY(h->a_txt.reserve(clip_layer_bytes(W, MLP, 0, x3) * d.txt_layers + 4 * (V * W + NP * W + 2 * W) + 6 * PD * W + 16 * 256));
+    const bool x3 = h->txt_x3 != 0, x3p = x3 || h->proj_x3;          // x3p: the final LayerNorm + text_projection tail in three products
+    const int tmask = x3 ? 0 : h->txt_w2_mask;
+    TRY(h->a_txt.reserve(clip_layer_bytes(W, MLP, tmask, x3) * d.txt_layers + 4 * (V * W + NP * W + 2 * W) + 6 * PD * W + 16 * 256));
     Arena& A = h->a_txt;
     CopyBatch copies;
     const int dt = h->tw_dtype;
     h->t_tok = A.take<float>(V * W); TRY(copy_f32(h->t_tok, P[0], V * W, s));
     h->t_pos = A.take<float>(NP * W); TRY(copy_f32(h->t_pos, P[1], NP * W, s));
     h->tl.resize(d.txt_layers);
-    for (int l = 0; l < d.txt_layers; ++l) TRY(pack_clip_layer(A, h->tl[l], P + 2 + 16 * l, W, MLP, dt, s, 0, x3));
+    for (int l = 0; l < d.txt_layers; ++l) TRY(pack_clip_layer(A, h->tl[l], P + 2 + 16 * l, W, MLP, dt, s, tmask, x3));
     const void* const* t = P + 2 + 16 * d.txt_layers;
     h->t_fin_g = A.take<float>(W); TRY(copy_f32(h->t_fin_g, t[0], W, s));
     h->t_fin_b = A.take<float>(W); TRY(copy_f32(h->t_fin_b, t[1], W, s));
-    h->t_proj_w = A.take<char>(2 * (x3 ? 3 : 1) * PD * W); TRY(ofx_launch_pack_rows((const float*)t[2], h->t_proj_w, PD, PD, W, W, W, x3 ? 2 : 0, dt, s));
+    h->t_proj_w = A.take<char>(2 * (x3p ? 3 : 1) * PD * W); TRY(ofx_launch_pack_rows((const float*)t[2], h->t_proj_w, PD, PD, W, W, W, x3p ? 2 : 0, dt, s));
     OFX_REQUIRE(A.off <= A.cap, OFX_ESTATE, "pack_text: arena overflow");
     TRY(copies.flush(s));
     h->txt_ready = true;
@@ -541,7 +549,7 @@ size_t vit_bytes(const ofx_handle* h, int n, ClipWs* w, void* ws, size_t cap) {
 size_t txt_bytes(const ofx_handle* h, int n, int Tc, ClipWs* w, void* ws, size_t cap) {
     const ofx_model_desc& d = h->d;
     Bump b(ws, cap);
-    size_t r = carve_clip(b, (size_t)n * Tc, n, d.txt_width, d.txt_mlp, d.proj_dim, 0, 0, w, h->txt_x3 ? 3 : 1, h->txt_x3 ? 3 : 1);
+    size_t r = carve_clip(b, (size_t)n * Tc, n, d.txt_width, d.txt_mlp, d.proj_dim, 0, 0, w, h->txt_x3 ? 3 : 1, h->txt_x3 ? 3 : (h->txt_w2_mask ? 2 : 1));
     return align_up(r, 256);
 }
 constexpr int VIT_CHUNK_MAX = 2048;
@@ -954,10 +962,10 @@ extern "C" int ofx_clip_text_fwd(ofx_handle* h, const int64_t* ids, const int64_
     const int W = d.txt_width, dt = h->tw_dtype, rows = N * Tc;
     TRY(ofx_launch_text_embed(ids, h->t_tok, h->t_pos, w.X, N, T, Tc, W, d.txt_vocab, s));
     TRY(ofx_launch_text_eos_index(ids, w.idx, N, T, Tc, d.txt_eos_id, s));      // EOS rows
-    const bool x3 = h->txt_x3 != 0;
-    const int pk = x3 ? 3 : 1;
+    const bool x3 = h->txt_x3 != 0, x3p = x3 || h->proj_x3;
+    const int pk = x3p ? 3 : 1;
     TRY(clip_layers(h->tl, w, rows, N, Tc, W, d.txt_mlp, d.txt_heads, d.txt_act, d.ln_eps, 1, attn_mask, T, dt, w.idx, s, false, false, x3));
-    LnArgs ln{w.XP, nullptr, h->t_fin_g, h->t_fin_b, w.PL, N, W, pk * W, x3 ? OFX_OUT_SPLIT3 : OFX_OUT_OP, d.ln_eps};
+    LnArgs ln{w.XP, nullptr, h->t_fin_g, h->t_fin_b, w.PL, N, W, pk * W, x3p ? OFX_OUT_SPLIT3 : OFX_OUT_OP, d.ln_eps};
     TRY(ofx_launch_layernorm(ln, dt, s));
     GemmArgs gj{}; gj.A = w.PL; gj.W = h->t_proj_w; gj.C = w.E; gj.M = N; gj.N = d.proj_dim; gj.K = pk * W; gj.k_mult = pk; gj.lda = pk * W; gj.ldc = d.proj_dim;
     gj.act = OFX_ACT_NONE; gj.out_kind = OFX_OUT_F32; gj.slab = w.slab; gj.slab_bytes = w.slab_bytes;
@@ -1342,6 +1350,7 @@ extern "C" int ofx_focal_loss_ex(const float* logits, const float* labels, int B
 }
 
 // ------------------------------------------------------------------------------------- tuning
+extern int g_topk_filter;
 extern int g_gemm_group_m, g_gemm_ablate, g_gemm_kernel, g_gemm_skew, g_gemm_pref, g_gemm_splitk, g_w2_persist, g_w2_fp8, g_w2_fp8_ashift, g_w2_trim, g_x3_kernel, g_x3_persist;
 extern unsigned long long* g_gemm_dbg;
 /* diagnostics: per-block {shader cycles, 100 MHz ticks} of the big-tile GEMM main loop go to buf (device, 16 B per block); NULL = off */
@@ -1365,6 +1374,7 @@ extern "C" int ofx_tune(int knob, int value) {
         case 14: g_w2_trim = value; return OFX_OK;
         case 15: g_x3_kernel = value; return OFX_OK;
         case 16: g_x3_persist = value != 0; return OFX_OK;
+        case 17: g_topk_filter = value != 0; return OFX_OK;
         case 13: if (value < -8 || value > 8) { ofx_set_error("ofx_tune(13): activation shift out of [-8, 8]"); return OFX_EINVAL; } g_w2_fp8_ashift = value; return OFX_OK;
         default: ofx_set_error("ofx_tune: unknown knob %d", knob); return OFX_EINVAL;
     }

@@ -41,9 +41,8 @@ class Engine:
         self.device = torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
         d = desc if desc is not None else L.default_desc()
         d.outfit_precision = L.PRECISIONS[precision]
-        if tower_precision not in L.TOWER_SCHEMES:
-            raise ValueError(f"unknown tower_precision {tower_precision!r}; one of {sorted(L.TOWER_SCHEMES)}")
-        d.tower_precision, d.vit_w2_mask, d.txt_x3, d.proj_x3, d.vit_x3 = L.TOWER_SCHEMES[tower_precision]
+        for k, v in L.tower_scheme(tower_precision).items():       # ValueError on an unknown scheme
+            setattr(d, k, v)
         self.desc = d
         self.h = self.lib.ofx_create(self.device.index, C.byref(d))
         if not self.h:

@@ -28,7 +28,7 @@ for ws in seeds:
     row = {}
     sd = {k: torch.from_numpy(v) for k, v in synth.full_state_dict(ws).items()}
     for name, tp, knobs in variants:
-        if tp not in L.TOWER_SCHEMES:
+        if tp.partition('@')[0] not in L.TOWER_SCHEMES:
             continue
         m = OutfitX(OutfitXConfig(item_encoder=ItemEncoderConfig(type="clip")), tower_precision=tp)
         m.load_state_dict(sd, strict=True); m = m.cuda().eval()

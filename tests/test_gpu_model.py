@@ -207,6 +207,34 @@ def test_topk_full_size_properties_and_sharded_merge():
         assert (np.abs(d_ours - d_orcl) <= 4e-7 * d_orcl).all()
 
 
+def test_topk_filtered_path_equals_the_matrix_path_also_when_candidate_lists_overflow():
+    """ofx_l2_topk on large pools: distances of a SAMPLE of the pool -> its k-th smallest per query bounds the k-th smallest of the whole pool
+    -> the remaining rows are filtered against it inside the distance kernel (the [nq, np] matrix is never written) -> sort of the few
+    hundred survivors.  Same indices and distances, bit for bit, as distance matrix + radix select (ofx_tune(17, 0)) - also for queries
+    whose candidate list overflows (here: thousands of pool rows behind the sample that sit next to query 3 and query 77), which the
+    always-launched fallback recomputes exactly."""
+    from outfitx_amd import _lib as L
+    from outfitx_amd.engine import Engine
+    lib = L.load()
+    nq, npool, k = 200, 40_000, 50
+    Q = (synth.item_embeddings(43, "q", nq) * 3.0).astype(np.float32)
+    P = synth.item_embeddings(43, "p", npool)
+    g = np.random.default_rng(43)
+    P[20_000:23_000] = Q[3] + 1e-3 * g.standard_normal((3000, 1024), dtype=np.float32)       # 3,000 rows closer to query 3 than anything in the sample
+    P[30_000:32_500] = Q[77] + 1e-3 * g.standard_normal((2500, 1024), dtype=np.float32)
+    P[35_000:35_010] = P[100]                                                                 # exact ties across the sample boundary
+    eng = Engine(torch.device("cuda", 0))
+    Qd, Pd = cu(Q), cu(P)
+    fi, fd = eng.l2_topk(Qd, Pd, k, index_base=7)
+    lib.ofx_tune(17, 0)
+    try:
+        mi, md = eng.l2_topk(Qd, Pd, k, index_base=7)
+    finally:
+        lib.ofx_tune(17, 1)
+    assert torch.equal(fi, mi) and torch.equal(fd, md)
+    assert int(((fi[3] - 7 >= 20_000) & (fi[3] - 7 < 23_000)).sum()) == k                    # the overflowed query's answer comes from the planted rows
+
+
 def test_topk_cfg4_vs_the_reference_fixture():
     """BASELINE configs[3] at FULL size - 1,000 queries x 100,000 pool rows, k = 50 - against the reference's own call
     (complementary_item_retrieval_trainer.py:241-242: torch.cdist + torch.topk(largest=False), fp32 CPU; tests/golden/topk_cfg4.npz from

@@ -3,7 +3,7 @@
   cfg1  CP forward, 32 precomputed-embedding outfits (8 of 16 items)       [+ hipGraph replay]
   cfg3  FITB: CIR forward + 4-candidate argmin, 1024 outfits
   cfg4  CIR: 1000 queries vs 100k-item pool, k=50 (unsharded, and one 12.5k shard = 1/8 of the 8-GPU layout)
-Prints one JSON line per config."""
+Prints one JSON line per config.   python tools/bench_configs.py [cfg1] [cfg3] [cfg4]   (default: all; rocprofv3 passes name one)"""
 import json, os, sys, time, warnings
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,6 +15,10 @@ from src.models.configs import ItemEncoderConfig, OutfitXConfig
 from src.models.datatypes import OutfitCompatibilityPredictionTask as CP, OutfitComplementaryItemRetrievalTask as CIR
 
 dev = torch.device("cuda", 0)
+if os.environ.get("OFX_TUNE"):                       # e.g. OFX_TUNE=17:0 (top-k through the distance matrix + radix select)
+    from outfitx_amd import _lib as _L
+    for kv in os.environ["OFX_TUNE"].split(","):
+        _L.check(_L.load().ofx_tune(*[int(v) for v in kv.split(":")]))
 model = OutfitX(OutfitXConfig(item_encoder=ItemEncoderConfig(type="clip")))
 model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.outfit_transformer_weights(7).items()}, strict=False)
 model = model.to(dev).eval()
@@ -30,8 +34,9 @@ def timeit(fn, iters=50, warm=5):
     return (time.perf_counter() - t0) / iters
 
 
+only = set(a for a in sys.argv[1:] if a.startswith("cfg"))
 with torch.no_grad():
-    for B in (32, 256, 1024):
+    for B in ((32, 256, 1024) if (not only or "cfg1" in only) else ()):
         emb, mask = synth.outfit_batch(1235, B, 16, 8)
         e, m = cu(emb), cu(mask)
         f = lambda: model(task=CP, outfit_embedding=e, outfit_mask=m)
@@ -54,6 +59,8 @@ with torch.no_grad():
         rec.update({"graph_ms": round(tg * 1e3, 4), "graph_outfits_per_s": round(B / tg, 1), "graph_equal": bool(torch.equal(out, out_g))})
         print(json.dumps(rec), flush=True)
 
+    if only and "cfg3" not in only and "cfg4" not in only:
+        sys.exit(0)
     B = 1024
     emb, mask = synth.outfit_batch(51, B, 16, 8)
     txt = synth.unit_rows(51, "t", B, 512); cand = synth.item_embeddings(51, "cand", B, 4)
@@ -61,8 +68,11 @@ with torch.no_grad():
     def fitb():
         y = model(task=CIR, outfit_embedding=e, outfit_mask=m, target_item_text_embedding=tx)
         return fitb_argmin(y, cd)
-    t = timeit(fitb, 30)
-    print(json.dumps({"config": "cfg3", "what": "FITB: CIR forward + cdist/argmin over 4 candidates, 1024 outfits", "ms": round(t * 1e3, 3), "outfits_per_s": round(B / t, 1)}), flush=True)
+    t = timeit(fitb, 30) if (not only or "cfg3" in only) else float("nan")
+    if not only or "cfg3" in only:
+        print(json.dumps({"config": "cfg3", "what": "FITB: CIR forward + cdist/argmin over 4 candidates, 1024 outfits", "ms": round(t * 1e3, 3), "outfits_per_s": round(B / t, 1)}), flush=True)
+    if only and "cfg4" not in only:
+        sys.exit(0)
 
     nq, npool, k = 1000, 100_000, 50
     emb, mask = synth.outfit_batch(61, nq, 16, 8)
