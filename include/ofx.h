@@ -72,9 +72,10 @@ typedef struct ofx_model_desc {
      * txt_w2_mask: OFX_W2_QKV / OUT / FC1 / FC2 bits - with txt_x3 = 0 the TEXT tower runs the ViT's scheme: f16 activations against split
      *              (hi, lo) weights on those GEMMs (1.5-2 product equivalents instead of 3), MFMA attention on once-rounded q, k, v;
      *              its final LayerNorm + text_projection stay three-product when proj_x3 is set;
-     * vit_w2_qkv_layers / vit_w2_fc1_layers: bit l set = ViT layer l's qkv / fc1 GEMM takes the split weights that OFX_W2_QKV / OFX_W2_FC1
-     *              ask for; 0 = every layer.  (The other layers run the single-product copy: qkv through the fused QKV + attention kernel.) */
-    int txt_w2_mask, vit_w2_qkv_layers, vit_w2_fc1_layers;
+     * vit_w2_qkv_layers / vit_w2_fc1_layers / vit_w2_out_layers / vit_w2_fc2_layers: bit l set = ViT layer l's qkv / fc1 / out-proj / fc2 GEMM
+     *              takes the split weights that the OFX_W2_* bit asks for; 0 = every layer.  (The other layers run the single-product copy:
+     *              qkv through the fused QKV + attention kernel.) */
+    int txt_w2_mask, vit_w2_qkv_layers, vit_w2_fc1_layers, vit_w2_out_layers, vit_w2_fc2_layers;
 } ofx_model_desc;
 enum { OFX_W2_PATCH = 1, OFX_W2_QKV = 2, OFX_W2_OUT = 4, OFX_W2_FC1 = 8, OFX_W2_FC2 = 16 };
 
@@ -263,7 +264,8 @@ int ofx_profile_records(ofx_prof_record* out, int cap);
  *          fetching the next tile's first k-steps under the current epilogue), 0 = one block per tile.
  * knob 16: 1 (default) gemm_x3_kernel launches one block per CU walking its tiles, 0 = one block per tile (short-lived blocks).
  * knob 17: 1 (default) ofx_l2_topk on pools of >= 32,768 rows runs sample + filter (the distance matrix is never written), 0 = always
- *          distance matrix + radix select.  Same results either way. */
+ *          distance matrix + radix select.  Same results either way.
+ * knob 18: 1 (default) the 64-row small-M GEMM kernel keeps two k-tiles in flight (a third LDS stage) on grids of <= 512 blocks, 0 = one.  Bit-identical. */
 int ofx_tune(int knob, int value);
 /* A counter that every ofx_tune call bumps, and whether per-launch profiling events are being recorded: the host mirror replays a
  * stream-captured forward (outfitx_amd/graphs.py) only while the counter still has the value it had at capture time and no recording

@@ -20,15 +20,18 @@ PREC_BF16, PREC_F16, PREC_BF16X3 = 0, 1, 2
 OUT_F32, OUT_OP, OUT_SPLIT3 = 0, 1, 2
 OP_SET_ENCODER, OP_VIT, OP_TEXT, OP_TOPK = 0, 1, 2, 3
 PRECISIONS = {"bf16": PREC_BF16, "f16": PREC_F16, "fp16": PREC_F16, "bf16x3": PREC_BF16X3}
-# CLIP tower operand schemes: name -> (operand type, vit_w2_mask, txt_x3, proj_x3, vit_x3).
-#   "bf16" / "f16": one MFMA product per term everywhere (fastest; 4e-3 / 5e-4 typical at the tower outputs).
-#   "f16w2": f16 operands; the ViT's patch-embedding, out-proj and fc2 GEMMs multiply against split (hi, lo) weights (two
-#   products per weight), the text tower and the ViT's projection tail run three products per term: within 1e-3 end to end on 98
-#   of 100 weight seeds in the 8-outfit test configuration (profiles/r02_seed_sweep_gpu.json; the two misses are draws whose logits are
-#   all small) and on 100 of 100 at the bench's batch size against the reference's own logits, but with the worst at 9.98e-4
-#   (profiles/r03_seed_sweep_bench_scale.json).
-#   "f16w2x" (default): every ViT GEMM against split weights - same two sweeps: 100 of 100 (worst 8.9e-4) and 100 of 100 (median 2.7e-4,
-#   worst 7.3e-4 (8.6e-4 on an earlier build of the round)).  At the bench's batch size the correction product A lo^T runs on the fp8 matrix instruction (gemm_w2f8.hip).
+# CLIP tower operand schemes: name -> (operand type, vit_w2_mask, txt_x3, proj_x3, vit_x3); `tower_scheme` below adds the
+# per-layer rungs.  Parity figures: max|d| / max|ref| over all 256 CP logits of bench.py's batch against the reference's own fp32 CPU output, 100
+# weight seeds (profiles/r04_seed_sweep_bench_scale.json, profiles/r04_rung_screen_100_seeds.json) - a DISTRIBUTION over weight draws, not a constant:
+#   "bf16" / "f16": one MFMA product per term everywhere (fastest; 7e-3 / 0.7-2.8e-3 end to end: outside the north star's 1e-3).
+#   "f16w2x": every ViT GEMM (patch embedding, qkv, out-proj, fc1, fc2) against split (hi, lo) weights, the correction product on the fp8 matrix
+#     instruction at the bench's batch size (gemm_w2f8.hip; e5m2 activation image since round 4); text tower, projection tails and the outfit
+#     transformer in three products.  100 of 100 seeds inside 1e-3: median 2.5e-4, p90 4.5e-4, worst 6.3e-4; lognormal fit: P(>= 1e-3) 0.12 % per draw.
+#   "f16w2h" (DEFAULT since round 4) = "f16w2x@qkv=0-5": the same, but only the first six ViT layers keep the qkv correction (layers 6-11 run the fused
+#     single-product QKV + attention kernel): 3 % faster; 100 of 100 inside 1e-3: median 3.0e-4, p90 5.4e-4, worst 7.35e-4; P(>= 1e-3) 0.24 % per draw.
+#     Rungs below it that were swept and rejected (worst seed >= 8e-4 or no faster): qkv on layers 0-3 (8.05e-4), fc1 on fewer layers (9.6e-4 / 7.7e-4),
+#     fc2 or out-proj corrections on half the layers (9.2e-4 ... 1.06e-3), the text tower in split-weight form (1.65e-3).
+#   "f16w2": split weights on patch / out-proj / fc2 only (qkv through the fused kernel): 9 % faster than f16w2x, worst seeds at 1.0e-3.
 W2_PATCH, W2_QKV, W2_OUT, W2_FC1, W2_FC2 = 1, 2, 4, 8, 16
 TOWER_SCHEMES = {
     "bf16": (PREC_BF16, 0, 0, 0, 0), "f16": (PREC_F16, 0, 0, 0, 0), "fp16": (PREC_F16, 0, 0, 0, 0),
@@ -43,7 +46,8 @@ TOWER_SCHEMES = {
     # q, k, v, P): 1.3-1.8e-4 end to end on the default scheme's worst seeds, 1.9x the time (60.5 vs 32 ms per cfg2 step)
     "f16x3": (PREC_F16, W2_PATCH, 1, 1, 1), "bf16x3": (PREC_BF16, W2_PATCH, 1, 1, 1),
 }
-DEFAULT_TOWER_PRECISION = "f16w2x"
+SCHEME_ALIASES = {"f16w2h": "f16w2x@qkv=0-5"}
+DEFAULT_TOWER_PRECISION = "f16w2h"
 
 
 def _layer_bits(spec: str) -> int:
@@ -60,28 +64,30 @@ def tower_scheme(name: str) -> dict:
     """A tower_precision string -> the ofx_model_desc fields it sets.  A key of TOWER_SCHEMES, optionally followed by '@' and ';'-separated
     options (the finer rungs of round 4, tests/studies/bench_scale_sweep.py):
       txt=w2            the text tower in the ViT's scheme (f16 activations x split weights on qkv / out / fc1 / fc2) instead of three products;
-      qkv=0-5  fc1=0-3,8   ViT layers whose qkv / fc1 GEMM keeps its split weights (the others run the single-product copy).
+      qkv=0-5  fc1=0-3,8  out=none  fc2=6-11   ViT layers whose qkv / fc1 / out-proj / fc2 GEMM keeps its split weights (the others run the
+                        single-product copy).
     Raises ValueError on anything else."""
+    name = SCHEME_ALIASES.get(name, name)
     base, _, opts = name.partition("@")
     if base not in TOWER_SCHEMES:
-        raise ValueError(f"unknown tower_precision {name!r}; one of {sorted(TOWER_SCHEMES)} [+ '@txt=w2;qkv=<layers>;fc1=<layers>']")
+        raise ValueError(f"unknown tower_precision {name!r}; one of {sorted(list(TOWER_SCHEMES) + list(SCHEME_ALIASES))} [+ '@txt=w2;qkv=<layers>;fc1=<layers>']")
     prec, mask, txt_x3, proj_x3, vit_x3 = TOWER_SCHEMES[base]
     d = {"tower_precision": prec, "vit_w2_mask": mask, "txt_x3": txt_x3, "proj_x3": proj_x3, "vit_x3": vit_x3,
-         "txt_w2_mask": 0, "vit_w2_qkv_layers": 0, "vit_w2_fc1_layers": 0}
+         "txt_w2_mask": 0, "vit_w2_qkv_layers": 0, "vit_w2_fc1_layers": 0, "vit_w2_out_layers": 0, "vit_w2_fc2_layers": 0}
     for o in filter(None, opts.split(";")):
         k, _, v = o.partition("=")
         try:
             if k == "txt" and v == "w2":
                 d["txt_x3"], d["txt_w2_mask"] = 0, W2_QKV | W2_OUT | W2_FC1 | W2_FC2
-            elif k in ("qkv", "fc1"):
+            elif k in ("qkv", "fc1", "out", "fc2"):
                 bits = _layer_bits(v) if v not in ("", "none") else 0
                 if bits == 0:
-                    d["vit_w2_mask"] &= ~(W2_QKV if k == "qkv" else W2_FC1)
+                    d["vit_w2_mask"] &= ~{"qkv": W2_QKV, "fc1": W2_FC1, "out": W2_OUT, "fc2": W2_FC2}[k]
                 d[f"vit_w2_{k}_layers"] = bits
             else:
                 raise ValueError
         except ValueError:
-            raise ValueError(f"tower_precision {name!r}: bad option {o!r} (txt=w2 | qkv=<layers> | fc1=<layers>, layers like 0-5,8 or none)") from None
+            raise ValueError(f"tower_precision {name!r}: bad option {o!r} (txt=w2 | qkv= / fc1= / out= / fc2=<layers>, layers like 0-5,8 or none)") from None
     return d
 ACTS = {"none": ACT_NONE, "quick_gelu": ACT_QUICK_GELU, "gelu": ACT_GELU, "mish": ACT_MISH}
 
@@ -95,7 +101,7 @@ class ModelDesc(C.Structure):
         "d_model", "n_head", "d_ffn", "n_layers", "max_items", "outfit_act", "outfit_precision",
         "vit_width", "vit_layers", "vit_heads", "vit_mlp", "vit_patch", "vit_image", "vit_act",
         "txt_width", "txt_layers", "txt_heads", "txt_mlp", "txt_vocab", "txt_max_pos", "txt_act", "txt_eos_id",
-        "proj_dim", "tower_precision")] + [("ln_eps", C.c_float)] + [(n, C.c_int) for n in ("vit_w2_mask", "txt_x3", "proj_x3", "vit_x3", "txt_w2_mask", "vit_w2_qkv_layers", "vit_w2_fc1_layers")]
+        "proj_dim", "tower_precision")] + [("ln_eps", C.c_float)] + [(n, C.c_int) for n in ("vit_w2_mask", "txt_x3", "proj_x3", "vit_x3", "txt_w2_mask", "vit_w2_qkv_layers", "vit_w2_fc1_layers", "vit_w2_out_layers", "vit_w2_fc2_layers")]
 
 
 class ProfRecord(C.Structure):

@@ -29,9 +29,10 @@ def _f32c(t: torch.Tensor, device) -> torch.Tensor:
 
 class Engine:
     """One per (module, device).  `precision`: MFMA operand format of the outfit transformer
-    ('bf16x3' | 'bf16' | 'f16'); `tower_precision`: operand scheme of the CLIP towers (a key of _lib.TOWER_SCHEMES:
-    'f16w2x' (default: every ViT weight split; inside 1e-3 of the reference on all 100 weight seeds swept at the bench's batch size, worst 7.3e-4 (8.6e-4 on an earlier build of the round),
-    and on 100 of 100 in the 8-outfit test configuration, worst 8.9e-4) | 'f16w2' (faster; same sweeps: worst 9.98e-4 / 98 of 100) | 'f16x3' (every tower GEMM three-product) | 'f16' | 'bf16')."""
+    ('bf16x3' | 'bf16' | 'f16'); `tower_precision`: operand scheme of the CLIP towers - a name `_lib.tower_scheme` accepts: 'f16w2h' (default:
+    every ViT weight split, the qkv correction on layers 0-5; all 100 weight seeds swept at the bench's batch size inside 1e-3 of the reference,
+    worst 7.35e-4) | 'f16w2x' (the correction on every layer: worst 6.3e-4, 3 % slower) | 'f16w2' (faster; worst seeds at 1.0e-3) | 'f16x3' (every
+    tower GEMM three-product) | 'f16' | 'bf16' (single product, outside 1e-3) | any of them + '@qkv=<layers>;fc1=...' (per-layer rungs)."""
 
     def __init__(self, device: torch.device, desc: Optional[L.ModelDesc] = None,
                  precision: str = "bf16x3", tower_precision: str = L.DEFAULT_TOWER_PRECISION):

@@ -3,7 +3,7 @@
   cfg1  CP forward, 32 precomputed-embedding outfits (8 of 16 items)       [+ hipGraph replay]
   cfg3  FITB: CIR forward + 4-candidate argmin, 1024 outfits
   cfg4  CIR: 1000 queries vs 100k-item pool, k=50 (unsharded, and one 12.5k shard = 1/8 of the 8-GPU layout)
-Prints one JSON line per config.   python tools/bench_configs.py [cfg1] [cfg3] [cfg4]   (default: all; rocprofv3 passes name one)"""
+Prints one JSON line per config.   python tools/bench_configs.py [cfg1] [cfg1x] [cfg3] [cfg4]   (default: all; cfg1 = 32 outfits only, cfg1x = its 256 / 1024-outfit variants; rocprofv3 passes name one)"""
 import json, os, sys, time, warnings
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -36,7 +36,7 @@ def timeit(fn, iters=50, warm=5):
 
 only = set(a for a in sys.argv[1:] if a.startswith("cfg"))
 with torch.no_grad():
-    for B in ((32, 256, 1024) if (not only or "cfg1" in only) else ()):
+    for B in ((32, 256, 1024) if not only else ((32,) if "cfg1" in only else ()) + ((256, 1024) if "cfg1x" in only else ())):
         emb, mask = synth.outfit_batch(1235, B, 16, 8)
         e, m = cu(emb), cu(mask)
         f = lambda: model(task=CP, outfit_embedding=e, outfit_mask=m)

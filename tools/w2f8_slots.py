@@ -14,14 +14,17 @@ g = torch.Generator(device="cuda"); g.manual_seed(0)
 grid = int(os.environ.get("OFX_GRID", "-1"))          # persistent grid size (ofx_tune 11): fewer blocks = fewer CUs in their epilogues at once
 lib.ofx_tune(11, grid)
 nblk = 256 if grid <= 0 else grid
-for name, M, N, K, okind in [("vit fc2", 102400, 768, 3072, 1), ("vit qkv", 102400, 2304, 768, 1), ("vit out", 102400, 768, 768, 1)]:
+# (act 1 = quick-GELU + bias: fc1's epilogue arithmetic without the LayerNorm-fold terms, which only the model path sets up)
+for name, M, N, K, okind, act in [("vit fc2", 102400, 768, 3072, 1, 0), ("vit qkv", 102400, 2304, 768, 1, 0), ("vit out", 102400, 768, 768, 1, 0),
+                                  ("vit fc1 plain", 102400, 3072, 768, 1, 0), ("vit fc1 quick-GELU + bias", 102400, 3072, 768, 1, 1)]:
     A = torch.randn(M, K, device="cuda", generator=g).half()
     Wf = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
     W2 = torch.empty(N, 2 * K, device="cuda", dtype=torch.float16); L.check(lib.ofx_convert(Wf.data_ptr(), W2.data_ptr(), N, K, 3, 2, s))
     W8 = torch.empty(N, K, device="cuda", dtype=torch.uint8); sc8 = torch.empty(N, device="cuda", dtype=torch.uint8)
     L.check(lib.ofx_pack_lo8(W2.data_ptr(), W8.data_ptr(), sc8.data_ptr(), N, K, s))
     C = torch.empty(M, N, device="cuda", dtype=torch.float16)
-    run = lambda: L.check(lib.ofx_gemm_w2f8(A.data_ptr(), W2.data_ptr(), W8.data_ptr(), sc8.data_ptr(), C.data_ptr(), None, None, M, N, K, K, N, 0, 0, 1, s))
+    bias = torch.randn(N, device="cuda", generator=g)
+    run = lambda: L.check(lib.ofx_gemm_w2f8(A.data_ptr(), W2.data_ptr(), W8.data_ptr(), sc8.data_ptr(), C.data_ptr(), bias.data_ptr() if act else None, None, M, N, K, K, N, 0, act, okind, s))
     for _ in range(30): run()
     torch.cuda.synchronize()
     dbg = torch.zeros(nblk * 32, dtype=torch.int64, device="cuda")
