@@ -24,13 +24,16 @@ PRECISIONS = {"bf16": PREC_BF16, "f16": PREC_F16, "fp16": PREC_F16, "bf16x3": PR
 # per-layer rungs.  Parity figures: max|d| / max|ref| over all 256 CP logits of bench.py's batch against the reference's own fp32 CPU output, 100
 # weight seeds (profiles/r04_seed_sweep_bench_scale.json, profiles/r04_rung_screen_100_seeds.json) - a DISTRIBUTION over weight draws, not a constant:
 #   "bf16" / "f16": one MFMA product per term everywhere (fastest; 7e-3 / 0.7-2.8e-3 end to end: outside the north star's 1e-3).
-#   "f16w2x": every ViT GEMM (patch embedding, qkv, out-proj, fc1, fc2) against split (hi, lo) weights, the correction product on the fp8 matrix
-#     instruction at the bench's batch size (gemm_w2f8.hip; e5m2 activation image since round 4); text tower, projection tails and the outfit
+#   "f16w2x" (DEFAULT): every ViT GEMM (patch embedding, qkv, out-proj, fc1, fc2) against split (hi, lo) weights, the correction product on the fp8
+#     matrix instruction at the bench's batch size (gemm_w2f8.hip; e5m2 activation image since round 4); text tower, projection tails and the outfit
 #     transformer in three products.  100 of 100 seeds inside 1e-3: median 2.5e-4, p90 4.5e-4, worst 6.3e-4; lognormal fit: P(>= 1e-3) 0.12 % per draw.
-#   "f16w2h" (DEFAULT since round 4) = "f16w2x@qkv=0-5": the same, but only the first six ViT layers keep the qkv correction (layers 6-11 run the fused
-#     single-product QKV + attention kernel): 3 % faster; 100 of 100 inside 1e-3: median 3.0e-4, p90 5.4e-4, worst 7.35e-4; P(>= 1e-3) 0.24 % per draw.
-#     Rungs below it that were swept and rejected (worst seed >= 8e-4 or no faster): qkv on layers 0-3 (8.05e-4), fc1 on fewer layers (9.6e-4 / 7.7e-4),
-#     fc2 or out-proj corrections on half the layers (9.2e-4 ... 1.06e-3), the text tower in split-weight form (1.65e-3).
+#     Also inside 1e-3 on every draw of the 8-outfit tests, whose worst (seed 99: all eight reference logits below 0.27) reads 8.9e-4.
+#   "f16w2h" = "f16w2x@qkv=0-5" (the cheapest rung the round-4 screens found inside 8e-4 at the bench's batch size): only the first six ViT layers keep
+#     the qkv correction (layers 6-11 run the fused single-product QKV + attention kernel): 3.2 % faster (8,092 vs 7,837 outfits/s on one box); 100 of
+#     100 inside 1e-3 at 256 outfits: median 3.0e-4, p90 5.4e-4, worst 7.35e-4; P(>= 1e-3) 0.24 % per draw - but 1.53e-3 on the 8-outfit seed-99 draw
+#     (same absolute error, 4e-4, over a batch whose largest logit is 0.27), which is why it is not the default.
+#     Rungs below it that were swept and rejected (worst seed >= 8e-4 at 256 outfits): qkv on layers 0-3 (8.05e-4), fc1 on fewer layers (9.6e-4 /
+#     7.7e-4), fc2 or out-proj corrections on half the layers (9.2e-4 ... 1.06e-3), the text tower in split-weight form (1.65e-3).
 #   "f16w2": split weights on patch / out-proj / fc2 only (qkv through the fused kernel): 9 % faster than f16w2x, worst seeds at 1.0e-3.
 W2_PATCH, W2_QKV, W2_OUT, W2_FC1, W2_FC2 = 1, 2, 4, 8, 16
 TOWER_SCHEMES = {
@@ -47,7 +50,7 @@ TOWER_SCHEMES = {
     "f16x3": (PREC_F16, W2_PATCH, 1, 1, 1), "bf16x3": (PREC_BF16, W2_PATCH, 1, 1, 1),
 }
 SCHEME_ALIASES = {"f16w2h": "f16w2x@qkv=0-5"}
-DEFAULT_TOWER_PRECISION = "f16w2h"
+DEFAULT_TOWER_PRECISION = "f16w2x"
 
 
 def _layer_bits(spec: str) -> int:
@@ -193,6 +196,10 @@ def load() -> C.CDLL:
         fn.restype, fn.argtypes = res, args
     if lib.ofx_abi_version() != ABI_VERSION:
         raise OfxError("libofx_hip.so ABI version mismatch; rebuild")
+    for kv in filter(None, os.environ.get("OFX_TUNE", "").split(",")):       # experiments / A-B runs only: OFX_TUNE=18:0,17:0 -> ofx_tune(18, 0), ofx_tune(17, 0) at load
+        knob, _, val = kv.partition(":")
+        if lib.ofx_tune(int(knob), int(val)) != OFX_OK:
+            raise OfxError(f"OFX_TUNE: ofx_tune({knob}, {val}) was refused")
     _lib = lib
     return lib
 

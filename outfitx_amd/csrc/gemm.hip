@@ -22,14 +22,9 @@ int g_gemm_splitk = 1;     // 0 disables split-K
 namespace {
 // MT = MFMA row tiles per wave: 4 -> the 128x128 block tile, 2 -> 64x128 (twice the blocks for grids that leave CUs idle: the
 // training step's M ~ 2k-row GEMMs with N = 1024; 48 KiB of LDS, three blocks per CU)
-template <typename T, int ABL, int MT = 4, int NSTG = 2>   // ABL: 0 product kernel; 1 no LDS-DMA; 2 no MFMA; 3 no LDS fragment reads (diagnostics, wrong results)
+template <typename T, int ABL, int MT = 4>   // ABL: 0 product kernel; 1 no LDS-DMA; 2 no MFMA; 3 no LDS fragment reads (diagnostics, wrong results)
 __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
     constexpr int BMT = 32 * MT, STAGE_T = (BMT + BN) * BK * 2, EPI_T = 16 * MT * EPI_STRIDE * 4;
-    // stages of the LDS-DMA ring: NSTG = 3 (64-row variant on grids of at most two blocks per CU: small-M GEMMs, each block walking 8-48 k-tiles of
-    // ~0.65 us when only ONE tile is in flight) keeps TWO tiles in flight (round 4: the batch-32 set transformer's 21 GEMMs are this kernel,
-    // profiles/r04_cfg1_kernel_stats.csv)
-    constexpr int NS = NSTG, PER_TILE = MT + 4;
-    static_assert(NS == 2 || (NS == 3 && MT == 2), "three stages: 64-row variant only");
     typedef typename OpT<T>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     OFX_LDS char* lds = (OFX_LDS char*)smem;
@@ -106,18 +101,15 @@ __global__ __launch_bounds__(256, 2) void gemm_128x128_kernel(KArgs p) {
     v8 af[2][MT], wf[2][4];
     const int kt0 = p.splits > 1 ? blockIdx.y * p.kt_per_split : 0;
     const int nk = p.splits > 1 ? min(p.K / BK, kt0 + p.kt_per_split) : p.K / BK;
-    static_assert(PER_TILE == 8 || PER_TILE == 6, "vmcnt immediates below");
-    issue(kt0, 0);
-    if (NS == 3 && kt0 + 1 < nk) issue(kt0 + 1, 1);
+    // (round 4: a third stage - two k-tiles in flight - for the 64-row variant on small grids was built and measured on the batch-32 set transformer,
+    //  whose 21 GEMMs are this kernel: 0.637 vs 0.638 ms per forward, i.e. nothing; the k-tile time of those launches is not prefetch depth. Removed.)
+    issue(kt0, kt0 & 1);
     for (int kt = kt0; kt < nk; ++kt) {
-        const int cur = (kt - kt0) % NS;
-        if (NS == 3) {          // tile kt + 2 goes to the stage tile kt - 1 left (its reads ended before the barrier that closed iteration kt - 1)
-            if (kt + 2 < nk) { issue(kt + 2, (kt - kt0 + 2) % NS); asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
-            else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if (kt + 1 < nk) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
             issue(kt + 1, cur ^ 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (MT == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -216,7 +208,6 @@ size_t ofx_gemm_splitk_bytes(int M, int N, int K) {
 }
 
 
-int g_gemm_deep64 = 1;    // ofx_tune(18, v): 1 (default) the 64-row small-M GEMM keeps two k-tiles in flight (three LDS stages) on grids of <= 512 blocks, 0 = one
 int g_gemm_group_m = 0;   // 0 = adaptive
 int g_gemm_ablate = 0;    // diagnostics only (tools/gemm_bench.py)
 unsigned long long* g_gemm_dbg = nullptr;   // diagnostics only
@@ -269,8 +260,6 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<f16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<bf16_t, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM64_LDS_BYTES));
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<f16_t, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM64_LDS_BYTES));
-        OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<bf16_t, 0, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM64_LDS3_BYTES));
-        OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<f16_t, 0, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM64_LDS3_BYTES));
 #ifdef OFX_DIAG
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
         OFX_HIP(hipFuncSetAttribute((const void*)gemm_128x128_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
@@ -358,10 +347,7 @@ int ofx_launch_gemm(const GemmArgs& g, int op_dtype, hipStream_t s) {
             k.tiles_m = (g.M + 63) / 64; k.nwg = k.tiles_m * k.tiles_n; k.group_m = 2 * gm;
             const dim3 grid64(k.nwg, splits);
             const bool one64 = splits <= 1 || g.defer_splits;      // the launch that carries the profile record's stop event
-            const bool deep = g_gemm_deep64 && (long)k.nwg * (splits > 1 ? splits : 1) <= 512;      // at most two blocks per CU anyway: spend the LDS on a third stage
-            if (deep && op_dtype == OFX_F16) OFX_PLAUNCH(one64, (gemm_128x128_kernel<f16_t, 0, 2, 3>), grid64, dim3(256), GEMM64_LDS3_BYTES, s, k);
-            else if (deep) OFX_PLAUNCH(one64, (gemm_128x128_kernel<bf16_t, 0, 2, 3>), grid64, dim3(256), GEMM64_LDS3_BYTES, s, k);
-            else if (op_dtype == OFX_F16) OFX_PLAUNCH(one64, (gemm_128x128_kernel<f16_t, 0, 2>), grid64, dim3(256), GEMM64_LDS_BYTES, s, k);
+            if (op_dtype == OFX_F16) OFX_PLAUNCH(one64, (gemm_128x128_kernel<f16_t, 0, 2>), grid64, dim3(256), GEMM64_LDS_BYTES, s, k);
             else OFX_PLAUNCH(one64, (gemm_128x128_kernel<bf16_t, 0, 2>), grid64, dim3(256), GEMM64_LDS_BYTES, s, k);
             if (splits > 1) TRY(second_pass());
             OFX_LAUNCH_CHECK();

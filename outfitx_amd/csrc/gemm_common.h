@@ -15,7 +15,6 @@ constexpr int EPI_STRIDE = 68;                         // floats per staged outp
 constexpr int EPI_BYTES_PER_WAVE = 64 * EPI_STRIDE * 4;
 constexpr int GEMM_LDS_BYTES = 4 * EPI_BYTES_PER_WAVE > 2 * STAGE_BYTES ? 4 * EPI_BYTES_PER_WAVE : 2 * STAGE_BYTES;
 constexpr int GEMM64_LDS_BYTES = 2 * (64 + BN) * BK * 2;      // 64x128 variant: 48 KiB (stages) > 4 x 8.5 KiB (epilogue staging)
-constexpr int GEMM64_LDS3_BYTES = 3 * (64 + BN) * BK * 2;     // ... with a third stage (two k-tiles in flight): 72 KiB, two blocks per CU
 
 struct KArgs {
     const char* A;

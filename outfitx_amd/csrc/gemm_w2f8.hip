@@ -126,6 +126,10 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
     int vb = blockIdx.x, m0, n0;
     map_tile(vb, m0, n0);
     if (m0 >= p.M) return;
+    // (Round 4 experiment, removed: a one-time start skew of every second XCD's blocks (v x ~8,100 cycles), so that the two halves of the chip are not in
+    //  their epilogues at the same moments of every round - all four ViT shapes got monotonically SLOWER with the skew (out-proj 261 -> 256 / 262-273 /
+    //  287 / 290 us at v = 3 / 6 / 9 / 12, fc1 727 -> 735 / 743 / 756 / 764; profiles/r04_epilogue_skew.txt): the epilogue's ~11 B/clk/CU is a per-CU
+    //  rate - its LDS round trips and stores in program order -, not a burst on HBM that desynchronising could spread.)
     int base = 0;                                       // (global index of the current tile's step 0) mod 4
     bool first = true, full_prev = false;
     // per-row E8M0 scale bytes of this wave's 128 columns: 8 bytes per lane (fragment j -> byte j); the NEXT tile's are requested before

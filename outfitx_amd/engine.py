@@ -29,9 +29,9 @@ def _f32c(t: torch.Tensor, device) -> torch.Tensor:
 
 class Engine:
     """One per (module, device).  `precision`: MFMA operand format of the outfit transformer
-    ('bf16x3' | 'bf16' | 'f16'); `tower_precision`: operand scheme of the CLIP towers - a name `_lib.tower_scheme` accepts: 'f16w2h' (default:
-    every ViT weight split, the qkv correction on layers 0-5; all 100 weight seeds swept at the bench's batch size inside 1e-3 of the reference,
-    worst 7.35e-4) | 'f16w2x' (the correction on every layer: worst 6.3e-4, 3 % slower) | 'f16w2' (faster; worst seeds at 1.0e-3) | 'f16x3' (every
+    ('bf16x3' | 'bf16' | 'f16'); `tower_precision`: operand scheme of the CLIP towers - a name `_lib.tower_scheme` accepts: 'f16w2x' (default:
+    every ViT weight split; all 100 weight seeds swept at the bench's batch size inside 1e-3 of the reference, worst 6.3e-4) | 'f16w2h' (the qkv
+    correction on ViT layers 0-5 only: 3 % faster, worst 7.35e-4 at that batch size, outside 1e-3 on one small-logit 8-outfit draw) | 'f16w2' (faster; worst seeds at 1.0e-3) | 'f16x3' (every
     tower GEMM three-product) | 'f16' | 'bf16' (single product, outside 1e-3) | any of them + '@qkv=<layers>;fc1=...' (per-layer rungs)."""
 
     def __init__(self, device: torch.device, desc: Optional[L.ModelDesc] = None,

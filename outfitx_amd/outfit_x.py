@@ -188,7 +188,7 @@ class OutfitX(nn.Module):
         # three-product bf16x3 scheme (kept for precomputed fp32 embeddings, where it holds 1e-5) buys nothing there; one f16
         # product (2^-12) is below the bf16 towers' input error and a third of the GEMM work (end-to-end error vs the oracle
         # unchanged at 5-7e-3, step 25.64 -> 24.98 ms; with f16 towers it would double 4e-4 to 8e-4, so it applies to bf16
-        # towers only: the default 'f16w2h' towers and plain 'f16' keep bf16x3).  None = always self.precision.
+        # towers only: the default 'f16w2x' towers and plain 'f16' keep bf16x3).  None = always self.precision.
         self.tower_fed_precision: Optional[str] = "f16"
         _LIVE_MODELS.add(self)
         self.train_precision = train_precision      # operand format of the training step (the reference trains under fp16 autocast on CUDA,

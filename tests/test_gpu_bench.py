@@ -24,7 +24,7 @@ def test_bench_single_gpu_line_has_the_contract_fields():
     if not torch.cuda.is_available():
         pytest.skip("needs a HIP device")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--outfits", "64", "--cpu-outfits", "2",
-                        "--cpu-cfg2-outfits", "1", "--secondary", ""], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--cpu-cfg2-outfits", "1", "--secondary", "", "--rung", ""], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _json_line(r.stdout)
     assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["unit"] == "outfits/s" and j["scaling"] == "weak"

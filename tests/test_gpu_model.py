@@ -5,9 +5,10 @@ size-independent properties at BASELINE.json's full sizes.
 Tolerances (metric: max|Δ| / max|ref| over the batch, as DESIGN.md states):
   outfit transformer, precision 'bf16x3' (default)  : 1e-3   (north-star bound; measured ~1e-5)
   outfit transformer, 'f16' / 'bf16' single product : 3e-3 / 3e-2  (operand-rounding floor; secondary modes)
-  CLIP towers, scheme 'f16w2h' (DEFAULT, what bench.py runs: every ViT GEMM against split weights, the qkv correction on layers 0-5 only) and
-  'f16w2x' (the correction on every layer): 1e-3 at the tower outputs AND end to end on the CP logit (weight draws here; 100 at the bench's batch
-  size in profiles/r04_seed_sweep_bench_scale.json: worst 7.35e-4 / 6.3e-4); 'f16w2' (a faster rung): worst seeds at 1.0e-3, tested on passing ones
+  CLIP towers, scheme 'f16w2x' (DEFAULT, what bench.py runs: every ViT GEMM against split weights): 1e-3 at the tower outputs AND end to end on the
+  CP logit (11 weight draws at 8 outfits here; 100 at the bench's batch size in profiles/r04_seed_sweep_bench_scale.json: worst 6.3e-4); 'f16w2h' (the
+  qkv correction on ViT layers 0-5 only, 3 % faster): 1e-3 at the bench's batch size (worst of 100 seeds 7.35e-4), NOT on the 8-outfit seed-99 draw
+  (1.5e-3), tested where it holds; 'f16w2' (a faster rung still): worst seeds at 1.0e-3, tested on passing ones
   CLIP towers 'f16' / 'bf16' single product          : 4e-3 / 3e-2  (secondary, faster modes: they do not meet the north star's 1e-3)
   argmin / top-k indices                             : bit-exact
 """
@@ -107,8 +108,8 @@ def test_vit_tower_vs_reference_golden(model):
     g = golden("vit_n4")
     px = synth.pixel_values(int(g["seed"]), 4)
     enc = model.item_encoder.image_enc
-    assert enc.tower_precision == DEFAULT_TOWERS == "f16w2h"
-    for prec, tol in ((DEFAULT_TOWERS, 1e-3), ("f16w2x", 1e-3), ("f16w2", 1e-3), ("f16x3", 3e-4), ("bf16", 3e-2), ("f16", 4e-3)):      # the default scheme holds the north star's bound;
+    assert enc.tower_precision == DEFAULT_TOWERS == "f16w2x"
+    for prec, tol in ((DEFAULT_TOWERS, 1e-3), ("f16w2h", 1e-3), ("f16w2", 1e-3), ("f16x3", 3e-4), ("bf16", 3e-2), ("f16", 4e-3)):      # the default scheme holds the north star's bound;
         enc.tower_precision = prec                      # f16x3: what is left is the MFMA attention core's f16 q, k, v, P (1.2e-4 measured)
         out = enc(cu(px).view(4, 1, 3, 224, 224), normalize=False).view(4, 512)
         e = rel_err(out.cpu().numpy(), g["image_embeds"])
@@ -139,7 +140,7 @@ def test_item_encoder_cp_with_encoder_and_precompute(model):
     px = synth.pixel_values(1239, B * L).reshape(B, L, 3, 224, 224)
     ids, att = synth.token_batch(1239, B * L, 64, np.array([4, 8, 6, 3, 9, 12]))
     texts = {"input_ids": torch.from_numpy(ids).view(B, L, 64), "attention_mask": torch.from_numpy(att).view(B, L, 64)}
-    with torch.no_grad():                                       # default tower scheme (f16w2h): the north star's 1e-3 throughout
+    with torch.no_grad():                                       # default tower scheme (f16w2x): the north star's 1e-3 throughout
         items = model.item_encoder(cu(px), texts)
         cp = model(task=CP, outfit_embedding=None, outfit_mask=cu(g["mask"]), encoder_input_dict={"images": cu(px), "texts": texts})
         pe = model(task=PE, images=cu(px[:, :1]), texts={k: v[:, :1] for k, v in texts.items()})
@@ -583,7 +584,7 @@ def test_vit_last_layer_query_pruning_changes_nothing(model):
 
 
 def test_fused_attention_kernel_matches_the_gemm_attention_pair_in_the_default_scheme(model):
-    """Scheme 'f16w2x' (the default 'f16w2h' does this on layers 0-5): ViT layers 0-10 run ofx_gemm (split weights) -> q | k | v in HBM ->
+    """Default scheme 'f16w2x': ViT layers 0-10 run ofx_gemm (split weights) -> q | k | v in HBM ->
     attention kernel; with ofx_tune(9, 3) they run the dual-weight variant of the fused QKV-projection + attention kernel instead (built,
     0.9 % faster, off by default: DESIGN.md section 2).  Same arithmetic: the image embeddings agree to the operand type's rounding, and both hold 1e-3
     against the reference's golden."""
@@ -829,7 +830,7 @@ def test_set_transformer_precision_follows_the_embedding_source(model):
     ids, att = synth.token_batch(77, B * L, 64, 8)
     texts = {"input_ids": torch.from_numpy(ids).view(B, L, 64), "attention_mask": torch.from_numpy(att).view(B, L, 64)}
     mask = np.zeros((B, L), bool)
-    assert model._tower_fed() is None                      # default towers (f16w2h): the set transformer stays bf16x3
+    assert model._tower_fed() is None                      # default towers (f16w2x): the set transformer stays bf16x3
     model.item_encoder.set_precision("bf16")
     assert model.tower_fed_precision == "f16" and model._tower_fed() == "f16"
     with torch.no_grad():
@@ -910,7 +911,7 @@ def _cfg2_end_to_end(wseed, towers, bound, outlier_level=1, force_split_kernel=F
 
 @pytest.mark.parametrize("wseed", [1, 2, 3, 4, 5, 6, 14, 20, 44, 99, -3])
 def test_cfg2_end_to_end_within_1e3_on_every_weight_seed(wseed):
-    """Default scheme ('f16w2h').  Seeds 1-6, the worst seeds of the hundred measured on the GPU for either split-weight scheme
+    """Default scheme ('f16w2x').  Seeds 1-6, the worst seeds of the hundred measured on the GPU for either split-weight scheme
     (profiles/r02_seed_sweep_gpu.json: 14, 20, 44, 99 - on 44 and 99 the cheaper 'f16w2' reads 1.3e-3 / 1.9e-3, this scheme 4.0e-4 /
     8.9e-4, its worst of the hundred: all eight logits of that draw are small, max|ref| = 0.27) and seed 3 with massive
     residual-stream channels."""
@@ -960,8 +961,15 @@ def _bench_batch():
     return _BENCH_BATCH
 
 
+@pytest.mark.parametrize("wseed", [17, 44, 99, "3o2"])
+def test_cfg2_bench_batch_rung_f16w2h_within_1e3_of_the_reference(wseed):
+    """The faster rung 'f16w2h' (qkv correction on ViT layers 0-5 only) at the bench's batch size, on the three worst seeds of its 100-seed sweep
+    (profiles/r04_seed_sweep_bench_scale.json: 44 7.35e-4, 17 and 99 7.26e-4) and on the massive-channel weights."""
+    test_cfg2_bench_batch_within_1e3_of_the_reference(wseed, scheme="f16w2h")
+
+
 @pytest.mark.parametrize("wseed", [7, 17, 44, 75, 89, 97, 99, "3o1", "3o2"])
-def test_cfg2_bench_batch_within_1e3_of_the_reference(wseed):
+def test_cfg2_bench_batch_within_1e3_of_the_reference(wseed, scheme=None):
     """The configuration bench.py times - 256 outfits x 8 items, so every ViT GEMM runs through the persistent 256x256 kernels and
     not the 128x128 split-K paths of the 8-outfit tests - in the default scheme, ALL 256 CP logits against the reference ITSELF
     (src.models.OutfitX._cp_forward with encoder_input_dict, outfit_x.py:120-144, on the CPU in fp32: tests/golden/
@@ -979,8 +987,9 @@ def test_cfg2_bench_batch_within_1e3_of_the_reference(wseed):
     CP = tasks()[0]
     bb = _bench_batch()
     ref = bb["z"][f"w{wseed}"].astype(np.float32)
-    m = OutfitX(OutfitXConfig(item_encoder=ItemEncoderConfig(type="clip")))
-    assert m.item_encoder.image_enc.tower_precision == DEFAULT_TOWERS
+    m = OutfitX(OutfitXConfig(item_encoder=ItemEncoderConfig(type="clip"))) if scheme is None else \
+        OutfitX(OutfitXConfig(item_encoder=ItemEncoderConfig(type="clip")), tower_precision=scheme)
+    assert m.item_encoder.image_enc.tower_precision == (scheme or DEFAULT_TOWERS)
     base, _, lvl = str(wseed).partition("o")
     sd = synth.full_state_dict(int(base))
     if lvl:
@@ -991,7 +1000,7 @@ def test_cfg2_bench_batch_within_1e3_of_the_reference(wseed):
         got = m(task=CP, outfit_embedding=None, outfit_mask=torch.zeros(bb["B"], bb["n"], dtype=torch.bool, device="cuda"),
                 encoder_input_dict={"images": bb["px"], "texts": bb["texts"]}).float().cpu().numpy().reshape(-1)
     e = rel_err(got, ref)
-    print(f"cfg2 bench batch ({DEFAULT_TOWERS}), weight seed {wseed}: {e:.2e} (abs {np.abs(got - ref).max():.2e}, max|ref| {np.abs(ref).max():.3f})")
+    print(f"cfg2 bench batch ({scheme or DEFAULT_TOWERS}), weight seed {wseed}: {e:.2e} (abs {np.abs(got - ref).max():.2e}, max|ref| {np.abs(ref).max():.3f})")
     assert e < 1e-3, e
     del m
     torch.cuda.empty_cache()

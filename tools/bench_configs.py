@@ -15,10 +15,7 @@ from src.models.configs import ItemEncoderConfig, OutfitXConfig
 from src.models.datatypes import OutfitCompatibilityPredictionTask as CP, OutfitComplementaryItemRetrievalTask as CIR
 
 dev = torch.device("cuda", 0)
-if os.environ.get("OFX_TUNE"):                       # e.g. OFX_TUNE=17:0 (top-k through the distance matrix + radix select)
-    from outfitx_amd import _lib as _L
-    for kv in os.environ["OFX_TUNE"].split(","):
-        _L.check(_L.load().ofx_tune(*[int(v) for v in kv.split(":")]))
+# (OFX_TUNE=17:0 in the environment sets a knob at library load, outfitx_amd/_lib.py: e.g. top-k through the distance matrix + radix select)
 model = OutfitX(OutfitXConfig(item_encoder=ItemEncoderConfig(type="clip")))
 model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.outfit_transformer_weights(7).items()}, strict=False)
 model = model.to(dev).eval()
