@@ -264,7 +264,9 @@ int ofx_profile_records(ofx_prof_record* out, int cap);
  *          fetching the next tile's first k-steps under the current epilogue), 0 = one block per tile.
  * knob 16: 1 (default) gemm_x3_kernel launches one block per CU walking its tiles, 0 = one block per tile (short-lived blocks).
  * knob 17: 1 (default) ofx_l2_topk on pools of >= 32,768 rows runs sample + filter (the distance matrix is never written), 0 = always
- *          distance matrix + radix select.  Same results either way. */
+ *          distance matrix + radix select.  Same results either way.
+ * knob 18: 1 (default) the split-weight GEMM's f16 outputs (qkv, fc1) are stored straight from the accumulator layout, 0 = through the LDS
+ *          transpose of rounds 1-3.  Bit-identical results. */
 int ofx_tune(int knob, int value);
 /* A counter that every ofx_tune call bumps, and whether per-launch profiling events are being recorded: the host mirror replays a
  * stream-captured forward (outfitx_amd/graphs.py) only while the counter still has the value it had at capture time and no recording

@@ -37,6 +37,7 @@ struct KArgs {
     // and its per-row E8M0 scale bytes laid out 8 per (128-column block, lane & 15); a8_scale / a8_e8m0: activations are converted as
     // fp8(a / a8_scale) in registers and enter the product with the scale byte a8_e8m0 (= 127 + log2 a8_scale)
     const char* W8 = nullptr; const char* w8_scale = nullptr; float a8_scale = 0.25f; int a8_e8m0 = 125;
+    int epi_direct = 0;         // operand-type outputs without residual / tape leave straight from the accumulator layout (epilogue_direct), no LDS round trip
 };
 
 __device__ __forceinline__ void glds16(const char* g, OFX_LDS char* l) {
@@ -341,6 +342,91 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
                 if (c < 2 * NP && gm < p.M) *(f32x2*)(p.stat_part + ((size_t)gm * (p.N >> 6) + (gn0 >> 6)) * 2) = f32x2{keep_s[k], keep_q[k]};
             }
         }
+    }
+}
+
+// Operand-type (f16 / bf16) output STRAIGHT from the accumulator layout - no LDS round trip (round 4).  epilogue2 above sends every 16-row pass through
+// the wave's LDS staging (4 KiB of fp32 written with ds_write_b128 at ~79 B/clk/CU, read back as row segments): 256 KiB in + 256 KiB out per 256x256
+// tile and a write -> read -> convert -> store chain per pass; stamped at 10.4-11.8k cycles per tile for a plain f16 output (profiles/r04_w2f8_slots.txt),
+// a sixth of a K = 768 tile.  Here a lane keeps what the MFMA left it - row i 16 + (lane & 15), columns j 16 + (lane >> 4) 4 + 0..3 of column block j -,
+// applies the LayerNorm-fold terms / bias / activation in that layout, rounds to the operand type, and ONE v_permlane16_swap per register pair trades halves
+// with the lane 16 away between two neighbouring column blocks: lanes with (lane >> 4) even end up with 8 consecutive columns of block A, the odd ones with
+// 8 consecutive columns of block B (tools/permlane_probe.hip pins the instruction's row mapping).  A store instruction then covers 16 rows x 64 contiguous
+// bytes; the two column-block pairs of a 64-column half complete every 128-byte line back to back.  Stores go through a buffer resource sized to the M
+// valid rows: rows past M fall outside it and are dropped by the hardware (no per-row predicate, no clamping).  FOLD: 0 bias (+ activation), 2 LayerNorm-fold
+// consumer ((acc - colsum mean) rstd + bias', row statistics through the wave's 1 KiB LDS slot `st` as in epilogue2).
+template <typename T, int ACT, int FOLD, int NP, int JW>
+__device__ __forceinline__ void epilogue_direct(const KArgs& p, f32x4 (&acc)[NP][JW], int gm0, int gn0, int lane, OFX_LDS float* st) {
+    static_assert(JW % 4 == 0 && (FOLD == 0 || FOLD == 2), "whole 64-column halves; bias or LayerNorm-fold consumer");
+    typedef T t2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int fr = lane & 15, fq = lane >> 4;
+    if (FOLD == 2) {            // the wave's (mean, rstd) pairs: one 16-byte load per lane (rows 2 lane, 2 lane + 1) -> LDS slot
+        const int ra = min(gm0 + 2 * lane, p.M - 1), rb = min(gm0 + 2 * lane + 1, p.M - 1);
+        f32x4 pr;
+        if (p.stat_ld == 1 && rb == ra + 1) pr = *(const f32x4*)(p.row_stat + 2 * (size_t)ra);
+        else {
+            const f32x2 a2 = *(const f32x2*)(p.row_stat + 2 * (size_t)ra * p.stat_ld), b2 = *(const f32x2*)(p.row_stat + 2 * (size_t)rb * p.stat_ld);
+            pr = f32x4{a2[0], a2[1], b2[0], b2[1]};
+        }
+        *(OFX_LDS f32x4*)(st + 4 * lane) = pr;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    const size_t cbytes = (size_t)p.M * p.ldc * 2;
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (int)(cbytes < 0x7fffffff ? cbytes : 0x7fffffff), 0x00020000);
+    // this lane's bytes of pass 0, column-block pair 0: row gm0 + fr, column gn0 + (fq & 1) 16 + (fq >> 1) 8
+    const unsigned vo = ((unsigned)(gm0 + fr) * (unsigned)p.ldc + (unsigned)(gn0 + (fq & 1) * 16 + (fq >> 1) * 8)) * 2u;
+    const unsigned pass_bytes = 16u * (unsigned)p.ldc * 2u;
+#pragma unroll
+    for (int h = 0; h < JW / 4; ++h) {          // 64-column halves: the per-column constants of one half (32 registers) at a time
+        f32x4 bb[4], cs[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            const int gn = gn0 + (h * 4 + jb) * 16 + fq * 4;
+            bb[jb] = p.bias ? *(const f32x4*)(p.bias + gn) : f32x4{0.f, 0.f, 0.f, 0.f};
+            cs[jb] = FOLD == 2 ? *(const f32x4*)(p.col_sum + gn) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            float mu = 0.f, rs = 1.f;
+            if (FOLD == 2) { const f32x2 ms = *(OFX_LDS f32x2*)(st + 2 * (i * 16 + fr)); mu = ms[0]; rs = ms[1]; }
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                f32x4 va = acc[i][h * 4 + 2 * jp], vb = acc[i][h * 4 + 2 * jp + 1];
+                if (FOLD == 2) { va = (va - cs[2 * jp] * mu) * rs + bb[2 * jp]; vb = (vb - cs[2 * jp + 1] * mu) * rs + bb[2 * jp + 1]; }
+                else { va += bb[2 * jp]; vb += bb[2 * jp + 1]; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { va[e] = act_apply<T, ACT>(va[e]); vb[e] = act_apply<T, ACT>(vb[e]); }
+                const unsigned a_lo = __builtin_bit_cast(unsigned, t2{(T)va[0], (T)va[1]}), a_hi = __builtin_bit_cast(unsigned, t2{(T)va[2], (T)va[3]});
+                const unsigned b_lo = __builtin_bit_cast(unsigned, t2{(T)vb[0], (T)vb[1]}), b_hi = __builtin_bit_cast(unsigned, t2{(T)vb[2], (T)vb[3]});
+                // first result = [A rows 0 | B rows 0 | A rows 2 | B rows 2] of the 16-lane rows, second = [A 1 | B 1 | A 3 | B 3]: a lane with fq even now holds A's
+                // columns fq 4 .. fq 4 + 7 (its own four, then its neighbour's), a lane with fq odd B's columns (fq - 1) 4 .. + 7
+                const u32x2 s0 = __builtin_amdgcn_permlane16_swap(a_lo, b_lo, false, false), s1 = __builtin_amdgcn_permlane16_swap(a_hi, b_hi, false, false);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rc, (int)(vo + (unsigned)(h * 128 + jp * 64)), (int)(i * pass_bytes), 0);
+            }
+        }
+    }
+}
+
+template <typename T, int NP, int JW>
+__device__ __forceinline__ bool epilogue_direct_dispatch(const KArgs& p, f32x4 (&acc)[NP][JW], int gm0, int gn0, int lane, OFX_LDS float* st) {
+    if (!p.epi_direct || p.out_kind != 1 || p.resid || p.xb_out || p.stat_part || p.aux_out || p.drop.thresh || p.n_valid != p.N) return false;
+    if ((size_t)p.M * p.ldc * 2 >= 0x7fffffff) return false;
+    if (p.row_stat) {
+        if (!st) return false;
+        switch (p.act) {
+            case OFX_ACT_QUICK_GELU: epilogue_direct<T, OFX_ACT_QUICK_GELU, 2, NP, JW>(p, acc, gm0, gn0, lane, st); return true;
+            case OFX_ACT_GELU: epilogue_direct<T, OFX_ACT_GELU, 2, NP, JW>(p, acc, gm0, gn0, lane, st); return true;
+            case OFX_ACT_NONE: epilogue_direct<T, OFX_ACT_NONE, 2, NP, JW>(p, acc, gm0, gn0, lane, st); return true;
+            default: return false;
+        }
+    }
+    switch (p.act) {
+        case OFX_ACT_QUICK_GELU: epilogue_direct<T, OFX_ACT_QUICK_GELU, 0, NP, JW>(p, acc, gm0, gn0, lane, st); return true;
+        case OFX_ACT_GELU: epilogue_direct<T, OFX_ACT_GELU, 0, NP, JW>(p, acc, gm0, gn0, lane, st); return true;
+        case OFX_ACT_NONE: epilogue_direct<T, OFX_ACT_NONE, 0, NP, JW>(p, acc, gm0, gn0, lane, st); return true;
+        default: return false;
     }
 }
 

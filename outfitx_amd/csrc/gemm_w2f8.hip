@@ -45,7 +45,7 @@
 // LayerNorm-fold statistics slots sit in the fp8 buffer, which is idle between the tile's last fp8 slot and the next tile's refill.
 #include "gemm_common.h"
 
-extern int g_w2_persist, g_w2_trim;
+extern int g_w2_persist, g_w2_trim, g_epi_direct;
 #ifndef OFX_F8_ABF8
 #define OFX_F8_ABF8 1
 #endif
@@ -364,8 +364,11 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
         if (p.row_stat && p.out_kind != 0) st = (OFX_LDS float*)(lds + W8BASE + wave * 1024);
         sc8 = *(const unsigned long long*)(p.w8_scale + ((size_t)((n1 >> 7) + wc) * 16 + (ln & 15)) * 8);     // the next tile's scale bytes (this tile's own again on the last one)
         OFX_F8_STAMP(st0_)
-        epilogue2_dispatch<T, 4, 8, 0>(p, ep, acc, gm0, gn0, ln, st);
-        epilogue2_dispatch<T, 4, 8, 4>(p, ep, acc, gm0, gn0 + 64, ln, st);
+        OFX_LDS float* st2 = (p.row_stat && p.out_kind != 0) ? st : nullptr;
+        if (!epilogue_direct_dispatch<T, 4, 8>(p, acc, gm0, gn0, ln, st2)) {
+            epilogue2_dispatch<T, 4, 8, 0>(p, ep, acc, gm0, gn0, ln, st);
+            epilogue2_dispatch<T, 4, 8, 4>(p, ep, acc, gm0, gn0 + 64, ln, st);
+        }
         if (ABL == 7) { OFX_F8_STAMP(st1_) epi_cyc += (unsigned)(st1_ - st0_); ++epi_tiles; st0_ = st1_; }
         if (!has_next) break;
         full_prev = m0 + TM <= p.M;
@@ -392,6 +395,7 @@ static int launch_w2f8(KArgs& k, int M, int N, hipStream_t s) {
         return OFX_OK;
     }));
     k.tiles_n = N / 256; k.tiles_m = (M + 255) / 256; k.nwg = k.tiles_m * k.tiles_n;
+    k.epi_direct = g_epi_direct;
     int persist = g_w2_persist;
     if (persist < 0) {
         static int cus[64] = {0};

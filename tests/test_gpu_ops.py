@@ -285,6 +285,39 @@ def test_gemm_split_weights_fp8_correction(force, M, N, K, big):
         assert rel_err(out.cpu().numpy(), exact) < 2e-5
 
 
+@pytest.mark.parametrize("act", [0, 1])
+@pytest.mark.parametrize("M,N,K,ldc", [(1, 256, 128, 256), (255, 512, 256, 512), (1000, 768, 768, 1536), (70001, 2304, 256, 2304)])
+def test_gemm_w2f8_f16_output_leaves_from_the_accumulator_layout(M, N, K, ldc, act):
+    """gemm_w2f8_kernel with an operand-type (f16) output, bias and quick-GELU: since round 4 the tile is stored straight from the MFMA accumulator layout
+    (epilogue_direct: v_permlane16_swap between neighbouring column blocks, 16 rows x 64 contiguous bytes per store instruction, rows past M dropped by the
+    buffer resource's bounds) instead of going through LDS.  Against the float64 product on the quantised operands rounded to f16, bit-identical to the LDS
+    epilogue (ofx_tune(18, 0)), ragged M, a row stride wider than N (columns beyond N untouched)."""
+    g = np.random.default_rng(M + N + K + act)
+    A = to_op(g.standard_normal((M, K), dtype=np.float32), "f16")
+    W2, Wv = _split_w((g.standard_normal((N, K), dtype=np.float32) / np.float32(np.sqrt(K))).astype(np.float32), "f16")
+    W8, sc, lo_seen, _ = _pack_lo8(W2, N, K)
+    bias = dev(g.standard_normal(N, dtype=np.float32))
+    lib = L.load()
+    outs = []
+    lib.ofx_tune(2, 6)
+    try:
+        for direct in (1, 0):
+            lib.ofx_tune(18, direct)
+            out = torch.full((M, ldc), -7.0, dtype=torch.float16, device="cuda")
+            L.check(lib.ofx_gemm_w2f8(A.data_ptr(), W2.data_ptr(), W8.data_ptr(), sc.data_ptr(), out.data_ptr(), bias.data_ptr(), None, M, N, K, K, ldc, 0, act, 1, stream()))
+            torch.cuda.synchronize()
+            outs.append(out)
+    finally:
+        lib.ofx_tune(2, 0); lib.ofx_tune(18, 1)
+    assert torch.equal(outs[0], outs[1])
+    got = outs[0].float().cpu().numpy()
+    assert (got[:, N:] == -7.0).all()                                   # nothing written beyond the N columns of a wider row
+    A8 = A.float().clamp(-57344.0, 57344.0).to(torch.float8_e5m2).double().cpu().numpy()
+    z = A.double().cpu().numpy() @ W2[:, :K].double().cpu().numpy().T + A8 @ lo_seen.T + bias.double().cpu().numpy()
+    want = z / (1.0 + np.exp(-1.702 * z)) if act else z
+    assert rel_err(got[:, :N], want) < 1e-3                             # f16 rounding of the output (2^-11) + the fp32 accumulation
+
+
 @pytest.mark.parametrize("kern", [2, 3, 4, 5])
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("M,N,K", [(1, 256, 64), (255, 256, 128), (257, 512, 768), (1000, 768, 3072), (5000, 256, 192)])
