@@ -403,7 +403,9 @@ __device__ __forceinline__ void epilogue_direct(const KArgs& p, f32x4 (&acc)[NP]
                 // first result = [A rows 0 | B rows 0 | A rows 2 | B rows 2] of the 16-lane rows, second = [A 1 | B 1 | A 3 | B 3]: a lane with fq even now holds A's
                 // columns fq 4 .. fq 4 + 7 (its own four, then its neighbour's), a lane with fq odd B's columns (fq - 1) 4 .. + 7
                 const u32x2 s0 = __builtin_amdgcn_permlane16_swap(a_lo, b_lo, false, false), s1 = __builtin_amdgcn_permlane16_swap(a_hi, b_hi, false, false);
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rc, (int)(vo + (unsigned)(h * 128 + jp * 64)), (int)(i * pass_bytes), 0);
+                // (the pass offset rides in the per-lane offset, NOT in the instruction's scalar offset: with a non-zero soffset on this resource the second and
+                //  fourth dword of rows 12-15 of every pass but the first came out wrong - tools/dbg_direct.py; everything in voffset is correct)
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rc, (int)(vo + (unsigned)i * pass_bytes + (unsigned)(h * 128 + jp * 64)), 0, 0);
             }
         }
     }
