@@ -38,7 +38,9 @@ enum ofx_dtype { OFX_F32 = 0, OFX_BF16 = 1, OFX_F16 = 2 };
 enum ofx_act { OFX_ACT_NONE = 0, OFX_ACT_QUICK_GELU = 1, OFX_ACT_GELU = 2, OFX_ACT_MISH = 3, OFX_ACT_MISH_GRAD = 4 };
 /* MFMA operand precision of a sub-model.  BF16X3 = three bf16 products per term
  * (hi*hi + lo*hi + hi*lo, realised as one K-concatenated GEMM) ~ fp32-grade results. */
-enum ofx_precision { OFX_PREC_BF16 = 0, OFX_PREC_F16 = 1, OFX_PREC_BF16X3 = 2 };
+/* OFX_PREC_F16W2 (outfit transformer only, round 4): f16 activations against split (hi, lo) f16 weights - two MFMA products per weight on ONE copy of
+ * the activations (the towers' scheme): two thirds of bf16x3's weight bytes and matrix work, ~1e-4 instead of ~1e-5 from the fp32 reference; scoring only. */
+enum ofx_precision { OFX_PREC_BF16 = 0, OFX_PREC_F16 = 1, OFX_PREC_BF16X3 = 2, OFX_PREC_F16W2 = 3 };
 enum ofx_out_kind { OFX_OUT_F32 = 0, OFX_OUT_OP = 1, OFX_OUT_SPLIT3 = 2 };
 
 typedef struct ofx_handle ofx_handle;

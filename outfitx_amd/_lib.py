@@ -19,7 +19,8 @@ ACT_NONE, ACT_QUICK_GELU, ACT_GELU, ACT_MISH = 0, 1, 2, 3
 PREC_BF16, PREC_F16, PREC_BF16X3 = 0, 1, 2
 OUT_F32, OUT_OP, OUT_SPLIT3 = 0, 1, 2
 OP_SET_ENCODER, OP_VIT, OP_TEXT, OP_TOPK = 0, 1, 2, 3
-PRECISIONS = {"bf16": PREC_BF16, "f16": PREC_F16, "fp16": PREC_F16, "bf16x3": PREC_BF16X3}
+PREC_F16W2 = 3          # outfit transformer only: f16 activations x split (hi, lo) f16 weights, two products per weight (include/ofx.h)
+PRECISIONS = {"bf16": PREC_BF16, "f16": PREC_F16, "fp16": PREC_F16, "bf16x3": PREC_BF16X3, "f16w2": PREC_F16W2}
 # CLIP tower operand schemes: name -> (operand type, vit_w2_mask, txt_x3, proj_x3, vit_x3); `tower_scheme` below adds the
 # per-layer rungs.  Parity figures: max|d| / max|ref| over all 256 CP logits of bench.py's batch against the reference's own fp32 CPU output, 100
 # weight seeds (profiles/r04_seed_sweep_bench_scale.json, profiles/r04_rung_screen_100_seeds.json) - a DISTRIBUTION over weight draws, not a constant:

@@ -195,7 +195,7 @@ struct ofx_handle {
     ofx_model_desc d;
     // outfit transformer
     Arena a_out; bool out_ready = false;
-    int ot_dtype, ot_kmul, ot_ffn_pad;
+    int ot_dtype, ot_kmul, ot_ffn_pad; bool ot_w2 = false;      // ot_w2: OFX_PREC_F16W2 - weights packed [hi | lo], GEMMs with a wrapping A index (two products per weight)
     std::vector<OutfitLayer> ol;
     float *outfit_token, *tgt_img_emb, *cp_w, *cp_b; void* cir_w; void* cir_w_t = nullptr;   // cir_w_t: W^T operand copy (training dgrad)
     // towers
@@ -233,7 +233,7 @@ extern "C" ofx_handle* ofx_create(int device, const ofx_model_desc* desc) {
     if (d.vit_image % d.vit_patch || (d.vit_image / d.vit_patch) * (d.vit_image / d.vit_patch) + 1 > 64) return bad("ViT sequence (patches+1) must be <= 64");
     if (d.max_items < 0 || d.max_items > 63) return bad("max_items must be in [0,63]");
     if (d.tower_precision != OFX_PREC_BF16 && d.tower_precision != OFX_PREC_F16) return bad("tower_precision must be BF16 or F16");
-    if (d.outfit_precision < 0 || d.outfit_precision > 2) return bad("bad outfit_precision");
+    if (d.outfit_precision < 0 || d.outfit_precision > 3) return bad("bad outfit_precision");
     if (d.n_layers < 1 || d.vit_layers < 1 || d.txt_layers < 1 || d.d_ffn < 1) return bad("layer counts / d_ffn must be positive");
     if (d.vit_w2_mask & ~(OFX_W2_PATCH | OFX_W2_QKV | OFX_W2_OUT | OFX_W2_FC1 | OFX_W2_FC2)) return bad("vit_w2_mask: unknown bit");
     if (d.txt_w2_mask & ~(OFX_W2_QKV | OFX_W2_OUT | OFX_W2_FC1 | OFX_W2_FC2)) return bad("txt_w2_mask: unknown bit");
@@ -241,8 +241,9 @@ extern "C" ofx_handle* ofx_create(int device, const ofx_model_desc* desc) {
     if (hipSetDevice(device) != hipSuccess) return bad("hipSetDevice failed");
     ofx_handle* h = new ofx_handle();
     h->device = device; h->d = d;
-    h->ot_dtype = d.outfit_precision == OFX_PREC_F16 ? OFX_F16 : OFX_BF16;
+    h->ot_dtype = (d.outfit_precision == OFX_PREC_F16 || d.outfit_precision == OFX_PREC_F16W2) ? OFX_F16 : OFX_BF16;
     h->ot_kmul = d.outfit_precision == OFX_PREC_BF16X3 ? 3 : 1;
+    h->ot_w2 = d.outfit_precision == OFX_PREC_F16W2;
     h->ot_ffn_pad = pad128(d.d_ffn);
     h->tw_dtype = d.tower_precision == OFX_PREC_F16 ? OFX_F16 : OFX_BF16;
     h->vit_w2_mask = d.vit_w2_mask; h->txt_w2_mask = d.txt_w2_mask; h->txt_x3 = d.txt_x3 != 0; h->vit_x3 = d.vit_x3 != 0; h->proj_x3 = d.proj_x3 != 0 || h->vit_x3;
@@ -288,26 +289,28 @@ extern "C" int ofx_pack_outfit_weights(ofx_handle* h, const void* const* P, int 
     OFX_REQUIRE(n == 5 + 12 * d.n_layers, OFX_EINVAL, "pack_outfit: expected %d tensors, got %d", 5 + 12 * d.n_layers, n);
     for (int i = 0; i < n; ++i) OFX_REQUIRE(P[i], OFX_EINVAL, "pack_outfit: tensor %d is NULL", i);
     hipStream_t s = (hipStream_t)stream;
-    const size_t D = d.d_model, F = d.d_ffn, Fp = h->ot_ffn_pad, km = h->ot_kmul;
+    const size_t D = d.d_model, F = d.d_ffn, Fp = h->ot_ffn_pad;
+    const size_t km = h->ot_w2 ? 2 : h->ot_kmul;          // K multiplier of the packed weight rows: 1 plain, 2 [hi | lo] (f16w2), 3 [hi | hi | lo] (bf16x3)
+    const bool trainable = h->ot_kmul == 1 && !h->ot_w2;  // single-product precisions also keep W^T operand copies for the backward
     const size_t per_layer = 2 * km * (3 * D * D + D * D + Fp * D + D * Fp) + 4 * (3 * D + D + Fp + D + 4 * D) + 16 * 256;
-    const size_t per_layer_t = km == 1 ? 2 * (3 * D * D + D * D + 2 * Fp * D) + 8 * 256 : 0;
+    const size_t per_layer_t = trainable ? 2 * (3 * D * D + D * D + 2 * Fp * D) + 8 * 256 : 0;
     TRY(h->a_out.reserve((per_layer + per_layer_t) * d.n_layers + 2 * (km + 1) * D * D + 4 * (3 * D + 8) + 16 * 256));
     Arena& A = h->a_out;
     const bool zero_pad = A.fresh;                  // padding written once per allocation
     CopyBatch copies;
-    const int dt = h->ot_dtype, mode = km == 3 ? 2 : 0;
+    const int dt = h->ot_dtype, mode = km == 3 ? 2 : (km == 2 ? 3 : 0);
     h->outfit_token = A.take<float>(D); TRY(copy_f32(h->outfit_token, P[0], D, s));
     h->tgt_img_emb = A.take<float>(D / 2); TRY(copy_f32(h->tgt_img_emb, P[1], D / 2, s));
     h->cp_w = A.take<float>(D); TRY(copy_f32(h->cp_w, P[2], D, s));
     h->cp_b = A.take<float>(1); TRY(copy_f32(h->cp_b, P[3], 1, s));
     h->cir_w = A.take<char>(2 * km * D * D); TRY(ofx_launch_pack_rows((const float*)P[4], h->cir_w, D, D, D, D, D, mode, dt, s));
     h->cir_w_t = nullptr;
-    if (km == 1) { h->cir_w_t = A.take<char>(2 * D * D); TRY(ofx_launch_transpose_cast((const float*)P[4], h->cir_w_t, (int)D, (int)D, (int)D, dt, s)); }
+    if (trainable) { h->cir_w_t = A.take<char>(2 * D * D); TRY(ofx_launch_transpose_cast((const float*)P[4], h->cir_w_t, (int)D, (int)D, (int)D, dt, s)); }
     h->ol.resize(d.n_layers);
     for (int l = 0; l < d.n_layers; ++l) {
         const void* const* q = P + 5 + 12 * l;
         OutfitLayer& L = h->ol[l];
-        const bool both = km == 1;          // single-product precisions: the row-major copy and W^T come out of ONE pass below
+        const bool both = trainable;        // single-product precisions: the row-major copy and W^T come out of ONE pass below
         L.w_in = A.take<char>(2 * km * 3 * D * D); if (!both) TRY(ofx_launch_pack_rows((const float*)q[0], L.w_in, 3 * D, 3 * D, D, D, D, mode, dt, s));
         L.b_in = A.take<float>(3 * D); TRY(copy_f32(L.b_in, q[1], 3 * D, s));
         L.w_out = A.take<char>(2 * km * D * D); if (!both) TRY(ofx_launch_pack_rows((const float*)q[2], L.w_out, D, D, D, D, D, mode, dt, s));
@@ -325,7 +328,7 @@ extern "C" int ofx_pack_outfit_weights(ofx_handle* h, const void* const* P, int 
         L.g2 = A.take<float>(D); TRY(copy_f32(L.g2, q[10], D, s));
         L.be2 = A.take<float>(D); TRY(copy_f32(L.be2, q[11], D, s));
         L.w_in_t = L.w_out_t = L.w_1_t = L.w_2_t = nullptr;
-        if (km == 1) {      // W^T copies for the backward dgrad GEMMs: [K_w, N_w] operand, zero padded
+        if (trainable) {    // W^T copies for the backward dgrad GEMMs: [K_w, N_w] operand, zero padded
             L.w_in_t = A.take<char>(2 * D * 3 * D); TRY(ofx_launch_transpose_cast((const float*)q[0], L.w_in_t, (int)(3 * D), (int)D, (int)(3 * D), dt, s, L.w_in, (int)D));
             L.w_out_t = A.take<char>(2 * D * D); TRY(ofx_launch_transpose_cast((const float*)q[2], L.w_out_t, (int)D, (int)D, (int)D, dt, s, L.w_out, (int)D));
             L.w_1_t = A.take<char>(2 * D * Fp); if (zero_pad) OFX_HIP(hipMemsetAsync(L.w_1_t, 0, 2 * D * Fp, s));      // [D, Fp], columns F.. stay zero
@@ -491,7 +494,7 @@ extern "C" int ofx_pack_text_weights(ofx_handle* h, const void* const* P, int n,
 namespace {
 struct SetWs { int* cu; float* X; char* H; float* QKV; char* U; char* HP; char* UP; char* slab; size_t slab_bytes; };
 size_t carve_set(const ofx_handle* h, Bump& b, int B, int L, SetWs* w) {
-    const size_t M = (size_t)B * (L + 1), D = h->d.d_model, km = h->ot_kmul, Fp = h->ot_ffn_pad;
+    const size_t M = (size_t)B * (L + 1), D = h->d.d_model, km = h->ot_kmul, Fp = h->ot_ffn_pad, wk = h->ot_w2 ? 2 : h->ot_kmul;
     SetWs t;
     t.cu = b.take<int>(B + 1);
     t.X = b.take<float>(M * D);
@@ -503,10 +506,10 @@ size_t carve_set(const ofx_handle* h, Bump& b, int B, int L, SetWs* w) {
     // split-K scratch for the under-filled GEMMs of small batches (largest need over the shapes used)
     t.slab_bytes = 0;
     for (int m : {(int)M, B}) {
-        t.slab_bytes = std::max(t.slab_bytes, ofx_gemm_splitk_bytes(m, 3 * (int)D, (int)(km * D)));
-        t.slab_bytes = std::max(t.slab_bytes, ofx_gemm_splitk_bytes(m, (int)D, (int)(km * D)));
-        t.slab_bytes = std::max(t.slab_bytes, ofx_gemm_splitk_bytes(m, (int)Fp, (int)(km * D)));
-        t.slab_bytes = std::max(t.slab_bytes, ofx_gemm_splitk_bytes(m, (int)D, (int)(km * Fp)));
+        t.slab_bytes = std::max(t.slab_bytes, ofx_gemm_splitk_bytes(m, 3 * (int)D, (int)(wk * D)));
+        t.slab_bytes = std::max(t.slab_bytes, ofx_gemm_splitk_bytes(m, (int)D, (int)(wk * D)));
+        t.slab_bytes = std::max(t.slab_bytes, ofx_gemm_splitk_bytes(m, (int)Fp, (int)(wk * D)));
+        t.slab_bytes = std::max(t.slab_bytes, ofx_gemm_splitk_bytes(m, (int)D, (int)(wk * Fp)));
     }
     t.slab = b.take<char>(t.slab_bytes);
     if (w) *w = t;
@@ -631,7 +634,8 @@ static int set_encoder_core(ofx_handle* h, const SetInput& in, const float* pref
         g1.M = M; g1.N = 3 * D; g1.K = km * D; g1.k_mult = km; g1.lda = km * D; g1.ldc = 3 * D; g1.ldr = 0; g1.act = OFX_ACT_NONE;
         // single-product precisions: q|k|v stay in the operand type and the varlen MFMA attention runs (as in the training forward);
         // bf16x3 keeps fp32 q|k|v and the fp32 set attention (1e-5 parity)
-        const bool mfma_attn = km == 1 && g_train_mfma_attn;
+        if (h->ot_w2) { g1.K = 2 * D; g1.a_wrap = D; }          // split weights: A . (hi + lo)^T on one copy of the activations
+        const bool mfma_attn = km == 1 && !h->ot_w2 && g_train_mfma_attn;       // f16w2 keeps fp32 q | k | v and the fp32 set attention, as bf16x3 does
         g1.out_kind = mfma_attn ? OFX_OUT_OP : OFX_OUT_F32;
         g1.slab = w.slab; g1.slab_bytes = w.slab_bytes;
         int qkv_splits = 1;
@@ -655,6 +659,7 @@ static int set_encoder_core(ofx_handle* h, const SetInput& in, const float* pref
         GemmArgs g2{}; g2.A = H; g2.W = Ly.w_out; g2.C = X; g2.bias = Ly.b_out; g2.resid = X; g2.m_dev = md;
         g2.M = Ml; g2.N = D; g2.K = km * D; g2.k_mult = km; g2.lda = km * D; g2.ldc = D; g2.ldr = D; g2.act = OFX_ACT_NONE; g2.out_kind = OFX_OUT_F32;
         g2.slab = w.slab; g2.slab_bytes = w.slab_bytes;
+        if (h->ot_w2) { g2.K = 2 * D; g2.a_wrap = D; }
         bool ln2_done = false;
         if (fuse) { g2.ln_gamma = Ly.g2; g2.ln_beta = Ly.be2; g2.ln_out = H; g2.ln_ld = km * D; g2.ln_kind = okind; g2.ln_eps = d.ln_eps; g2.ln_done = &ln2_done; }
         TRY(ofx_launch_gemm(g2, dt, s));
@@ -665,10 +670,12 @@ static int set_encoder_core(ofx_handle* h, const SetInput& in, const float* pref
         GemmArgs g3{}; g3.A = H; g3.W = Ly.w_1; g3.C = U; g3.bias = Ly.b_1; g3.resid = nullptr; g3.m_dev = md;
         g3.M = Ml; g3.N = Fp; g3.K = km * D; g3.k_mult = km; g3.lda = km * D; g3.ldc = km * Fp; g3.ldr = 0; g3.act = d.outfit_act; g3.out_kind = okind;
         g3.slab = w.slab; g3.slab_bytes = w.slab_bytes;
+        if (h->ot_w2) { g3.K = 2 * D; g3.a_wrap = D; }
         TRY(ofx_launch_gemm(g3, dt, s));
         GemmArgs g4{}; g4.A = U; g4.W = Ly.w_2; g4.C = X; g4.bias = Ly.b_2; g4.resid = X; g4.m_dev = md;
         g4.M = Ml; g4.N = D; g4.K = km * Fp; g4.k_mult = km; g4.lda = km * Fp; g4.ldc = D; g4.ldr = D; g4.act = OFX_ACT_NONE; g4.out_kind = OFX_OUT_F32;
         g4.slab = w.slab; g4.slab_bytes = w.slab_bytes;
+        if (h->ot_w2) { g4.K = 2 * Fp; g4.a_wrap = Fp; }
         if (fuse && !last) {                            // ... and the next layer's norm1
             const OutfitLayer& Nx = h->ol[l + 1];
             g4.ln_gamma = Nx.g1; g4.ln_beta = Nx.be1; g4.ln_out = w.H; g4.ln_ld = km * D; g4.ln_kind = okind; g4.ln_eps = d.ln_eps; g4.ln_done = &ln1_done;
@@ -693,6 +700,7 @@ extern "C" int ofx_cir_head(ofx_handle* h, const float* row0, int B, float* emb,
     TRY(ofx_launch_pack_rows(row0, ws, B, B, D, D, D, km == 3 ? 1 : 0, h->ot_dtype, s));
     GemmArgs g{}; g.A = ws; g.W = h->cir_w; g.C = emb; g.bias = nullptr; g.resid = nullptr;
     g.M = B; g.N = D; g.K = km * D; g.lda = km * D; g.ldc = D; g.ldr = 0; g.act = OFX_ACT_NONE; g.out_kind = OFX_OUT_F32;
+    if (h->ot_w2) { g.K = 2 * D; g.a_wrap = D; }
     return ofx_launch_gemm(g, h->ot_dtype, s);
 }
 
@@ -1097,7 +1105,7 @@ static int cp_train_fwd_core(ofx_handle* h, const SetInput& in, int B, int L, fl
                              size_t ws_bytes, float dropout_p, unsigned seed, hipStream_t s, int head, const float* target_text) {
     OFX_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, OFX_EINVAL, "cp_train_fwd: dropout_p=%g", dropout_p);
     OFX_REQUIRE(h && h->out_ready, OFX_ESTATE, "cp_train_fwd: outfit weights not packed");
-    OFX_REQUIRE(h->ot_kmul == 1, OFX_ESTATE, "cp_train_fwd: training uses a single-product precision (bf16 / f16), not bf16x3");
+    OFX_REQUIRE(h->ot_kmul == 1 && !h->ot_w2, OFX_ESTATE, "cp_train_fwd: training uses a single-product precision (bf16 / f16), not bf16x3 / f16w2");
     const ofx_model_desc& d = h->d;
     Bump tb(tape_mem, tape_bytes);
     Tape T;
@@ -1216,7 +1224,7 @@ static int set_train_bwd_core(ofx_handle* h, void* tape_mem, size_t tape_bytes, 
     // per-layer completion events (data-parallel overlap): consumed by this call whatever its outcome
     std::vector<hipEvent_t> layer_ev;
     if (h) layer_ev.swap(h->bwd_events);
-    OFX_REQUIRE(h && h->out_ready && h->ot_kmul == 1, OFX_ESTATE, "cp_train_bwd: needs packed single-product weights");
+    OFX_REQUIRE(h && h->out_ready && h->ot_kmul == 1 && !h->ot_w2, OFX_ESTATE, "cp_train_bwd: needs packed single-product weights");
     OFX_REQUIRE(tape_mem && dlogits && (grads || grad_ptrs) && ws && B > 0, OFX_EINVAL, "cp_train_bwd: bad argument");
     OFX_REQUIRE(d_outfit_act_is_mish(h), OFX_ESTATE, "cp_train_bwd: only the Mish activation has a backward epilogue");
     const ofx_model_desc& d = h->d;

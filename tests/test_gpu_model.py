@@ -49,7 +49,7 @@ def cu(a):
 
 
 @pytest.mark.parametrize("tag", ["ot_cfg1", "ot_ragged"])
-@pytest.mark.parametrize("prec,tol", [("bf16x3", 1e-3), ("f16", 3e-3), ("bf16", 3e-2)])
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 1e-3), ("f16w2", 1e-3), ("f16", 3e-3), ("bf16", 3e-2)])
 def test_cp_and_cir_vs_reference_golden(model, tag, prec, tol):
     CP, CIR, FITB, _ = tasks()
     g = golden(tag)

@@ -19,6 +19,7 @@ dev = torch.device("cuda", 0)
 model = OutfitX(OutfitXConfig(item_encoder=ItemEncoderConfig(type="clip")))
 model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.outfit_transformer_weights(7).items()}, strict=False)
 model = model.to(dev).eval()
+model.precision = os.environ.get("OFX_OT_PRECISION", "bf16x3")        # outfit-transformer operand scheme: bf16x3 (default) | f16w2 | f16 | bf16
 cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
@@ -38,7 +39,7 @@ with torch.no_grad():
         e, m = cu(emb), cu(mask)
         f = lambda: model(task=CP, outfit_embedding=e, outfit_mask=m)
         t = timeit(f)
-        rec = {"config": "cfg1" if B == 32 else f"cfg1-B{B}", "what": f"CP forward, {B} precomputed outfits (8 of 16 items), bf16x3", "ms": round(t * 1e3, 4), "outfits_per_s": round(B / t, 1)}
+        rec = {"config": "cfg1" if B == 32 else f"cfg1-B{B}", "what": f"CP forward, {B} precomputed outfits (8 of 16 items), {model.precision}", "ms": round(t * 1e3, 4), "outfits_per_s": round(B / t, 1)}
         if B == 32:       # cfg1 is weight-stream bound - 51,155,313 weights x 2 B once per forward (x3 operand copies in bf16x3)
             rec["weight_stream_GBps_bf16"] = round(51_155_313 * 2 / t / 1e9, 1)
             rec["weight_stream_GBps_as_executed_x3"] = round(51_155_313 * 6 / t / 1e9, 1)
