@@ -258,7 +258,7 @@ int ofx_profile_records(ofx_prof_record* out, int cap);
  * knob 10: 1 (default) small-batch outfit-transformer GEMMs (split-K plans) leave their second pass to the consumer kernel (set
  *          attention sums the q | k | v slabs; reduce + LayerNorm in one launch), 0 the separate reduce and LayerNorm launches;
  * knob 12: 1 (default) split-weight GEMMs with an fp8 copy of their lo halves run the fp8 correction product, 0 = the f16 one;
- * knob 13: log2 of the activation scale of that product (default 2).
+ * knob 13: log2 of the activation scale of that product (default 0 with the e5m2 activation image of round 4; 2 in an e4m3 build, -DOFX_F8_ABF8=0).
  * knob 15: three-product GEMMs: 1 (default) the operand-tiles-loaded-once kernel from 192 tiles on, 2 always, 0 never.
  * knob 14: 1 = the persistent split-weight GEMMs launch the smallest grid that finishes in the same number of rounds (the CUs left alone
  * serve the side stream's kernels); default 0 = one block per CU (the trimmed grid measured 0.4 ms per step slower).
@@ -297,8 +297,10 @@ int ofx_gemm_x3(const void* A3, const void* W3, void* C, const float* bias, cons
 /* The same with the correction product A . lo^T on the block-scaled fp8 matrix instruction (2x the f16 rate; f16 operands only):
  * ofx_pack_lo8 turns the lo halves of W2 [N, 2K] into W8 [N, K] e4m3 bytes (per row scaled to max |lo| 2^sw in [128, 256), the
  * 128-blocks k-permuted as the kernel's in-register fp8 activation image is) + scale8 [N] E8M0 bytes; N and K multiples of 128.
- * ofx_gemm_w2f8 = A hi^T + fp8(A 2^shift) fp8(lo 2^sw)^T 2^-(shift + sw): the weight error drops from 2^-12 to ~2^-15 relative, the
- * activation operand stays the one f16 copy.  Small problems (fewer than 256 tiles of 256 x 256) run ofx_gemm_w2's path on W2. */
+ * ofx_gemm_w2f8 = A hi^T + bf8(A 2^shift) fp8(lo 2^sw)^T 2^-(shift + sw): the weight error drops from 2^-12 to ~2^-15 relative, the
+ * activation operand stays the one f16 copy.  Since round 4 the in-register activation image is E5M2 (f16's exponent range, 3 significant bits,
+ * shift 0): it follows any finite f16 operand - no magnitude precondition on A; values above 57,344 are clamped there (rounds 3's e4m3 image
+ * saturated at |a| > 112 and then corrected such a column only in part).  Small problems (fewer than 256 tiles of 256 x 256) run ofx_gemm_w2's path on W2. */
 int ofx_pack_lo8(const void* W2, void* W8, void* scale8, int N, int K, ofx_stream stream);
 int ofx_gemm_w2f8(const void* A, const void* W2, const void* W8, const void* scale8, void* C, const float* bias, const float* resid, int M, int N, int K,
                   int lda, int ldc, int ldr, int act, int out_kind, ofx_stream stream);
