@@ -695,6 +695,71 @@ def test_cp_forward_as_one_hip_graph_matches_launch_by_launch(model):
         model.eval()
 
 
+def test_drop_in_call_replays_by_itself_and_follows_inputs_weights_and_knobs(model):
+    """OutfitX.graph_replay (default on): the reference's own eval-mode call model(task=CP, outfit_embedding=None, outfit_mask=..., encoder_input_dict=...)
+    runs launch by launch twice, is captured on the second occurrence and replayed as one graph launch from the third on - every result bit-identical
+    to the launch-by-launch one and a FRESH tensor; new contents of the same input tensors are followed (pageable host token tensors included: they are
+    copied before each launch); a parameter update drops the capture (the next calls run on the re-packed weights, launch by launch, then capture again);
+    a longer token row, another tower scheme or an ofx_tune knob starts another entry; train() mode never replays."""
+    from outfitx_amd import _lib as L
+    CP = tasks()[0]
+    B, n = 5, 4
+    mk = lambda seed, nreal=8: (cu(synth.pixel_values(seed, B * n).reshape(B, n, 3, 224, 224)), synth.token_batch(seed, B * n, 64, nreal))
+    px, (ids, att) = mk(601)
+    texts = {"input_ids": torch.from_numpy(ids).view(B, n, 64).clone(), "attention_mask": torch.from_numpy(att).view(B, n, 64).clone()}   # pageable host tensors, as a tokenizer returns them
+    mask = torch.zeros(B, n, dtype=torch.bool, device="cuda")
+    call = lambda: model(task=CP, outfit_embedding=None, outfit_mask=mask, encoder_input_dict={"images": px, "texts": texts})
+    model._replay = None
+    with torch.no_grad():
+        model.graph_replay = False
+        ref1 = call().clone()
+        model.graph_replay = True
+        outs = [call() for _ in range(4)]
+        st = model._replay.stats
+        assert (st["eager"], st["captures"], st["replays"]) == (2, 1, 2)
+        assert all(torch.equal(o, ref1) for o in outs) and outs[2].data_ptr() != outs[3].data_ptr()
+        # new contents at the same addresses
+        px2, (ids2, att2) = mk(602)
+        px.copy_(px2); texts["input_ids"].copy_(torch.from_numpy(ids2).view(B, n, 64)); texts["attention_mask"].copy_(torch.from_numpy(att2).view(B, n, 64))
+        got2 = call()
+        assert model._replay.stats["replays"] == 3
+        model.graph_replay = False
+        ref2 = call().clone()
+        model.graph_replay = True
+        assert torch.equal(got2, ref2) and not torch.equal(ref2, ref1)
+        # a parameter update: the captured step would launch on stale packed weights -> dropped, recomputed
+        w = model.cp_ffn[1].bias
+        w.add_(0.25)
+        got3 = call()
+        assert torch.allclose(got3, ref2 + 0.25, atol=1e-6) and model._replay.stats["replays"] == 3
+        w.sub_(0.25)
+        # a longer token row: another key (the captured graph computes 8 positions)
+        _, (ids3, att3) = mk(603, 12)
+        texts["input_ids"].copy_(torch.from_numpy(ids3).view(B, n, 64)); texts["attention_mask"].copy_(torch.from_numpy(att3).view(B, n, 64))
+        cap0 = model._replay.stats["captures"]
+        a = call(); b = call(); c = call()
+        assert model._replay.stats["captures"] == cap0 + 1 and torch.equal(a, b) and torch.equal(b, c)
+        model.graph_replay = False
+        assert torch.equal(call(), c)
+        model.graph_replay = True
+        # a knob turned between calls: never a stale launch sequence
+        gen = L.load().ofx_config_generation()
+        L.load().ofx_tune(8, 1)
+        assert L.load().ofx_config_generation() == gen + 1
+        n_eager = model._replay.stats["eager"]
+        call()
+        assert model._replay.stats["eager"] == n_eager + 1
+    model.train()
+    try:
+        n_rep = model._replay.stats["replays"]
+        with torch.no_grad():
+            call(); call(); call()
+        assert model._replay.stats["replays"] == n_rep
+    finally:
+        model.eval()
+        model._replay = None
+
+
 def test_text_tower_side_stream_variants_are_bit_identical(model):
     """The text tower beside the ViT: torch's side stream (default), a lowest-priority HIP stream from the C ABI
     (ofx_stream_create_low_priority) and the towers back to back on one stream write the same embeddings bit for bit; so does the
