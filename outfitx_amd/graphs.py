@@ -113,11 +113,13 @@ class ForwardReplay:
         self.capacity, self.capture_after = capacity, capture_after
         self.entries: dict = {}
         self.seen: dict = {}
+        self.failed: set = set()          # keys whose capture raised: never tried again (the launch-by-launch call keeps serving them)
         self.stats = {"eager": 0, "captures": 0, "replays": 0, "capture_failures": 0}
 
     def clear(self) -> None:
         self.entries.clear()
         self.seen.clear()
+        self.failed.clear()
 
     @staticmethod
     def eligible(model, outfit_mask, enc_in) -> bool:
@@ -159,6 +161,9 @@ class ForwardReplay:
         if e is not None and e["sig"] != sig:
             del self.entries[key]
             e = None
+        if e is None and key in self.failed:
+            self.stats["eager"] += 1
+            return eager()
         if e is None:
             n = self.seen.get(key, 0) + 1
             if len(self.seen) > 64:
@@ -170,7 +175,10 @@ class ForwardReplay:
             out = eager()                                  # this call's result; the capture below serves the following ones
             self.stats["eager"] += 1
             e = self._capture(model, outfit_mask, images, ids, att, tokens, sig)
-            if e is not None:
+            if e is None:
+                if len(self.failed) < 256:
+                    self.failed.add(key)
+            else:
                 while len(self.entries) >= self.capacity:
                     self.entries.pop(next(iter(self.entries)))
                 self.entries[key] = e
@@ -202,7 +210,6 @@ class ForwardReplay:
             cc = CapturedCall(fn, dev, warmup=1)
         except Exception:                                  # the launch-by-launch call stays the one that runs
             self.stats["capture_failures"] += 1
-            self.seen.clear()
             return None
         self.stats["captures"] += 1
         return {"graph": cc, "out": cc.output, "ids": ids_d, "att": att_d, "mask": mask_d, "sig": sig}
