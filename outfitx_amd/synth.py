@@ -175,10 +175,23 @@ def outlier_channels(sd: Dict[str, np.ndarray], level: int = 1) -> Dict[str, np.
       level 1: pre-LayerNorm gains and class-embedding entries of 3 residual-stream channels x 30, one fc2 output row (layer 3) x 20;
       level 2: those 3 channels x 100 (residual-stream values in the hundreds: with LayerNorm folding the RAW stream is the A operand
                of qkv and fc1), one fc2 output row x 50, and fc1 rows 77 of layers 2 and 6 (weight and bias) x 50, so that single
-               hidden units of the MLP - fc2's A operand - run into the hundreds as well."""
+               hidden units of the MLP - fc2's A operand - run into the hundreds as well;
+      level 3: level 2, and every encoder layer's LayerNorm gains AND the post-LayerNorm gain of the three massive channels x 1/100 - what trained
+               networks do (without the post-LayerNorm part the pooled CLS row is dominated by the three channels, every image maps to nearly the same
+               embedding and the logits stop depending on the ViT's arithmetic: levels 1 and 2 read 1-2e-5 for that reason): the raw stream
+               carries the massive values (they dominate every LayerNorm's mean and variance, so the other channels arrive at a sixth of their usual
+               scale), while their normalised contribution to the next GEMM is of ordinary size.  With LayerNorm folding the folded weight columns of
+               those channels are 100x smaller than their neighbours and multiply operand values 100x larger."""
     sd = dict(sd)
     p = IMG_PREFIX + "vision_model."
     f_chan, f_row = (30.0, 20.0) if level == 1 else (100.0, 50.0)
+    if level >= 3:
+        for l in range(VIT_LAYERS):
+            for ln in ("layer_norm1", "layer_norm2"):
+                k = p + f"encoder.layers.{l}.{ln}.weight"
+                v = sd[k].copy(); v[[5, 100, 700]] *= np.float32(0.01); sd[k] = v
+        k = p + "post_layernorm.weight"
+        v = sd[k].copy(); v[[5, 100, 700]] *= np.float32(0.01); sd[k] = v
     for k in (p + "pre_layrnorm.weight", p + "embeddings.class_embedding"):
         v = sd[k].copy(); v[[5, 100, 700]] *= np.float32(f_chan); sd[k] = v
     k = p + "encoder.layers.3.mlp.fc2.weight"
