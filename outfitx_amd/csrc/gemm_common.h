@@ -274,14 +274,23 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             if (FOLD == 3 && i + D3 < NP) fetch_hl(i + D3, rh[FOLD == 3 ? (i + D3) % (D3 + 1) : 0], rl[FOLD == 3 ? (i + D3) % (D3 + 1) : 0]);
+#ifndef OFX_EP3_NOLDS
+#define OFX_EP3_NOLDS 0          // experiment build only (WRONG results): the (hi, lo) epilogue without its LDS transposition - same loads, stores and arithmetic
+#endif
+            if (!(OFX_EP3_NOLDS && FOLD == 3)) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *(OFX_LDS f32x4*)(ep + fr * 256 + (((j * 4 + fq) ^ (fr & 7)) << 4)) = acc[i][J0 + j];
+                for (int j = 0; j < 4; ++j) *(OFX_LDS f32x4*)(ep + fr * 256 + (((j * 4 + fq) ^ (fr & 7)) << 4)) = acc[i][J0 + j];
+            }
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const int row = it * 8 + rsub;
                 const int gm = gm0 + i * 16 + row;
-                f32x4 v0 = *(OFX_LDS f32x4*)(ep + row * 256 + (((2 * c8) ^ (row & 7)) << 4));
-                f32x4 v1 = *(OFX_LDS f32x4*)(ep + row * 256 + (((2 * c8 + 1) ^ (row & 7)) << 4));
+                f32x4 v0, v1;
+                if (OFX_EP3_NOLDS && FOLD == 3) { v0 = acc[i][J0 + 2 * it]; v1 = acc[i][J0 + 2 * it + 1]; }
+                else {
+                    v0 = *(OFX_LDS f32x4*)(ep + row * 256 + (((2 * c8) ^ (row & 7)) << 4));
+                    v1 = *(OFX_LDS f32x4*)(ep + row * 256 + (((2 * c8 + 1) ^ (row & 7)) << 4));
+                }
                 if (gm < p.M) {
                     if (FOLD == 2) {
                         float mu, rs;
