@@ -268,7 +268,10 @@ int ofx_profile_records(ofx_prof_record* out, int cap);
  * knob 17: 1 (default) ofx_l2_topk on pools of >= 32,768 rows runs sample + filter (the distance matrix is never written), 0 = always
  *          distance matrix + radix select.  Same results either way.
  * knob 18: 1 (default) the split-weight GEMM's f16 outputs (qkv, fc1) are stored straight from the accumulator layout, 0 = through the LDS
- *          transpose of rounds 1-3.  Bit-identical results. */
+ *          transpose of rounds 1-3, 2 = as 1 with whole-line stores (8 rows x 128 B per instruction after a DPP row exchange; measured level
+ *          with 1: profiles/r04_epilogue_wide_skew.txt).  Bit-identical results.
+ * knob 19: experiment, default 0: start skew of gemm_w2f8_kernel's blocks by XCD (v > 0: odd XCDs start v x ~2,000 cycles late, v < 0:
+ *          XCD x starts x |v| x ~2,000 cycles late).  Results unchanged; no setting was faster (same file). */
 int ofx_tune(int knob, int value);
 /* A counter that every ofx_tune call bumps, and whether per-launch profiling events are being recorded: the host mirror replays a
  * stream-captured forward (outfitx_amd/graphs.py) only while the counter still has the value it had at capture time and no recording

@@ -1360,7 +1360,7 @@ extern "C" int ofx_focal_loss_ex(const float* logits, const float* labels, int B
 }
 
 // ------------------------------------------------------------------------------------- tuning
-extern int g_topk_filter, g_epi_direct;
+extern int g_topk_filter, g_epi_direct, g_w2f8_skew;
 extern int g_gemm_group_m, g_gemm_ablate, g_gemm_kernel, g_gemm_skew, g_gemm_pref, g_gemm_splitk, g_w2_persist, g_w2_fp8, g_w2_fp8_ashift, g_w2_trim, g_x3_kernel, g_x3_persist;
 extern unsigned long long* g_gemm_dbg;
 /* diagnostics: per-block {shader cycles, 100 MHz ticks} of the big-tile GEMM main loop go to buf (device, 16 B per block); NULL = off */
@@ -1385,7 +1385,8 @@ extern "C" int ofx_tune(int knob, int value) {
         case 15: g_x3_kernel = value; return OFX_OK;
         case 16: g_x3_persist = value != 0; return OFX_OK;
         case 17: g_topk_filter = value != 0; return OFX_OK;
-        case 18: g_epi_direct = value != 0; return OFX_OK;
+        case 18: g_epi_direct = value < 0 ? 0 : (value > 2 ? 2 : value); return OFX_OK;
+        case 19: g_w2f8_skew = value; return OFX_OK;
         case 13: if (value < -8 || value > 8) { ofx_set_error("ofx_tune(13): activation shift out of [-8, 8]"); return OFX_EINVAL; } g_w2_fp8_ashift = value; return OFX_OK;
         default: ofx_set_error("ofx_tune: unknown knob %d", knob); return OFX_EINVAL;
     }

@@ -208,6 +208,7 @@ size_t ofx_gemm_splitk_bytes(int M, int N, int K) {
 }
 
 
+int g_w2f8_skew = 0;      // ofx_tune(19, v): start skew of gemm_w2f8_kernel's blocks by XCD (experiment; KArgs::skew)
 int g_epi_direct = 1;     // ofx_tune(18, v): 1 (default) gemm_w2f8_kernel's operand-type outputs leave straight from the accumulator layout (epilogue_direct), 0 = through LDS
 int g_gemm_group_m = 0;   // 0 = adaptive
 int g_gemm_ablate = 0;    // diagnostics only (tools/gemm_bench.py)

@@ -364,7 +364,11 @@ __device__ __forceinline__ void epilogue2(const KArgs& p, OFX_LDS char* ep, f32x
 // bytes; the two column-block pairs of a 64-column half complete every 128-byte line back to back.  Stores go through a buffer resource sized to the M
 // valid rows: rows past M fall outside it and are dropped by the hardware (no per-row predicate, no clamping).  FOLD: 0 bias (+ activation), 2 LayerNorm-fold
 // consumer ((acc - colsum mean) rstd + bias', row statistics through the wave's 1 KiB LDS slot `st` as in epilogue2).
-template <typename T, int ACT, int FOLD, int NP, int JW>
+// WIDE (ofx_tune(18, 2)): the two registers of a 64-column half trade their upper / lower eight rows through DPP row_ror:8 (lane fr <-> fr ^ 8, 8 moves per pair of
+// stores), so that a store instruction covers 8 rows x 128 contiguous bytes - whole cache lines - and leaves as a plain global store predicated on row < M.
+// tools/store_shape_probe.hip: with a quarter of the chip storing, 16 rows x 64 B per instruction leave at 33 GB/s per CU whatever the instruction, 8 rows x 128 B
+// at > 80 GB/s (HBM-bound at 64 CUs); with all 256 CUs storing at once every shape is HBM-bound (5.1-6.9 TB/s).
+template <typename T, int ACT, int FOLD, int NP, int JW, bool WIDE = false>
 __device__ __forceinline__ void epilogue_direct(const KArgs& p, f32x4 (&acc)[NP][JW], int gm0, int gn0, int lane, OFX_LDS float* st) {
     static_assert(JW % 4 == 0 && (FOLD == 0 || FOLD == 2), "whole 64-column halves; bias or LayerNorm-fold consumer");
     typedef T t2 __attribute__((ext_vector_type(2)));
@@ -387,6 +391,8 @@ __device__ __forceinline__ void epilogue_direct(const KArgs& p, f32x4 (&acc)[NP]
     // this lane's bytes of pass 0, column-block pair 0: row gm0 + fr, column gn0 + (fq & 1) 16 + (fq >> 1) 8
     const unsigned vo = ((unsigned)(gm0 + fr) * (unsigned)p.ldc + (unsigned)(gn0 + (fq & 1) * 16 + (fq >> 1) * 8)) * 2u;
     const unsigned pass_bytes = 16u * (unsigned)p.ldc * 2u;
+    // WIDE: row gm0 + (fr & 7) (+ 8 for the second store), bytes (fr >> 3) 64 + (fq & 1) 32 + (fq >> 1) 16 of the 128-byte half
+    const unsigned wo = ((unsigned)(gm0 + (fr & 7)) * (unsigned)p.ldc + (unsigned)(gn0 + (fr >> 3) * 32 + (fq & 1) * 16 + (fq >> 1) * 8)) * 2u;
 #pragma unroll
     for (int h = 0; h < JW / 4; ++h) {          // 64-column halves: the per-column constants of one half (32 registers) at a time
         f32x4 bb[4], cs[4];
@@ -400,6 +406,7 @@ __device__ __forceinline__ void epilogue_direct(const KArgs& p, f32x4 (&acc)[NP]
         for (int i = 0; i < NP; ++i) {
             float mu = 0.f, rs = 1.f;
             if (FOLD == 2) { const f32x2 ms = *(OFX_LDS f32x2*)(st + 2 * (i * 16 + fr)); mu = ms[0]; rs = ms[1]; }
+            u32x4 d[2];
 #pragma unroll
             for (int jp = 0; jp < 2; ++jp) {
                 f32x4 va = acc[i][h * 4 + 2 * jp], vb = acc[i][h * 4 + 2 * jp + 1];
@@ -414,7 +421,21 @@ __device__ __forceinline__ void epilogue_direct(const KArgs& p, f32x4 (&acc)[NP]
                 const u32x2 s0 = __builtin_amdgcn_permlane16_swap(a_lo, b_lo, false, false), s1 = __builtin_amdgcn_permlane16_swap(a_hi, b_hi, false, false);
                 // (the pass offset rides in the per-lane offset, NOT in the instruction's scalar offset: with a non-zero soffset on this resource the second and
                 //  fourth dword of rows 12-15 of every pass but the first came out wrong - tools/dbg_direct.py; everything in voffset is correct)
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rc, (int)(vo + (unsigned)i * pass_bytes + (unsigned)(h * 128 + jp * 64)), 0, 0);
+                if (!WIDE) __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rc, (int)(vo + (unsigned)i * pass_bytes + (unsigned)(h * 128 + jp * 64)), 0, 0);
+                else d[jp] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+            }
+            if (WIDE) {
+                // d[0] = bytes [0, 64) of this lane's row in the half, d[1] = bytes [64, 128).  x: rows 0-7 whole (lanes fr >= 8 take row fr - 8's d[1]),
+                // y: rows 8-15 whole (lanes fr < 8 take row fr + 8's d[0]); row_ror:8 = 0x128, bank mask = the four-lane banks written
+                u32x4 x = d[0], y = d[1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x[e] = (unsigned)__builtin_amdgcn_update_dpp((int)x[e], (int)d[1][e], 0x128, 0xf, 0xc, false);
+                    y[e] = (unsigned)__builtin_amdgcn_update_dpp((int)y[e], (int)d[0][e], 0x128, 0xf, 0x3, false);
+                }
+                const unsigned o = wo + (unsigned)i * pass_bytes + (unsigned)(h * 128);
+                if (gm0 + i * 16 + (fr & 7) < p.M) *(u32x4*)((char*)p.C + (size_t)o) = x;
+                if (gm0 + i * 16 + 8 + (fr & 7) < p.M) *(u32x4*)((char*)p.C + (size_t)(o + 8u * (unsigned)p.ldc * 2u)) = y;
             }
         }
     }
@@ -424,21 +445,24 @@ template <typename T, int NP, int JW>
 __device__ __forceinline__ bool epilogue_direct_dispatch(const KArgs& p, f32x4 (&acc)[NP][JW], int gm0, int gn0, int lane, OFX_LDS float* st) {
     if (!p.epi_direct || p.out_kind != 1 || p.resid || p.xb_out || p.stat_part || p.aux_out || p.drop.thresh || p.n_valid != p.N) return false;
     if ((size_t)p.M * p.ldc * 2 >= 0x7fffffff) return false;
+    const bool wide = p.epi_direct == 2;
+#define OFX_EPD(ACT_, FOLD_) { if (wide) epilogue_direct<T, ACT_, FOLD_, NP, JW, true>(p, acc, gm0, gn0, lane, st); else epilogue_direct<T, ACT_, FOLD_, NP, JW, false>(p, acc, gm0, gn0, lane, st); return true; }
     if (p.row_stat) {
         if (!st) return false;
         switch (p.act) {
-            case OFX_ACT_QUICK_GELU: epilogue_direct<T, OFX_ACT_QUICK_GELU, 2, NP, JW>(p, acc, gm0, gn0, lane, st); return true;
-            case OFX_ACT_GELU: epilogue_direct<T, OFX_ACT_GELU, 2, NP, JW>(p, acc, gm0, gn0, lane, st); return true;
-            case OFX_ACT_NONE: epilogue_direct<T, OFX_ACT_NONE, 2, NP, JW>(p, acc, gm0, gn0, lane, st); return true;
+            case OFX_ACT_QUICK_GELU: OFX_EPD(OFX_ACT_QUICK_GELU, 2)
+            case OFX_ACT_GELU: OFX_EPD(OFX_ACT_GELU, 2)
+            case OFX_ACT_NONE: OFX_EPD(OFX_ACT_NONE, 2)
             default: return false;
         }
     }
     switch (p.act) {
-        case OFX_ACT_QUICK_GELU: epilogue_direct<T, OFX_ACT_QUICK_GELU, 0, NP, JW>(p, acc, gm0, gn0, lane, st); return true;
-        case OFX_ACT_GELU: epilogue_direct<T, OFX_ACT_GELU, 0, NP, JW>(p, acc, gm0, gn0, lane, st); return true;
-        case OFX_ACT_NONE: epilogue_direct<T, OFX_ACT_NONE, 0, NP, JW>(p, acc, gm0, gn0, lane, st); return true;
+        case OFX_ACT_QUICK_GELU: OFX_EPD(OFX_ACT_QUICK_GELU, 0)
+        case OFX_ACT_GELU: OFX_EPD(OFX_ACT_GELU, 0)
+        case OFX_ACT_NONE: OFX_EPD(OFX_ACT_NONE, 0)
         default: return false;
     }
+#undef OFX_EPD
 }
 
 template <typename T, int NP = 8, int JW = 4, int J0 = 0>

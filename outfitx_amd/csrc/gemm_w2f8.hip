@@ -45,7 +45,7 @@
 // LayerNorm-fold statistics slots sit in the fp8 buffer, which is idle between the tile's last fp8 slot and the next tile's refill.
 #include "gemm_common.h"
 
-extern int g_w2_persist, g_w2_trim, g_epi_direct;
+extern int g_w2_persist, g_w2_trim, g_epi_direct, g_w2f8_skew;
 #ifndef OFX_F8_ABF8
 #define OFX_F8_ABF8 1
 #endif
@@ -126,10 +126,14 @@ __global__ __launch_bounds__(512, 2) void gemm_w2f8_kernel(KArgs p) {
     int vb = blockIdx.x, m0, n0;
     map_tile(vb, m0, n0);
     if (m0 >= p.M) return;
-    // (Round 4 experiment, removed: a one-time start skew of every second XCD's blocks (v x ~8,100 cycles), so that the two halves of the chip are not in
-    //  their epilogues at the same moments of every round - all four ViT shapes got monotonically SLOWER with the skew (out-proj 261 -> 256 / 262-273 /
-    //  287 / 290 us at v = 3 / 6 / 9 / 12, fc1 727 -> 735 / 743 / 756 / 764; profiles/r04_epilogue_skew.txt): the epilogue's ~11 B/clk/CU is a per-CU
-    //  rate - its LDS round trips and stores in program order -, not a burst on HBM that desynchronising could spread.)
+    // Experiment knob (ofx_tune(19, v), default 0): a one-time start skew by XCD, so that the chip's CUs are not in their epilogues at the same moments of every
+    // round.  With the 16 rows x 64 B stores every ViT shape got monotonically slower with the skew (profiles/r04_epilogue_skew.txt); with whole-line stores
+    // (ofx_tune(18, 2)), whose per-CU rate is 2.5x higher (tools/store_shape_probe.hip), two-phase and eight-phase skews measure level within +-1 %
+    // (profiles/r04_epilogue_wide_skew.txt): neither the instruction's shape nor the phase of the other CUs sets the epilogue's time.
+    if (p.skew) {
+        const int x = blockIdx.x & 7, units = p.skew > 0 ? (x & 1) * p.skew : x * -p.skew;
+        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(32);       // ~2,048 cycles each
+    }
     int base = 0;                                       // (global index of the current tile's step 0) mod 4
     bool first = true, full_prev = false;
     // per-row E8M0 scale bytes of this wave's 128 columns: 8 bytes per lane (fragment j -> byte j); the NEXT tile's are requested before
@@ -396,6 +400,7 @@ static int launch_w2f8(KArgs& k, int M, int N, hipStream_t s) {
     }));
     k.tiles_n = N / 256; k.tiles_m = (M + 255) / 256; k.nwg = k.tiles_m * k.tiles_n;
     k.epi_direct = g_epi_direct;
+    k.skew = g_w2f8_skew;
     int persist = g_w2_persist;
     if (persist < 0) {
         static int cus[64] = {0};

@@ -301,7 +301,7 @@ def test_gemm_w2f8_f16_output_leaves_from_the_accumulator_layout(M, N, K, ldc, a
     outs = []
     lib.ofx_tune(2, 6)
     try:
-        for direct in (1, 0):
+        for direct in (1, 0, 2):
             lib.ofx_tune(18, direct)
             out = torch.full((M, ldc), -7.0, dtype=torch.float16, device="cuda")
             L.check(lib.ofx_gemm_w2f8(A.data_ptr(), W2.data_ptr(), W8.data_ptr(), sc.data_ptr(), out.data_ptr(), bias.data_ptr(), None, M, N, K, K, ldc, 0, act, 1, stream()))
@@ -310,6 +310,7 @@ def test_gemm_w2f8_f16_output_leaves_from_the_accumulator_layout(M, N, K, ldc, a
     finally:
         lib.ofx_tune(2, 0); lib.ofx_tune(18, 1)
     assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[2])                                # 2 = whole-line stores (8 rows x 128 B through a DPP row exchange, predicated global stores)
     got = outs[0].float().cpu().numpy()
     assert (got[:, N:] == -7.0).all()                                   # nothing written beyond the N columns of a wider row
     A8 = A.float().clamp(-57344.0, 57344.0).to(torch.float8_e5m2).double().cpu().numpy()
