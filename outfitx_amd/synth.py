@@ -272,6 +272,50 @@ def bench_batch(seed: int, B: int = 256, n_items: int = 8, T: int = 64, n_real: 
     ids, att = token_batch(seed, B * n_items, T, n_real)
     return px, ids, att
 
+# ---- a synthetic CLIP BPE vocabulary (string inputs) -------------------------------------------------
+# The fashion-clip vocabulary is not available offline.  CLIPTokenizer itself is (transformers): given ANY vocab.json + merges.txt of
+# CLIP's format it runs the reference's string path (clip_text_encoder.py:42-50: lower-case, byte-level BPE, BOS / EOS, EOS-id padding
+# to 64).  This writes such a pair, deterministically: the 256 byte symbols and their end-of-word forms (ids 0..511, as in the real
+# vocabulary), one merged token per rule below, fillers up to 49,405, BOS 49,406, EOS 49,407 (the ids the text tower's kernels key on).
+CLIP_SYNTH_MERGES = [("r", "e"), ("re", "d</w>"), ("d", "r"), ("dr", "e"), ("dre", "s"), ("dres", "s</w>"), ("b", "l"), ("bl", "u"), ("blu", "e</w>"),
+                     ("j", "e"), ("je", "a"), ("jea", "n"), ("jean", "s</w>"), ("s", "h"), ("sh", "o"), ("sho", "e"), ("shoe", "s</w>"),
+                     ("t", "o"), ("to", "p</w>"), ("s", "k"), ("sk", "i"), ("ski", "r"), ("skir", "t</w>"), ("b", "a"), ("ba", "g</w>"),
+                     ("c", "o"), ("co", "a"), ("coa", "t</w>"), ("h", "a"), ("ha", "t</w>"), ("l", "e"), ("le", "a"), ("lea", "t"),
+                     ("leat", "h"), ("leath", "e"), ("leathe", "r</w>"), ("w", "o"), ("wo", "o"), ("woo", "l</w>")]
+
+
+def _bytes_to_unicode() -> Dict[int, str]:
+    """The byte -> printable-character table of GPT-2 / CLIP byte-level BPE (public algorithm; transformers 5 no longer exports it)."""
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(0xA1, 0xAC + 1)) + list(range(0xAE, 0xFF + 1))
+    cs, n = bs[:], 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b); cs.append(256 + n); n += 1
+    return dict(zip(bs, (chr(c) for c in cs)))
+
+
+def write_clip_vocabulary(directory: str) -> str:
+    """vocab.json + merges.txt in `directory` (created); returns it.  CLIPTokenizer.from_pretrained(directory) then tokenises strings."""
+    import json, os
+    chars = list(_bytes_to_unicode().values())
+    vocab: Dict[str, int] = {}
+    for c in chars:
+        vocab[c] = len(vocab)
+    for c in chars:
+        vocab[c + "</w>"] = len(vocab)
+    for a, b in CLIP_SYNTH_MERGES:
+        vocab.setdefault(a + b, len(vocab))
+    while len(vocab) < BOS_ID:
+        vocab[f"<filler_{len(vocab)}>"] = len(vocab)
+    vocab["<|startoftext|>"] = BOS_ID
+    vocab["<|endoftext|>"] = EOS_ID
+    os.makedirs(directory, exist_ok=True)
+    with open(os.path.join(directory, "vocab.json"), "w") as f:
+        json.dump(vocab, f)
+    with open(os.path.join(directory, "merges.txt"), "w") as f:
+        f.write("#version: 0.2\n" + "\n".join(f"{a} {b}" for a, b in CLIP_SYNTH_MERGES) + "\n")
+    return directory
+
 
 def checksum(a: np.ndarray) -> str:
     return f"{zlib.crc32(np.ascontiguousarray(a).tobytes()):08x}"

@@ -132,6 +132,40 @@ def test_text_tower_vs_reference_golden(model):
         assert rel_err(a, g["text_embeds"]) < tol and rel_err(b, g["text_embeds"]) < tol
     enc.tower_precision = DEFAULT_TOWERS
 
+def test_string_inputs_through_the_towers_vs_the_reference(model, tmp_path):
+    """The reference's text path starts from Python strings (clip_text_encoder.py:42-50).  With a vocabulary of CLIP's format on disk (here the synthetic one of
+    synth.write_clip_vocabulary; the fashion-clip files are not available offline) List[List[str]] goes through transformers' CLIPTokenizer and the HIP text tower:
+    vs the reference's own outputs for the same strings (tests/golden/text_strings.npz from oracle/gen_string_golden.py) - raw text embeddings, item embeddings,
+    CP logits from encoder_input_dict, precompute_embeddings - incl. an empty string and a text truncated at 64 tokens; bit-identical to feeding the token ids."""
+    pytest.importorskip("transformers")
+    CP, _, _, PE = tasks()
+    g = golden("text_strings")
+    B, L = int(g["rows"]), int(g["cols"])
+    flat = [str(t) for t in g["strings"]]
+    strings = [flat[b * L:(b + 1) * L] for b in range(B)]
+    enc = model.item_encoder.text_enc
+    old = enc._tok_name, enc.tokenizer
+    enc._tok_name, enc.tokenizer = synth.write_clip_vocabulary(str(tmp_path / "clip_synth")), None
+    try:
+        px = synth.pixel_values(int(g["px_seed"]), B * L).reshape(B, L, 3, 224, 224)
+        ids = {"input_ids": torch.from_numpy(g["input_ids"]).view(B, L, 64), "attention_mask": torch.from_numpy(g["attention_mask"]).view(B, L, 64)}
+        with torch.no_grad():
+            raw = enc(strings, normalize=False)
+            raw_ids = enc(ids, normalize=False)
+            items = model.item_encoder(cu(px), strings)
+            cp = model(task=CP, outfit_embedding=None, outfit_mask=cu(g["mask"]), encoder_input_dict={"images": cu(px), "texts": strings})
+            cp_ids = model(task=CP, outfit_embedding=None, outfit_mask=cu(g["mask"]), encoder_input_dict={"images": cu(px), "texts": ids})
+            pe = model(task=PE, images=cu(px[:, :1]), texts=[[r[0]] for r in strings])
+        assert torch.equal(raw, raw_ids) and torch.equal(cp, cp_ids)
+        e = [rel_err(raw.cpu().numpy(), g["text_embeds"]), rel_err(items.cpu().numpy(), g["item_emb"]), rel_err(cp.cpu().numpy(), g["cp_logits"]),
+             rel_err(pe.cpu().numpy(), g["precomputed"])]
+        print("strings: text %.2e items %.2e cp %.2e precompute %.2e" % tuple(e))
+        assert max(e) < 1e-3
+        with pytest.raises(ValueError):
+            enc([["a", "b"], ["c"]])
+    finally:
+        enc._tok_name, enc.tokenizer = old
+
 
 def test_item_encoder_cp_with_encoder_and_precompute(model):
     CP, _, _, PE = tasks()

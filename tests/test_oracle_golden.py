@@ -58,6 +58,19 @@ def test_text_tower(txt_weights):
         o = O.text_forward(ids[i:i + 1, :n], att[i:i + 1, :n], txt_weights)
         assert rel_err(o, g["text_embeds"][i:i + 1]) < TOL
 
+def test_string_inputs_tokenise_to_the_fixture_and_the_oracle_follows(tmp_path, txt_weights):
+    """Strings (clip_text_encoder.py:42-50): transformers' CLIPTokenizer on the synthetic vocabulary that synth.write_clip_vocabulary regenerates gives the
+    token ids the reference's own tokenizer produced (oracle/gen_string_golden.py), incl. the empty string and the text truncated at 64 tokens; the oracle's
+    text tower on those ids reproduces the reference's text embeddings."""
+    transformers = pytest.importorskip("transformers")
+    g = golden("text_strings")
+    tok = transformers.CLIPTokenizer.from_pretrained(synth.write_clip_vocabulary(str(tmp_path / "clip_synth")))
+    enc = tok(text=[str(t) for t in g["strings"]], max_length=64, padding="max_length", truncation=True, return_tensors="np")
+    assert np.array_equal(enc["input_ids"], g["input_ids"]) and np.array_equal(enc["attention_mask"], g["attention_mask"])
+    assert g["attention_mask"].sum(-1).tolist() == [5, 6, 6, 4, 2, 64]
+    out = O.text_forward(g["input_ids"], g["attention_mask"], txt_weights)
+    assert rel_err(out, g["text_embeds"].reshape(-1, 512)) < TOL
+
 
 def test_item_encoder_and_cp_with_encoder(ot_weights, vit_weights, txt_weights):
     g = golden("item_encoder")
