@@ -6,6 +6,7 @@ fixture it writes is data (expected outputs + checksums of the regenerated input
 
     python oracle/gen_bench_golden.py 7 44 89 97 99        # -> tests/golden/cfg2_bench_logits.npz  (resumable: seeds are appended)
     python oracle/gen_bench_golden.py 3o1 3o2              # weight seed 3 with synth.outlier_channels level 1 / 2 (rows "w3o1", "w3o2")
+    python oracle/gen_bench_golden.py 5t3 11t3             # weight seeds 5 / 11 with heavy-tailed (Student-t, 3 degrees of freedom) matrices (synth.heavy_tailed)
 
 bench.py's parity leg, tests/test_gpu_model.py::test_cfg2_bench_batch_* and tests/studies/bench_scale_sweep.py compare all 256
 logits of the HIP path with these rows (max|d| / max|ref| over the batch, the north star's metric).  ~2 CPU-minutes per seed on
@@ -43,10 +44,7 @@ def main():
         if f"w{ws}" in have:
             continue
         t0 = time.time()
-        base, _, lvl = str(ws).partition("o")
-        sd = synth.full_state_dict(int(base))
-        if lvl:
-            sd = synth.outlier_channels(sd, int(lvl))
+        sd = synth.variant_state_dict(ws)
         model.load_state_dict({k: t(v) for k, v in sd.items()}, strict=True)
         rows = []
         for b0 in range(0, B, CHUNK):

@@ -203,6 +203,32 @@ def outlier_channels(sd: Dict[str, np.ndarray], level: int = 1) -> Dict[str, np.
                 v = sd[k].copy(); v[77] *= np.float32(50.0); sd[k] = v
     return sd
 
+def heavy_tailed(sd: Dict[str, np.ndarray], seed: int, df: float = 3.0) -> Dict[str, np.ndarray]:
+    """A copy of a state dict whose matrices (every parameter with two or more dimensions) follow a Student-t distribution with `df` degrees of freedom
+    at the variance the normal draw had: each element times sqrt(df / chi2_df) / sqrt(df / (df - 2)), the chi-square draws seeded by (seed, name).  At df = 3
+    one weight in a thousand sits beyond 7 sigma and single weights of a row reach 20-60 sigma - the within-row dynamic range trained checkpoints have and
+    O(1) normal draws do not: what the (hi, lo) split, the per-row scale of the fp8 lo copy and the LayerNorm-fold column sums meet."""
+    assert df > 2
+    out = dict(sd)
+    for k, v in sd.items():
+        if v.ndim >= 2:
+            g = _rng(seed, "t:" + k)
+            out[k] = (v * np.sqrt(df / g.chisquare(df, size=v.shape)) / np.sqrt(df / (df - 2.0))).astype(np.float32)
+    return out
+
+
+def variant_state_dict(key) -> Dict[str, np.ndarray]:
+    """Weights by fixture key: "<seed>" plain, "<seed>o<level>" with massive ViT channels (outlier_channels), "<seed>t<df>" heavy-tailed (heavy_tailed)."""
+    key = str(key)
+    if "o" in key:
+        base, _, lvl = key.partition("o")
+        return outlier_channels(full_state_dict(int(base)), int(lvl))
+    if "t" in key:
+        base, _, df = key.partition("t")
+        return heavy_tailed(full_state_dict(int(base)), int(base), float(df))
+    return full_state_dict(int(key))
+
+
 
 # ---- inputs ---------------------------------------------------------------
 def item_embeddings(seed: int, name: str, *lead: int) -> np.ndarray:
