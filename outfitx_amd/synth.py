@@ -216,10 +216,29 @@ def heavy_tailed(sd: Dict[str, np.ndarray], seed: int, df: float = 3.0) -> Dict[
             out[k] = (v * np.sqrt(df / g.chisquare(df, size=v.shape)) / np.sqrt(df / (df - 2.0))).astype(np.float32)
     return out
 
+def sharp_attention(sd: Dict[str, np.ndarray], factor: float = 3.0) -> Dict[str, np.ndarray]:
+    """A copy of a state dict whose attention logits are factor^2 times larger everywhere: q and k projection weights and biases of both CLIP towers and the
+    q / k thirds of the set transformer's in_proj times `factor`.  Random-init attention is near-uniform (logits of order 0.1-1); trained attention is peaked,
+    and a peaked softmax turns the operand rounding of q and k (2^-11 relative of the logit) into larger probability errors."""
+    out = dict(sd)
+    f = np.float32(factor)
+    for k, v in sd.items():
+        if k.endswith(("q_proj.weight", "q_proj.bias", "k_proj.weight", "k_proj.bias")):
+            out[k] = (v * f).astype(np.float32)
+        elif k.endswith(("in_proj_weight", "in_proj_bias")):
+            w = v.copy(); n = w.shape[0] // 3
+            w[:2 * n] *= f
+            out[k] = w
+    return out
+
 
 def variant_state_dict(key) -> Dict[str, np.ndarray]:
-    """Weights by fixture key: "<seed>" plain, "<seed>o<level>" with massive ViT channels (outlier_channels), "<seed>t<df>" heavy-tailed (heavy_tailed)."""
+    """Weights by fixture key: "<seed>" plain, "<seed>o<level>" with massive ViT channels (outlier_channels), "<seed>t<df>" heavy-tailed (heavy_tailed),
+    "<seed>s<factor>" peaked attention (sharp_attention)."""
     key = str(key)
+    if "s" in key:
+        base, _, fac = key.partition("s")
+        return sharp_attention(full_state_dict(int(base)), float(fac))
     if "o" in key:
         base, _, lvl = key.partition("o")
         return outlier_channels(full_state_dict(int(base)), int(lvl))
