@@ -291,6 +291,29 @@ def pixel_values(seed: int, N: int, name: str = "pixels") -> np.ndarray:
     std = np.asarray(CLIP_STD, np.float32).reshape(1, 3, 1, 1)
     return ((u8.astype(np.float32) * np.float32(1 / 255.0) - mean) / std).astype(np.float32)
 
+def smooth_pixel_values(seed: int, N: int, name: str = "smooth") -> np.ndarray:
+    """[N,3,224,224] fp32 images with the statistics photographs have and uniform noise does not: a per-image background colour, a coarse 7x7 random field
+    upsampled bilinearly (large smooth regions), a few flat rectangles ("garments") and a little sensor noise, quantised to uint8 and put through the same
+    CLIP rescale + normalise as pixel_values.  Neighbouring pixels are strongly correlated, so a 32x32 patch is nearly constant: the patch embedding sees
+    inputs dominated by their common-mode component - the other end of the input distribution from uniform noise."""
+    g = _rng(seed, name)
+    out = np.empty((N, 3, VIT_IMG, VIT_IMG), dtype=np.float32)
+    xs = (np.arange(VIT_IMG) + 0.5) / VIT_IMG * 6.0                     # sample positions in the 7-point coarse grid
+    i0 = np.minimum(xs.astype(np.int64), 5); f = (xs - i0).astype(np.float32)
+    for n in range(N):
+        bg = g.uniform(40, 230, size=(3, 1, 1)).astype(np.float32)
+        coarse = g.normal(0, 35, size=(3, 7, 7)).astype(np.float32)
+        rows = coarse[:, i0, :] * (1 - f)[None, :, None] + coarse[:, i0 + 1, :] * f[None, :, None]          # [3, 224, 7]
+        img = bg + rows[:, :, i0] * (1 - f)[None, None, :] + rows[:, :, i0 + 1] * f[None, None, :]
+        for _ in range(int(g.integers(1, 4))):
+            y0, x0 = (int(v) for v in g.integers(0, 160, size=2)); h, w = (int(v) for v in g.integers(30, 120, size=2))
+            img[:, y0:y0 + h, x0:x0 + w] = g.uniform(0, 255, size=(3, 1, 1)).astype(np.float32)
+        img += g.normal(0, 2.0, size=img.shape).astype(np.float32)
+        out[n] = np.clip(np.rint(img), 0, 255)
+    mean = np.asarray(CLIP_MEAN, np.float32).reshape(1, 3, 1, 1)
+    std = np.asarray(CLIP_STD, np.float32).reshape(1, 3, 1, 1)
+    return ((out * np.float32(1 / 255.0) - mean) / std).astype(np.float32)
+
 
 def token_batch(seed: int, N: int, T: int = 64, n_real=8, name: str = "tokens"):
     """(input_ids [N,T] int64, attention_mask [N,T] int64) shaped like
