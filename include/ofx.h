@@ -271,7 +271,9 @@ int ofx_profile_records(ofx_prof_record* out, int cap);
  *          transpose of rounds 1-3, 2 = as 1 with whole-line stores (8 rows x 128 B per instruction after a DPP row exchange; measured level
  *          with 1: profiles/r04_epilogue_wide_skew.txt).  Bit-identical results.
  * knob 19: experiment, default 0: start skew of gemm_w2f8_kernel's blocks by XCD (v > 0: odd XCDs start v x ~2,000 cycles late, v < 0:
- *          XCD x starts x |v| x ~2,000 cycles late).  Results unchanged; no setting was faster (same file). */
+ *          XCD x starts x |v| x ~2,000 cycles late).  Results unchanged; no setting was faster (same file).
+ * knob 20: validation only, default 0: 1 = a three-product ViT (vit_x3) keeps q | k | v in fp32 and runs the fp32 attention kernel instead of the MFMA attention
+ *          on operand-rounded q | k | v (several times slower; tools/parity_selfcheck.py uses it for its reference run). */
 int ofx_tune(int knob, int value);
 /* A counter that every ofx_tune call bumps, and whether per-launch profiling events are being recorded: the host mirror replays a
  * stream-captured forward (outfitx_amd/graphs.py) only while the counter still has the value it had at capture time and no recording

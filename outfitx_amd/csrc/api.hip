@@ -719,6 +719,8 @@ int g_fuse_qkv = 1;     // ofx_tune(9, v): bit 0 (default on) = ViT layers with 
                         // 8.9e-4 to 1.05e-3 / 1.12e-3, so the default scheme keeps the dual-weight GEMM + attention-kernel pair
 int ofx_launch_fused_qkv_attn(const void* X, const void* Wqkv, const float* bias, const float* row_stat, const float* col_sum, void* out,
                               int n_img, int S, int Wm, int heads, int ldx, int ldo, float scale, int op_dtype, hipStream_t s, bool w2 = false);
+int g_x3_vit_f32_attn = 0;   // ofx_tune(20, v), experiment: 1 = the three-product ViT keeps q | k | v in fp32 and runs the fp32 set attention (as the text tower does) instead of
+                            // the MFMA attention on operand-rounded q | k | v - what the attention core's operand rounding costs under peaked attention
 int g_prune_q = 1;      // ofx_tune(8, v): 1 = the ViT's last layer computes queries for the CLS rows only
 int g_ln_fold = 2;      // ofx_tune(6, v) (default 2): 0 = materialise every LayerNorm, 1 = fold the towers' LayerNorms into the GEMM epilogues,
                         // 2 = fold AND keep the residual stream as an operand-type (hi, lo) pair (no fp32 stream between the layers)
@@ -869,7 +871,7 @@ static int clip_layers(const std::vector<ClipLayer>& Ls, const ClipWs& w, int ro
                        const int* pool_idx, hipStream_t s, bool stats_ready = false, bool pool_first = false, bool x3 = false) {
     if (x3) {
         for (size_t l = 0; l < Ls.size(); ++l)
-            TRY(clip_layer_x3(Ls[l], w, rows, nseq, S, W, MLP, heads, act, eps, causal, key_mask, mask_ld, dt, l + 1 == Ls.size() ? pool_idx : nullptr, s, !causal && !key_mask));
+            TRY(clip_layer_x3(Ls[l], w, rows, nseq, S, W, MLP, heads, act, eps, causal, key_mask, mask_ld, dt, l + 1 == Ls.size() ? pool_idx : nullptr, s, !causal && !key_mask && !g_x3_vit_f32_attn));
         return OFX_OK;
     }
     const bool fold = clip_fold(W);
@@ -1387,6 +1389,7 @@ extern "C" int ofx_tune(int knob, int value) {
         case 17: g_topk_filter = value != 0; return OFX_OK;
         case 18: g_epi_direct = value < 0 ? 0 : (value > 2 ? 2 : value); return OFX_OK;
         case 19: g_w2f8_skew = value; return OFX_OK;
+        case 20: g_x3_vit_f32_attn = value != 0; return OFX_OK;
         case 13: if (value < -8 || value > 8) { ofx_set_error("ofx_tune(13): activation shift out of [-8, 8]"); return OFX_EINVAL; } g_w2_fp8_ashift = value; return OFX_OK;
         default: ofx_set_error("ofx_tune: unknown knob %d", knob); return OFX_EINVAL;
     }

@@ -19,6 +19,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--checkpoint"); ap.add_argument("--weights", default="7"); ap.add_argument("--outfits", type=int, default=256)
     ap.add_argument("--items", type=int, default=8); ap.add_argument("--scheme", default=L.DEFAULT_TOWER_PRECISION)
+    ap.add_argument("--f32-attention", type=int, default=1, help="1 (default): the three-product run also keeps the ViT's q | k | v in fp32 and runs fp32 attention (ofx_tune(20, 1): slow, "
+                    "and 2.5x closer to the reference under peaked attention than the MFMA attention on f16 q | k | v that every timed scheme uses)")
     a = ap.parse_args()
     if a.checkpoint:
         sd = torch.load(a.checkpoint, map_location="cpu")
@@ -31,11 +33,13 @@ def main():
     mask = torch.zeros(a.outfits, a.items, dtype=torch.bool, device="cuda")
     out = {}
     for s in (a.scheme, "f16x3"):
+        L.check(L.load().ofx_tune(20, 1 if (s == "f16x3" and a.f32_attention) else 0))
         m = OutfitX(OutfitXConfig(item_encoder=ItemEncoderConfig(type="clip")), tower_precision=s)
         m.load_state_dict(sd, strict=True); m = m.cuda().eval()
         with torch.no_grad():
             out[s] = m(task=CP, outfit_embedding=None, outfit_mask=mask, encoder_input_dict={"images": px, "texts": tx}).float().cpu().numpy().reshape(-1).astype(np.float64)
         del m; torch.cuda.empty_cache()
+    L.check(L.load().ofx_tune(20, 0))
     d = float(np.abs(out[a.scheme] - out["f16x3"]).max()); r = float(np.abs(out["f16x3"]).max())
     print(f"{a.scheme} vs f16x3 on {a.outfits} outfits x {a.items} items: max|d| {d:.3e}, max|ref| {r:.3f}, max|d| / max|ref| = {d / r:.2e}  (north star's bound vs fp32: 1e-3)")
 
