@@ -447,7 +447,7 @@ def main():
                        "parity_bound": "north star: <= 1e-3 max|d| / max|ref| over the batch on the CP logit vs the fp32 reference path; measured on THIS batch below "
                                        "(parity_rel_err_vs_reference, all logits) and at this batch size on weight seeds 7/44/89/97/99 by "
                                        "tests/test_gpu_model.py::test_cfg2_bench_batch_within_1e3_of_the_reference (+ weights with massive ViT channels); over 100 weight seeds the error is a distribution "
-                                       "(profiles/r04_seed_sweep_bench_scale.json: median 2.5e-4, p90 4.5e-4, worst 6.3e-4, none at or above 8e-4; lognormal fit: P(>= 1e-3) 0.12 % per weight draw)"},
+                                       "(profiles/r04_seed_sweep_bench_scale.json: median 2.5e-4, p90 4.5e-4, worst 6.3e-4, none at or above 8e-4; lognormal fit: P(>= 1e-3) 0.12 % per weight draw); conditional on the random-init network's near-uniform attention: with q, k x 1.5 (logits x 2.25) 4 of 40 weight draws read >= 1e-3 (f16x3: none), DESIGN.md section 2"},
             "roofline": {"bound": "mfma", "kernel": "every dense contraction of the step: " + " / ".join(sorted({t_["kernel"] for t_ in table})),
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
